@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — retriever hot-path benchmark on MI355X (contract: see DESIGN.md "Measurement").
+
+Workload (BASELINE.json configs[1], "WebQSP full index, bge-base-en-v1.5, 1xMI355X brute-force
+top-k", concrete shapes from SURVEY.md §8(d) config 2): a synthetic L2-normalised index of
+N = 2^23 rows x D = 768 f32 (25.8 GB) resident in HBM; one step = one batch of Q = 32 question
+embeddings -> exact cosine top-500 row ids + scores.  With --gpus P > 1 the SAME index is
+row-sharded over the ranks (strong scaling): per-shard top-k, one RCCL all-gather of the packed
+[Q, k] lists, merge on every rank.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
+if REPO_ROOT not in sys.path:
+    sys.path.insert(0, REPO_ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+K_WINDOW = [1, 10, 25, 50, 100, 200, 300, 400, 500]  # configs/window/default.yaml:8
+CHUNK_ROWS = 1 << 16
+EPS = 1e-6
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1 << 23, help="total index rows (all ranks)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=32)
+    ap.add_argument("--k", type=int, default=500)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_shard(dev, row_begin, row_end, D, seed):
+    """Rows [row_begin, row_end) of the global synthetic index, generated chunk-wise on the GPU so
+    that the content of a global row does not depend on the number of ranks.  N(0,1) entries,
+    global row 0 all-zero (eps clamp), 1 % of each chunk's rows duplicated (exact ties)."""
+    from evi_rag_amd import ops
+
+    n = row_end - row_begin
+    shard = torch.empty((n, D), dtype=torch.float32, device=dev)
+    c0 = row_begin // CHUNK_ROWS
+    c1 = (row_end + CHUNK_ROWS - 1) // CHUNK_ROWS
+    gen = torch.Generator(device=dev)
+    for c in range(c0, c1):
+        gen.manual_seed(seed * 1_000_003 + c)
+        chunk = torch.randn((CHUNK_ROWS, D), generator=gen, device=dev, dtype=torch.float32)
+        ndup = CHUNK_ROWS // 100
+        src = torch.randint(1, CHUNK_ROWS, (ndup,), generator=gen, device=dev)
+        dst = torch.randint(1, CHUNK_ROWS, (ndup,), generator=gen, device=dev)
+        chunk[dst] = chunk[src]
+        if c == 0:
+            chunk[0] = 0.0
+        lo = max(row_begin, c * CHUNK_ROWS)
+        hi = min(row_end, (c + 1) * CHUNK_ROWS)
+        shard[lo - row_begin: hi - row_begin] = chunk[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS]
+        del chunk
+    ops.normalize_embeddings(shard, EPS, out=shard)  # C1, in place: the resident index is normalised
+    return shard
+
+
+def gold_row(step, qi, n_total):
+    # global row the query (step, qi) is a noisy copy of; a fixed hash so every rank agrees
+    return (1 + (step * 7919 + qi * 104729) * 2654435761) % n_total
+
+
+def build_queries(dev, shard, row_begin, row_end, n_total, n_batches, Q, D, seed, world):
+    """Each query = normalise(gold index row + 0.5 * noise): Hits@k of the gold row is the
+    size-independent correctness signal at full scale.  The rank that owns the gold row
+    contributes it; an all-reduce SUM assembles the batch on every rank."""
+    from evi_rag_amd import ops
+
+    gold = torch.tensor([[gold_row(s, i, n_total) for i in range(Q)] for s in range(n_batches)], dtype=torch.int64)
+    base = torch.zeros((n_batches, Q, D), dtype=torch.float32, device=dev)
+    mine = (gold >= row_begin) & (gold < row_end)
+    if bool(mine.any()):
+        local = (gold[mine] - row_begin).to(dev)
+        base[mine.to(dev)] = shard.index_select(0, local)
+    if world > 1:
+        dist.all_reduce(base, op=dist.ReduceOp.SUM)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 7 + 12345)
+    noise = torch.randn((n_batches, Q, D), generator=gen, device=dev, dtype=torch.float32)
+    q = base + 0.5 * noise / (D ** 0.5)
+    q = ops.normalize_embeddings(q.view(-1, D), EPS).view(n_batches, Q, D)
+    return q, gold
+
+
+def cpu_baseline(shard, queries, k, n_total, cpu_rows, budget_s):
+    """The oracle's torch-CPU path (normalised matmul + top-k, all host threads) timed on a bounded
+    row sample of the same index, extrapolated linearly in N (the scan is linear in rows)."""
+    from oracle import cpu_baseline as ob
+
+    rows = int(min(cpu_rows, shard.shape[0]))
+    x = shard[:rows].cpu()
+    q = queries[0].cpu()
+    return ob.time_cosine_topk(q, x, k, n_total=n_total, budget_s=budget_s)
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from evi_rag_amd import _lib, ops
+
+    lib = _lib.load()
+    N, D, Q, k = args.rows, args.dim, args.queries, args.k
+    row_begin = N * rank // world
+    row_end = N * (rank + 1) // world
+    shard = build_shard(dev, row_begin, row_end, D, args.seed)
+    n_batches = args.warmup + args.steps
+    queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, args.seed, world)
+    ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
+    gather_s = torch.empty((world, Q, k), dtype=torch.float32, device=dev) if world > 1 else None
+    gather_i = torch.empty((world, Q, k), dtype=torch.int64, device=dev) if world > 1 else None
+
+    def step(b):
+        s, i = ops.cosine_topk(queries[b], shard, k, row_id_base=row_begin, workspace=ws)
+        if world > 1:
+            dist.all_gather_into_tensor(gather_s, s)
+            dist.all_gather_into_tensor(gather_i, i)
+            s, i = ops.topk_merge(gather_s, gather_i)
+        return s, i
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for b in range(args.warmup):
+        step(b)
+    fence()
+    lib.evi_timing_enable(1)
+    t0 = time.perf_counter()
+    out = None
+    for b in range(args.warmup, n_batches):
+        out = step(b)
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.evi_timing_enable(0)
+    import ctypes
+
+    ms = (ctypes.c_double * 2)()
+    launches = (ctypes.c_int32 * 2)()
+    _lib.check(lib.evi_timing_read(ms, launches, 2))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
+    s_last, i_last = out
+    g = gold[n_batches - 1].to(dev).view(Q, 1)
+    rank_of_gold = torch.where((i_last == g).any(dim=1), (i_last == g).float().argmax(dim=1), torch.full((Q,), 10 ** 9, device=dev))
+    hits = {f"hits@{kk}": float((rank_of_gold < kk).float().mean().item()) for kk in K_WINDOW if kk <= k}
+    sorted_ok = bool((s_last[:, 1:] <= s_last[:, :-1]).all().item())
+
+    if rank == 0:
+        steps = args.steps
+        shard_rows = row_end - row_begin
+        bytes_per_step = shard_rows * D * 4 + Q * D * 4 + Q * k * 12
+        score_ms_per_step = ms[0] / steps
+        achieved = bytes_per_step / (score_ms_per_step * 1e-3) / 1e9 if score_ms_per_step > 0 else 0.0
+        result = {
+            "metric": "queries/sec",
+            "value": Q * steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k",
+                "index_rows": N,
+                "dim": D,
+                "queries_per_step": Q,
+                "k": k,
+                "index_dtype": "f32",
+                "sharding": f"rows/{world}" if world > 1 else "none",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "k_cosine_score",
+                "algorithmic_bytes_per_step": bytes_per_step,
+                "launches_per_step": launches[0] / steps,
+                "kernel_ms_per_step": score_ms_per_step,
+                "select_ms_per_step": ms[1] / steps,
+            },
+            "hits_at_k": hits,
+            "sorted_ok": sorted_ok,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(shard, queries, k, N, args.cpu_rows, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""ctypes binding of libevi_hip.so (the C-ABI declared in include/evi_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol the header
+declares is absent, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from typing import Dict, List, Optional
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libevi_hip.so")
+HEADER_PATH = os.path.join(REPO_ROOT, "include", "evi_hip.h")
+
+EVI_OK = 0
+EVI_ERR_INVALID = -22
+EVI_ERR_NOMEM = -12
+EVI_ERR_HIP = -5
+EVI_ERR_UNSUPPORTED = -95
+EVI_TOPK_MAX_K = 2048
+
+_P = c_void_p
+
+# name -> (restype, argtypes)
+_SIGNATURES = {
+    "evi_version": (c_int, []),
+    "evi_last_error": (c_size_t, [c_char_p, c_size_t]),
+    "evi_timing_enable": (c_int, [c_int]),
+    "evi_timing_read": (c_int, [_P, _P, c_int]),
+    "evi_row_inv_norm": (c_int, [_P, c_int64, c_int, c_float, _P, _P]),
+    "evi_row_normalize": (c_int, [_P, c_int64, c_int, c_float, _P, _P]),
+    "evi_cosine_topk_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
+    "evi_cosine_topk_min_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
+    "evi_cosine_topk": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "evi_topk_merge": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "evi_segment_topk": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class EviLibraryError(RuntimeError):
+    """The HIP extension is missing or incomplete."""
+
+
+def header_symbols(header_path: str = HEADER_PATH) -> List[str]:
+    """Every function name include/evi_hip.h declares."""
+    with open(header_path, "r", encoding="utf-8") as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(evi_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EviLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C evi-rag_amd/csrc` (there is no CPU fallback)."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise EviLibraryError(f"{LIB_PATH} does not export {name}; rebuild the extension.") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.evi_version() != 1:
+        raise EviLibraryError(f"ABI version mismatch: library {lib.evi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    lib = load()
+    buf = ctypes.create_string_buffer(2048)
+    lib.evi_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status: int) -> None:
+    """Map a status code to the reference's exception conventions."""
+    if status == EVI_OK:
+        return
+    msg = last_error() or f"evi_hip status {status}"
+    if status == EVI_ERR_INVALID:
+        raise ValueError(msg)
+    if status == EVI_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if status == EVI_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def bound_symbols() -> Dict[str, tuple]:
+    return dict(_SIGNATURES)

@@ -1,0 +1,189 @@
+// Shared host/device helpers for the evi_hip library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/evi_hip.h"
+
+namespace evi {
+
+// ---- error plumbing -------------------------------------------------------------------------
+std::string& last_error_ref();
+int fail(int code, const char* fmt, ...);
+
+#define EVI_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return ::evi::fail(EVI_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define EVI_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            return ::evi::fail(EVI_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                               hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+#define EVI_LAUNCH_CHECK()                                                               \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess)                                                            \
+            return ::evi::fail(EVI_ERR_HIP, "kernel launch failed: %s (%s:%d)",          \
+                               hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------
+// When enabled, launch sites bracket their dominant kernel with hipEvents on the call's stream;
+// evi_timing_read() synchronises those events and returns the summed durations per class.
+enum TimingClass { kTimeCosineScore = 0, kTimeSelect = 1, kTimeClasses = 8 };
+bool timing_enabled();
+// Records a start event on `st`; returns a token (or -1 when timing is off).
+int timing_begin(int cls, hipStream_t st);
+void timing_end(int token, hipStream_t st);
+
+// ---- ordered keys ---------------------------------------------------------------------------
+// A 64-bit key whose unsigned order is the ranking order used everywhere in this library:
+// larger score first, then smaller index first.  -0.0 ranks with +0.0; NaN ranks above +inf
+// (torch.topk's convention).  key 0 is reserved for padding: it is smaller than any real key
+// (the smallest real high word is that of -inf = 0x007FFFFF).
+__host__ __device__ inline uint32_t float_to_ordered(float f) {
+    if (f != f) return 0xFFFFFFFFu;
+    f += 0.0f;  // -0.0 -> +0.0
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    __builtin_memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ordered_to_float(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+__host__ __device__ inline uint64_t make_key(float score, uint32_t index) {
+    return ((uint64_t)float_to_ordered(score) << 32) | (uint64_t)(0xFFFFFFFFu - index);
+}
+__host__ __device__ inline float key_score(uint64_t key) { return ordered_to_float((uint32_t)(key >> 32)); }
+__host__ __device__ inline uint32_t key_index(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)key; }
+
+// ---- block-wide exact top-k -----------------------------------------------------------------
+constexpr int kSelectThreads = 1024;
+constexpr int kSortCap = 8192;  // keys a block can sort in LDS (64 KiB)
+
+struct SelectShared {
+    uint64_t keys[kSortCap];
+    uint32_t hist[256];
+    uint32_t scalar[4];  // [0] gathered count, [1] chosen digit, [2] keys above digit, [3] spare
+};
+
+__device__ inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Sorts sh.keys[0..n_pow2) descending (n_pow2 a power of two <= kSortCap). All threads call.
+__device__ inline void block_bitonic_sort_desc(SelectShared& sh, int n_pow2) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (n_pow2 >> 1); t += nt) {
+                int i = 2 * t - (t & (stride - 1));
+                int j = i + stride;
+                uint64_t a = sh.keys[i], b = sh.keys[j];
+                bool desc = ((i & size) == 0);
+                bool swap = desc ? (a < b) : (a > b);
+                if (swap) {
+                    sh.keys[i] = b;
+                    sh.keys[j] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Exact top-k of `cnt` distinct keys produced by load(i), i in [0, cnt).  On return
+// sh.keys[0..m) holds the m = min(cnt, k) largest keys in descending order (visible to all
+// threads).  k <= EVI_TOPK_MAX_K <= kSortCap.  Keys equal to 0 are padding and sort last.
+//
+// cnt <= kSortCap: one bitonic sort in LDS.  Otherwise an MSB-first 8-bit radix select narrows
+// the keys to the k-th largest key's bucket until the survivors fit in LDS, then sorts those.
+template <class Load>
+__device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (cnt <= 0) return 0;
+    if (cnt <= kSortCap) {
+        int p2 = next_pow2((int)cnt);
+        for (int i = tid; i < p2; i += nt) sh.keys[i] = (i < cnt) ? load(i) : 0ull;
+        block_bitonic_sort_desc(sh, p2);
+        return (int)(cnt < k ? cnt : k);
+    }
+    // Radix select.  Invariant: exactly `above` keys are > every key matching (prefix, mask),
+    // and the k-th largest key matches (prefix, mask).
+    uint64_t prefix = 0, mask = 0;
+    uint32_t above = 0;
+    for (int pass = 7; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int i = tid; i < 256; i += nt) sh.hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < cnt; i += nt) {
+            uint64_t key = load(i);
+            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFF], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t need = (uint32_t)k - above;  // rank of the k-th key inside the matching set
+            uint32_t acc = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + sh.hist[d] >= need) break;
+                acc += sh.hist[d];
+            }
+            sh.scalar[1] = (uint32_t)d;
+            sh.scalar[2] = acc;
+        }
+        __syncthreads();
+        const uint32_t d = sh.scalar[1];
+        const uint32_t in_bucket = sh.hist[d];
+        above += sh.scalar[2];
+        prefix |= (uint64_t)d << shift;
+        mask |= 0xFFull << shift;
+        __syncthreads();
+        // Survivors = keys above the bucket + keys in the bucket. If they fit, sort them.
+        if (above + in_bucket <= (uint32_t)kSortCap || pass == 0) {
+            if (tid == 0) sh.scalar[0] = 0;
+            __syncthreads();
+            for (int64_t i = tid; i < cnt; i += nt) {
+                uint64_t key = load(i);
+                if ((key & mask) >= prefix) {
+                    uint32_t pos = atomicAdd(&sh.scalar[0], 1u);
+                    if (pos < (uint32_t)kSortCap) sh.keys[pos] = key;
+                }
+            }
+            __syncthreads();
+            int got = (int)sh.scalar[0];
+            if (got > kSortCap) got = kSortCap;  // unreachable for distinct keys
+            int p2 = next_pow2(got);
+            for (int i = got + tid; i < p2; i += nt) sh.keys[i] = 0ull;
+            block_bitonic_sort_desc(sh, p2);
+            return got < k ? got : k;
+        }
+    }
+    return 0;  // unreachable
+}
+
+}  // namespace evi

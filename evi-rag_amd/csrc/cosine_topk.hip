@@ -1,0 +1,369 @@
+// Dense query x index cosine top-k for gfx950 (MI355X).
+//
+// Replaces (generalised from per-group arg-max to a global top-k) the arithmetic of
+//   _normalize_embeddings + index_select + torch.mv + argmax
+//   reference: scripts/build_retrieval_pipeline.py:833-837, 856-874.
+//
+// Data path
+//   The index [N, D] f32 lives in HBM and is streamed exactly once per batch of <= 32 queries.
+//   Each wave owns 16 index rows at a time and loads them straight into MFMA B-fragments
+//   (lane (n = l&15, g = l>>4) reads 16 B of row n at column 16 j + 4 g): no LDS round trip for
+//   the stream, which no other wave reuses.  The <= 32 queries are pre-fragmented once into the
+//   A-operand order and parked in LDS for the whole launch (D * 128 B: 96 KiB at D = 768).
+//   v_mfma_f32_16x16x4_f32 computes the [32 queries x 16 rows] block as an exact f32 FMA chain
+//   in a fixed order of d, so a row's score never depends on where the row sits.
+//
+// Selection (exact)
+//   Rows are scanned in segments of geometrically growing length.  The first segment writes its
+//   scores densely; every later segment appends only rows whose score reaches the query's current
+//   k-th best (tau), through a per-query atomic cursor.  After each segment one workgroup per
+//   query selects the exact top-k of its candidate list (LDS bitonic sort, with an 8-bit radix
+//   select in front when the list exceeds 8192 keys) and raises tau.  The candidate buffer holds
+//   k + segment_rows entries, so it cannot overflow for any data (e.g. an index sorted by score).
+//
+// Bound: HBM.  Algorithmic bytes per batch = N*D*4 + N*4 (row_scale, optional) + Q*D*4 + Q*k*12.
+#include "common.hpp"
+
+namespace evi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kScoreThreads = 512;            // 8 waves, 2 per SIMD
+constexpr int kWavesPerBlock = kScoreThreads / 64;
+constexpr int kQueryBlock = 32;               // queries per pass over the index
+constexpr int64_t kFirstSegment = 8192;       // dense segment (fits one LDS sort)
+constexpr int64_t kSegmentGrowth = 8;
+constexpr int64_t kMaxSegmentDefault = 1 << 21;
+
+// q [Q, D] -> qfrag[((j*4 + g) * (NQB*16) + i) * 4 + t] = q[i][16 j + 4 g + t], zero for i >= Q.
+__global__ void k_query_fragments(const float* __restrict__ q, int Q, int D, int nq_pad,
+                                  float* __restrict__ qfrag) {
+    const int total = (D / 16) * 4 * nq_pad;  // float4 slots
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        const int i = s % nq_pad;
+        const int jg = s / nq_pad;  // j*4 + g
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < Q) v = *reinterpret_cast<const float4*>(q + (int64_t)i * D + jg * 4);
+        reinterpret_cast<float4*>(qfrag)[s] = v;
+    }
+}
+
+__global__ void k_init_state(float* tau, int32_t* cnt, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        tau[i] = -INFINITY;
+        cnt[i] = 0;
+    }
+}
+
+// One pass over rows [seg_begin, seg_end) of the shard.
+//   NQB: query blocks of 16 (1 or 2).  U: float4 loads in flight per lane per prefetch group
+//   (U divides D/16).
+template <int NQB, int U>
+__global__ __launch_bounds__(kScoreThreads) void k_cosine_score(
+    const float* __restrict__ qfrag, const float* __restrict__ idx, int64_t seg_begin,
+    int64_t seg_end, int D, int Q, const float* __restrict__ row_scale,
+    const float* __restrict__ tau, float* __restrict__ cand_score, int32_t* __restrict__ cand_id,
+    int32_t* __restrict__ cand_cnt, int64_t cap, int dense) {
+    extern __shared__ float4 lds_q[];  // [(D/16)*4][NQB*16] float4
+    constexpr int NQ = NQB * 16;
+    const int tid = threadIdx.x;
+    const int chunks = D / 16;
+    {
+        const int total = chunks * 4 * NQ;
+        const float4* src = reinterpret_cast<const float4*>(qfrag);
+        for (int s = tid; s < total; s += kScoreThreads) lds_q[s] = src[s];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float tq[NQB][4];
+#pragma unroll
+    for (int b = 0; b < NQB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = b * 16 + 4 * g + r;
+            tq[b][r] = (dense || qi >= Q) ? -INFINITY : tau[qi];
+        }
+
+    const int64_t seg_rows = seg_end - seg_begin;
+    const int64_t tiles = (seg_rows + 15) / 16;
+    const int groups = chunks / U;
+    const float4* lq = lds_q + g * NQ + n;  // + (j*4)*NQ + b*16
+
+    for (int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave; t < tiles;
+         t += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t row = seg_begin + t * 16 + n;
+        const int64_t rowc = row < seg_end ? row : seg_end - 1;
+        const float4* xp = reinterpret_cast<const float4*>(idx + rowc * (int64_t)D) + g;
+
+        f32x4 acc[NQB];
+#pragma unroll
+        for (int b = 0; b < NQB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float4 xcur[U], xnext[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xcur[u] = xp[u * 4];
+        for (int gi = 0; gi < groups; ++gi) {
+            if (gi + 1 < groups) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xnext[u] = xp[((gi + 1) * U + u) * 4];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = gi * U + u;
+                float4 a[NQB];
+#pragma unroll
+                for (int b = 0; b < NQB; ++b) a[b] = lq[(j * 4) * NQ + b * 16];
+                const float xb[4] = {xcur[u].x, xcur[u].y, xcur[u].z, xcur[u].w};
+#pragma unroll
+                for (int b = 0; b < NQB; ++b) {
+                    const float ab[4] = {a[b].x, a[b].y, a[b].z, a[b].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[e], xb[e], acc[b], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xcur[u] = xnext[u];
+        }
+
+        if (row < seg_end) {
+            const float scale = row_scale ? row_scale[row] : 1.0f;
+#pragma unroll
+            for (int b = 0; b < NQB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = b * 16 + 4 * g + r;
+                    if (qi >= Q) continue;
+                    const float s = row_scale ? acc[b][r] * scale : acc[b][r];
+                    if (dense) {
+                        const int64_t pos = row - seg_begin;
+                        cand_score[qi * cap + pos] = s;
+                        cand_id[qi * cap + pos] = (int32_t)row;
+                    } else if (s >= tq[b][r] || s != s) {
+                        const int32_t pos = atomicAdd(&cand_cnt[qi], 1);
+                        cand_score[qi * cap + pos] = s;
+                        cand_id[qi * cap + pos] = (int32_t)row;
+                    }
+                }
+        }
+    }
+}
+
+// One workgroup per query: exact top-k of its candidate list, written back sorted to the head of
+// the list; raises tau to the k-th score.  The last call of a batch also writes the outputs.
+__global__ __launch_bounds__(kSelectThreads) void k_candidates_select(
+    float* __restrict__ cand_score, int32_t* __restrict__ cand_id, int32_t* __restrict__ cand_cnt,
+    float* __restrict__ tau, int64_t cap, int k, int64_t dense_count, int final_pass,
+    int64_t row_id_base, float* __restrict__ out_score, int64_t* __restrict__ out_index) {
+    __shared__ SelectShared sh;
+    const int qi = blockIdx.x;
+    const float* cs = cand_score + qi * cap;
+    const int32_t* ci = cand_id + qi * cap;
+    const int64_t cnt = dense_count >= 0 ? dense_count : (int64_t)cand_cnt[qi];
+    auto load = [&](int64_t i) -> uint64_t { return make_key(cs[i], (uint32_t)ci[i]); };
+    const int m = block_topk(sh, load, cnt, k);
+    // block_topk ends on a barrier: every read of the old list is done before it is overwritten.
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint64_t key = sh.keys[i];
+        cand_score[qi * cap + i] = key_score(key);
+        cand_id[qi * cap + i] = (int32_t)key_index(key);
+    }
+    if (threadIdx.x == 0) {
+        cand_cnt[qi] = m;
+        if (m == k) tau[qi] = key_score(sh.keys[k - 1]);
+    }
+    if (final_pass) {
+        for (int i = threadIdx.x; i < k; i += blockDim.x) {
+            if (i < m) {
+                const uint64_t key = sh.keys[i];
+                out_score[(int64_t)qi * k + i] = key_score(key);
+                out_index[(int64_t)qi * k + i] = row_id_base + (int64_t)key_index(key);
+            } else {
+                out_score[(int64_t)qi * k + i] = -INFINITY;
+                out_index[(int64_t)qi * k + i] = -1;
+            }
+        }
+    }
+}
+
+struct WsLayout {
+    size_t qfrag_off, tau_off, cnt_off, score_off, id_off, total;
+    int64_t cap;
+};
+
+static WsLayout ws_layout(int D, int k, int64_t seg_max) {
+    WsLayout w;
+    size_t off = 0;
+    w.qfrag_off = off;
+    off = align_up(off + (size_t)D * kQueryBlock * sizeof(float), 256);
+    w.tau_off = off;
+    off = align_up(off + kQueryBlock * sizeof(float), 256);
+    w.cnt_off = off;
+    off = align_up(off + kQueryBlock * sizeof(int32_t), 256);
+    w.cap = seg_max + k;
+    w.score_off = off;
+    off = align_up(off + (size_t)kQueryBlock * w.cap * sizeof(float), 256);
+    w.id_off = off;
+    off = align_up(off + (size_t)kQueryBlock * w.cap * sizeof(int32_t), 256);
+    w.total = off;
+    return w;
+}
+
+static int64_t clamp_seg(int64_t N, int64_t want) {
+    int64_t s = N < want ? N : want;
+    return s < 1 ? 1 : s;
+}
+
+template <int NQB, int U>
+static int launch_score(int grid, size_t lds, hipStream_t st, const float* qfrag, const float* idx,
+                        int64_t b, int64_t e, int D, int Q, const float* row_scale, const float* tau,
+                        float* cs, int32_t* ci, int32_t* cc, int64_t cap, int dense) {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cosine_score<NQB, U>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_cosine_score<NQB, U>), dim3(grid), dim3(kScoreThreads), lds, st, qfrag, idx,
+                       b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+template <int NQB>
+static int launch_score_u(int U, int grid, size_t lds, hipStream_t st, const float* qfrag,
+                          const float* idx, int64_t b, int64_t e, int D, int Q, const float* row_scale,
+                          const float* tau, float* cs, int32_t* ci, int32_t* cc, int64_t cap,
+                          int dense) {
+    switch (U) {
+        case 8: return launch_score<NQB, 8>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+        case 4: return launch_score<NQB, 4>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+        case 2: return launch_score<NQB, 2>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+        default: return launch_score<NQB, 1>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+    }
+}
+
+static int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace evi
+
+using namespace evi;
+
+extern "C" size_t evi_cosine_topk_workspace_bytes(int Q, int64_t N, int D, int k) {
+    (void)Q;
+    if (D <= 0 || k <= 0 || N < 0) return 0;
+    return ws_layout(D, k, clamp_seg(N, kMaxSegmentDefault)).total;
+}
+
+extern "C" size_t evi_cosine_topk_min_workspace_bytes(int Q, int64_t N, int D, int k) {
+    (void)Q;
+    if (D <= 0 || k <= 0 || N < 0) return 0;
+    return ws_layout(D, k, clamp_seg(N, kFirstSegment)).total;
+}
+
+extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t N, int D,
+                               const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                               int64_t* out_index, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    EVI_REQUIRE(Q >= 1, "evi_cosine_topk: Q must be >= 1, got %d", Q);
+    EVI_REQUIRE(N >= 0, "evi_cosine_topk: N must be >= 0, got %lld", (long long)N);
+    EVI_REQUIRE(N < (int64_t)0x7FFFFFFF, "evi_cosine_topk: a shard holds at most 2^31-1 rows, got %lld",
+                (long long)N);
+    EVI_REQUIRE(k >= 1 && k <= EVI_TOPK_MAX_K, "evi_cosine_topk: k must be in [1, %d], got %d",
+                EVI_TOPK_MAX_K, k);
+    EVI_REQUIRE(q && out_score && out_index, "evi_cosine_topk: null q/out pointer");
+    EVI_REQUIRE(N == 0 || idx, "evi_cosine_topk: null idx with N > 0");
+    if (D < 16 || D % 16 != 0 || D > 1280)
+        return fail(EVI_ERR_UNSUPPORTED,
+                    "evi_cosine_topk: D must be a multiple of 16 in [16, 1280], got %d", D);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    const size_t min_ws = evi_cosine_topk_min_workspace_bytes(Q, N, D, k);
+    EVI_REQUIRE(workspace != nullptr, "evi_cosine_topk: null workspace");
+    if (workspace_bytes < min_ws)
+        return fail(EVI_ERR_NOMEM, "evi_cosine_topk: workspace %zu B < minimum %zu B", workspace_bytes,
+                    min_ws);
+    // Largest segment the workspace can hold (halve until it fits).
+    int64_t seg_max = clamp_seg(N, kMaxSegmentDefault);
+    while (seg_max > kFirstSegment && ws_layout(D, k, seg_max).total > workspace_bytes) seg_max >>= 1;
+    if (seg_max < clamp_seg(N, kFirstSegment)) seg_max = clamp_seg(N, kFirstSegment);
+    const WsLayout w = ws_layout(D, k, seg_max);
+    char* base = static_cast<char*>(workspace);
+    float* qfrag = reinterpret_cast<float*>(base + w.qfrag_off);
+    float* tau = reinterpret_cast<float*>(base + w.tau_off);
+    int32_t* cnt = reinterpret_cast<int32_t*>(base + w.cnt_off);
+    float* cs = reinterpret_cast<float*>(base + w.score_off);
+    int32_t* ci = reinterpret_cast<int32_t*>(base + w.id_off);
+
+    const int chunks = D / 16;
+    const int U = (chunks % 8 == 0) ? 8 : (chunks % 4 == 0) ? 4 : (chunks % 2 == 0) ? 2 : 1;
+    const int cus = device_cu_count();
+
+    for (int q0 = 0; q0 < Q; q0 += kQueryBlock) {
+        const int qn = (Q - q0) < kQueryBlock ? (Q - q0) : kQueryBlock;
+        const int nqb = qn <= 16 ? 1 : 2;
+        const int nq_pad = nqb * 16;
+        float* o_score = out_score + (int64_t)q0 * k;
+        int64_t* o_index = out_index + (int64_t)q0 * k;
+
+        hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, st, tau, cnt, kQueryBlock);
+        EVI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_query_fragments, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D,
+                           nq_pad, qfrag);
+        EVI_LAUNCH_CHECK();
+
+        if (N == 0) {
+            hipLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, cs, ci, cnt,
+                               tau, w.cap, k, (int64_t)0, 1, row_id_base, o_score, o_index);
+            EVI_LAUNCH_CHECK();
+            continue;
+        }
+        const size_t lds = (size_t)chunks * 4 * nq_pad * sizeof(float4);
+        int64_t begin = 0;
+        int64_t seg = clamp_seg(N, kFirstSegment);
+        bool first = true;
+        while (begin < N) {
+            int64_t end = begin + seg;
+            if (end > N) end = N;
+            const int64_t tiles = (end - begin + 15) / 16;
+            int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+            const int grid = (int)(want < cus ? want : cus);
+            int rc;
+            const int tok = timing_begin(kTimeCosineScore, st);
+            if (nqb == 1)
+                rc = launch_score_u<1>(U, grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau, cs,
+                                       ci, cnt, w.cap, first ? 1 : 0);
+            else
+                rc = launch_score_u<2>(U, grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau, cs,
+                                       ci, cnt, w.cap, first ? 1 : 0);
+            timing_end(tok, st);
+            if (rc != EVI_OK) return rc;
+            const int final_pass = end >= N ? 1 : 0;
+            const int tok2 = timing_begin(kTimeSelect, st);
+            hipLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, cs, ci, cnt,
+                               tau, w.cap, k, first ? (end - begin) : (int64_t)-1, final_pass,
+                               row_id_base, o_score, o_index);
+            timing_end(tok2, st);
+            EVI_LAUNCH_CHECK();
+            begin = end;
+            first = false;
+            int64_t next = begin * kSegmentGrowth;
+            seg = next < seg_max ? next : seg_max;
+            if (seg < 1) seg = 1;
+        }
+    }
+    return EVI_OK;
+}

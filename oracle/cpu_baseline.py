@@ -1,0 +1,45 @@
+"""Timed CPU leg for bench.py's `cpu_baseline` (oracle; test infrastructure only).
+
+The reference's arithmetic for this path is torch on the CPU (normalised rows, `torch.mv` /
+matmul, then top-k: scripts/build_retrieval_pipeline.py:833-837, 868-873), so the port is timed
+with torch's own multi-threaded CPU kernels on a bounded row sample and scaled linearly in rows.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict
+
+import torch
+
+
+def time_cosine_topk(q: torch.Tensor, x: torch.Tensor, k: int, *, n_total: int, budget_s: float = 12.0) -> Dict:
+    """q [Q, D], x [rows, D] (both already L2-normalised, CPU f32).  Returns the bench JSON object."""
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    Q = q.shape[0]
+    rows = x.shape[0]
+    kk = min(k, rows)
+
+    def one():
+        scores = q @ x.T
+        return torch.topk(scores, kk, dim=1, largest=True, sorted=True)
+
+    one()  # warm-up
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or iters >= 200:
+            break
+    per_iter = dt / iters
+    full = per_iter * (n_total / rows)
+    return {
+        "value": Q / full,
+        "unit": "queries/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": (f"torch-CPU f32 matmul+topk on the first {rows} of {n_total} index rows, Q={Q}, k={kk}, "
+                   f"{iters} iters, {per_iter * 1e3:.1f} ms/iter, scaled x{n_total / rows:.1f} in rows"),
+    }

@@ -1,0 +1,198 @@
+"""GPU parity: evi_cosine_topk / evi_row_normalize / evi_topk_merge / evi_segment_topk vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cosine as ocos
+from oracle import ranking as orank
+from tests.helpers import check_topk_against_scores
+
+pytestmark = pytest.mark.gpu
+
+EPS = 1e-6
+
+
+def _make_index(n, d, seed, dup_frac=0.01):
+    """N(0,1) rows, row 0 all-zero (eps clamp), 1 % duplicated rows (ties)."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    if n > 0:
+        x[0] = 0.0
+    ndup = int(n * dup_frac)
+    if ndup > 0 and n > 2:
+        src = rng.integers(1, n, size=ndup)
+        dst = rng.integers(1, n, size=ndup)
+        x[dst] = x[src]
+    return x
+
+
+@pytest.mark.parametrize("n,d", [(1, 16), (5, 64), (1000, 384), (4097, 768)])
+def test_row_normalize_matches_oracle(dev, n, d):
+    from evi_rag_amd import ops
+
+    x = _make_index(n, d, seed=n + d)
+    got = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS).cpu().numpy()
+    ref = ocos.normalize_embeddings(x, EPS)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-7)
+    assert np.all(got[0] == 0.0)  # zero rows stay zero rows (clamp on the norm)
+    inv = ops.row_inv_norm(torch.from_numpy(x).to(dev), EPS).cpu().numpy()
+    np.testing.assert_allclose(inv, ocos.row_inv_norm(x, EPS), rtol=2e-6)
+    assert inv[0] == np.float32(1.0 / EPS)
+
+
+def test_row_normalize_empty_passthrough(dev):
+    from evi_rag_amd import ops
+
+    e = torch.empty((0, 0), device=dev)
+    assert ops.normalize_embeddings(e, EPS) is e  # reference :834-835
+
+
+@pytest.mark.parametrize(
+    "Q,N,D,k",
+    [
+        (32, 1000, 384, 100),    # BASELINE config 1 (toy)
+        (1, 1, 16, 1),           # smallest
+        (3, 7, 16, 10),          # N < k: padding
+        (16, 300, 64, 500),      # one query block, k > N
+        (17, 5000, 128, 50),     # two query blocks, ragged
+        (33, 9000, 768, 500),    # > 32 queries: two passes; > first dense segment
+        (32, 70000, 768, 500),   # several filtered segments
+        (8, 20000, 1024, 2048),  # max k, radix-select path in later segments
+        (5, 12345, 1280, 7),     # max D, N not a multiple of 16
+        (4, 10000, 48, 64),      # D/16 odd (U = 1 path)
+    ],
+)
+def test_cosine_topk_matches_oracle(dev, Q, N, D, k):
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N * 7 + D)
+    rng = np.random.default_rng(Q + 13)
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    if Q > 2:
+        q[1] = 0.0  # a zero query: all scores tie at 0 -> pure id order
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    sc, ids = ops.cosine_topk(qn, xn, k, row_id_base=1000)
+    torch.cuda.synchronize()
+    ref_full = ocos.cosine_scores(q, x, EPS)  # reference arithmetic: normalise, then matmul
+    check_topk_against_scores(sc.cpu().numpy(), ids.cpu().numpy(), ref_full, k, id_base=1000)
+    if Q > 2:
+        m = min(k, N)
+        assert np.array_equal(ids[1, :m].cpu().numpy(), np.arange(m) + 1000)
+
+
+def test_cosine_topk_row_scale_equals_prenormalised(dev):
+    """raw index + row_scale (fused normalisation) returns the same ids as a normalised index."""
+    from evi_rag_amd import ops
+
+    N, D, Q, k = 30000, 768, 32, 500
+    x = _make_index(N, D, seed=5)
+    q = np.random.default_rng(6).standard_normal((Q, D), dtype=np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    sc, ids = ops.cosine_topk(qn, xd, k, row_scale=ops.row_inv_norm(xd, EPS))
+    ref_full = ocos.cosine_scores(q, x, EPS)
+    check_topk_against_scores(sc.cpu().numpy(), ids.cpu().numpy(), ref_full, k)
+
+
+def test_cosine_topk_sorted_index_worst_case(dev):
+    """Adversarial order: every later row beats every earlier one, so every row passes the filter."""
+    from evi_rag_amd import ops
+
+    N, D, k = 50000, 64, 100
+    base = np.zeros((N, D), dtype=np.float32)
+    base[:, 0] = 1.0
+    base[:, 1] = np.linspace(-1.0, 1.0, N, dtype=np.float32)  # cosine with e1 increases with row id
+    q = np.zeros((2, D), dtype=np.float32)
+    q[0, 1] = 1.0
+    q[1, 1] = -1.0
+    xn = ops.normalize_embeddings(torch.from_numpy(base).to(dev), EPS)
+    qn = torch.from_numpy(q).to(dev)
+    sc, ids = ops.cosine_topk(qn, xn, k)
+    ids = ids.cpu().numpy()
+    assert np.array_equal(ids[0], np.arange(N - 1, N - 1 - k, -1))
+    assert np.array_equal(ids[1], np.arange(k))
+
+
+def test_cosine_topk_small_workspace_same_result(dev):
+    """A minimum-size workspace only changes the segment schedule, never the result."""
+    from evi_rag_amd import _lib, ops
+
+    N, D, Q, k = 40000, 384, 32, 300
+    x = _make_index(N, D, seed=11)
+    q = np.random.default_rng(12).standard_normal((Q, D), dtype=np.float32)
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    s1, i1 = ops.cosine_topk(qn, xn, k)
+    small = int(_lib.load().evi_cosine_topk_min_workspace_bytes(Q, N, D, k))
+    ws = torch.empty(small, dtype=torch.uint8, device=dev)
+    s2, i2 = ops.cosine_topk(qn, xn, k, workspace=ws)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    with pytest.raises(MemoryError):
+        ops.cosine_topk(qn, xn, k, workspace=ws[: small // 2])
+
+
+def test_cosine_topk_rejects_bad_shapes(dev):
+    from evi_rag_amd import ops
+
+    q = torch.zeros((2, 24), device=dev)
+    x = torch.zeros((4, 24), device=dev)
+    with pytest.raises(NotImplementedError):
+        ops.cosine_topk(q, x, 2)  # D % 16 != 0
+    q = torch.zeros((2, 32), device=dev)
+    x = torch.zeros((4, 32), device=dev)
+    with pytest.raises(ValueError):
+        ops.cosine_topk(q, x, 0)
+    with pytest.raises(ValueError):
+        ops.cosine_topk(q, x, 5000)
+
+
+def test_sharded_topk_merge_equals_single_shard(dev):
+    """Row-sharding invariance: per-shard top-k + merge == one-shard top-k, bit-exact."""
+    from evi_rag_amd import ops
+
+    N, D, Q, k, P = 36000, 768, 32, 500, 4
+    x = _make_index(N, D, seed=21)
+    q = np.random.default_rng(22).standard_normal((Q, D), dtype=np.float32)
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    s_all, i_all = ops.cosine_topk(qn, xn, k)
+    bounds = [N * r // P for r in range(P + 1)]
+    parts = [ops.cosine_topk(qn, xn[bounds[r]:bounds[r + 1]], k, row_id_base=bounds[r]) for r in range(P)]
+    ss = torch.stack([p[0] for p in parts])
+    ii = torch.stack([p[1] for p in parts])
+    s_m, i_m = ops.topk_merge(ss, ii)
+    assert torch.equal(i_m, i_all)
+    assert torch.equal(s_m, s_all)
+    # and the merge kernel itself against the oracle merge
+    rs, ri = orank.merge_topk(ss.cpu().numpy(), ii.cpu().numpy(), k)
+    assert np.array_equal(ri, i_m.cpu().numpy())
+    assert np.array_equal(rs, s_m.cpu().numpy())
+
+
+def test_topk_merge_padding(dev):
+    from evi_rag_amd import ops
+
+    scores = torch.tensor([[[3.0, 1.0, -np.inf]], [[3.0, 2.0, 0.5]]], device=dev)
+    ids = torch.tensor([[[4, 9, -1]], [[10, 11, 12]]], device=dev, dtype=torch.int64)
+    s, i = ops.topk_merge(scores, ids)
+    assert i.cpu().tolist() == [[4, 10, 11]]
+    assert s.cpu().tolist() == [[3.0, 3.0, 2.0]]
+
+
+@pytest.mark.parametrize("k", [1, 10, 500])
+def test_segment_topk_matches_oracle(dev, k):
+    from evi_rag_amd import ops
+
+    rng = np.random.default_rng(k)
+    sizes = [0, 1, 5, 31, 4096, 0, 10000, 20000, 3]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    scores = rng.standard_normal(int(ptr[-1])).astype(np.float32)
+    scores[ptr[4]:ptr[4] + 2000] = 0.25  # a long run of exact ties
+    scores[ptr[6] + 5] = np.inf
+    idx, val, cnt = ops.segment_topk(torch.from_numpy(scores).to(dev), torch.from_numpy(ptr).to(dev), k)
+    ridx, rval, rcnt = orank.segment_topk(scores, ptr, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(val.cpu().numpy(), rval)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
