@@ -24,16 +24,17 @@
 // Bound: HBM.  Algorithmic bytes per batch = N*D*4 + N*4 (row_scale, optional) + Q*D*4 + Q*k*12.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace evi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kScoreThreads = 512;            // 8 waves, 2 per SIMD
-constexpr int kWavesPerBlock = kScoreThreads / 64;
 constexpr int kQueryBlock = 32;               // queries per pass over the index
 constexpr int64_t kFirstSegment = 8192;       // dense segment (fits one LDS sort)
+constexpr int kCntStride = 64;                // one append cursor per 256 B: no false sharing between queries
 constexpr int64_t kSegmentGrowth = 8;
-constexpr int64_t kMaxSegmentDefault = 1 << 21;
+constexpr int64_t kMaxSegmentDefault = 1 << 24;  // recommended workspace: 8 B x 32 x (min(N, 2^24) + k)
 
 // q [Q, D] -> qfrag[((j*4 + g) * (NQB*16) + i) * 4 + t] = q[i][16 j + 4 g + t], zero for i >= Q.
 __global__ void k_query_fragments(const float* __restrict__ q, int Q, int D, int nq_pad,
@@ -52,27 +53,36 @@ __global__ void k_init_state(float* tau, int32_t* cnt, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         tau[i] = -INFINITY;
-        cnt[i] = 0;
+        cnt[i * kCntStride] = 0;
     }
 }
 
 // One pass over rows [seg_begin, seg_end) of the shard.
 //   NQB: query blocks of 16 (1 or 2).  U: float4 loads in flight per lane per prefetch group
-//   (U divides D/16).
-template <int NQB, int U>
-__global__ __launch_bounds__(kScoreThreads) void k_cosine_score(
+//   (U divides D/16).  THREADS: workgroup size (one workgroup per CU: LDS holds the queries).
+//   NT: stream the index with non-temporal loads.
+// Appends are staged per workgroup in LDS (capq entries per query) and flushed once at the end
+// with one global atomic per query, so the per-query cursors see ~256 atomics per launch instead
+// of one per candidate; entries that do not fit go straight to the global list.
+template <int NQB, int U, int THREADS, int NT>
+__global__ __launch_bounds__(THREADS) void k_cosine_score(
     const float* __restrict__ qfrag, const float* __restrict__ idx, int64_t seg_begin,
     int64_t seg_end, int D, int Q, const float* __restrict__ row_scale,
     const float* __restrict__ tau, float* __restrict__ cand_score, int32_t* __restrict__ cand_id,
-    int32_t* __restrict__ cand_cnt, int64_t cap, int dense) {
-    extern __shared__ float4 lds_q[];  // [(D/16)*4][NQB*16] float4
+    int32_t* __restrict__ cand_cnt, int64_t cap, int dense, int capq) {
+    extern __shared__ float4 lds_q[];  // [(D/16)*4][NQB*16] float4, then the append staging area
     constexpr int NQ = NQB * 16;
+    constexpr int WAVES = THREADS / 64;
     const int tid = threadIdx.x;
     const int chunks = D / 16;
+    const int qslots = chunks * 4 * NQ;
+    int* lds_cnt = reinterpret_cast<int*>(lds_q + qslots);          // [32]
+    float* lds_sc = reinterpret_cast<float*>(lds_cnt + kQueryBlock);  // [32][capq]
+    int* lds_id = reinterpret_cast<int*>(lds_sc + kQueryBlock * capq);  // [32][capq]
     {
-        const int total = chunks * 4 * NQ;
         const float4* src = reinterpret_cast<const float4*>(qfrag);
-        for (int s = tid; s < total; s += kScoreThreads) lds_q[s] = src[s];
+        for (int s = tid; s < qslots; s += THREADS) lds_q[s] = src[s];
+        if (tid < kQueryBlock) lds_cnt[tid] = 0;
     }
     __syncthreads();
 
@@ -92,23 +102,27 @@ __global__ __launch_bounds__(kScoreThreads) void k_cosine_score(
     const int groups = chunks / U;
     const float4* lq = lds_q + g * NQ + n;  // + (j*4)*NQ + b*16
 
-    for (int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave; t < tiles;
-         t += (int64_t)gridDim.x * kWavesPerBlock) {
+    auto ldx = [](const f32x4* p) -> f32x4 {
+        if (NT) return __builtin_nontemporal_load(p);
+        return *p;
+    };
+
+    for (int64_t t = (int64_t)blockIdx.x * WAVES + wave; t < tiles; t += (int64_t)gridDim.x * WAVES) {
         const int64_t row = seg_begin + t * 16 + n;
         const int64_t rowc = row < seg_end ? row : seg_end - 1;
-        const float4* xp = reinterpret_cast<const float4*>(idx + rowc * (int64_t)D) + g;
+        const f32x4* xp = reinterpret_cast<const f32x4*>(idx + rowc * (int64_t)D) + g;
 
         f32x4 acc[NQB];
 #pragma unroll
         for (int b = 0; b < NQB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        float4 xcur[U], xnext[U];
+        f32x4 xcur[U], xnext[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xcur[u] = xp[u * 4];
+        for (int u = 0; u < U; ++u) xcur[u] = ldx(xp + u * 4);
         for (int gi = 0; gi < groups; ++gi) {
             if (gi + 1 < groups) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) xnext[u] = xp[((gi + 1) * U + u) * 4];
+                for (int u = 0; u < U; ++u) xnext[u] = ldx(xp + ((gi + 1) * U + u) * 4);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -116,13 +130,12 @@ __global__ __launch_bounds__(kScoreThreads) void k_cosine_score(
                 float4 a[NQB];
 #pragma unroll
                 for (int b = 0; b < NQB; ++b) a[b] = lq[(j * 4) * NQ + b * 16];
-                const float xb[4] = {xcur[u].x, xcur[u].y, xcur[u].z, xcur[u].w};
 #pragma unroll
                 for (int b = 0; b < NQB; ++b) {
                     const float ab[4] = {a[b].x, a[b].y, a[b].z, a[b].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[e], xb[e], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[e], xcur[u][e], acc[b], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -143,11 +156,33 @@ __global__ __launch_bounds__(kScoreThreads) void k_cosine_score(
                         cand_score[qi * cap + pos] = s;
                         cand_id[qi * cap + pos] = (int32_t)row;
                     } else if (s >= tq[b][r] || s != s) {
-                        const int32_t pos = atomicAdd(&cand_cnt[qi], 1);
-                        cand_score[qi * cap + pos] = s;
-                        cand_id[qi * cap + pos] = (int32_t)row;
+                        const int p = atomicAdd(&lds_cnt[qi], 1);
+                        if (p < capq) {
+                            lds_sc[qi * capq + p] = s;
+                            lds_id[qi * capq + p] = (int32_t)row;
+                        } else {
+                            const int32_t pos = atomicAdd(&cand_cnt[qi * kCntStride], 1);
+                            cand_score[qi * cap + pos] = s;
+                            cand_id[qi * cap + pos] = (int32_t)row;
+                        }
                     }
                 }
+        }
+    }
+
+    if (!dense && capq > 0) {
+        __syncthreads();
+        for (int qi = wave; qi < Q; qi += WAVES) {
+            int cnt = lds_cnt[qi];
+            cnt = cnt < capq ? cnt : capq;
+            if (cnt <= 0) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&cand_cnt[qi * kCntStride], cnt);
+            base = __shfl(base, 0, 64);
+            for (int e = lane; e < cnt; e += 64) {
+                cand_score[qi * cap + base + e] = lds_sc[qi * capq + e];
+                cand_id[qi * cap + base + e] = lds_id[qi * capq + e];
+            }
         }
     }
 }
@@ -162,7 +197,7 @@ __global__ __launch_bounds__(kSelectThreads) void k_candidates_select(
     const int qi = blockIdx.x;
     const float* cs = cand_score + qi * cap;
     const int32_t* ci = cand_id + qi * cap;
-    const int64_t cnt = dense_count >= 0 ? dense_count : (int64_t)cand_cnt[qi];
+    const int64_t cnt = dense_count >= 0 ? dense_count : (int64_t)cand_cnt[qi * kCntStride];
     auto load = [&](int64_t i) -> uint64_t { return make_key(cs[i], (uint32_t)ci[i]); };
     const int m = block_topk(sh, load, cnt, k);
     // block_topk ends on a barrier: every read of the old list is done before it is overwritten.
@@ -172,7 +207,7 @@ __global__ __launch_bounds__(kSelectThreads) void k_candidates_select(
         cand_id[qi * cap + i] = (int32_t)key_index(key);
     }
     if (threadIdx.x == 0) {
-        cand_cnt[qi] = m;
+        cand_cnt[qi * kCntStride] = m;
         if (m == k) tau[qi] = key_score(sh.keys[k - 1]);
     }
     if (final_pass) {
@@ -202,7 +237,7 @@ static WsLayout ws_layout(int D, int k, int64_t seg_max) {
     w.tau_off = off;
     off = align_up(off + kQueryBlock * sizeof(float), 256);
     w.cnt_off = off;
-    off = align_up(off + kQueryBlock * sizeof(int32_t), 256);
+    off = align_up(off + (size_t)kQueryBlock * kCntStride * sizeof(int32_t), 256);
     w.cap = seg_max + k;
     w.score_off = off;
     off = align_up(off + (size_t)kQueryBlock * w.cap * sizeof(float), 256);
@@ -217,33 +252,71 @@ static int64_t clamp_seg(int64_t N, int64_t want) {
     return s < 1 ? 1 : s;
 }
 
-template <int NQB, int U>
-static int launch_score(int grid, size_t lds, hipStream_t st, const float* qfrag, const float* idx,
-                        int64_t b, int64_t e, int D, int Q, const float* row_scale, const float* tau,
-                        float* cs, int32_t* ci, int32_t* cc, int64_t cap, int dense) {
+struct ScanVariant {
+    int threads, nt, u_cap;
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Tunables (defaults are the measured best on MI355X; the env overrides exist for
+// tools/scan_variants.py, which A/Bs them in one process).
+static ScanVariant scan_variant() {
+    ScanVariant v;
+    v.threads = env_int("EVI_SCAN_THREADS", 1024);
+    v.nt = env_int("EVI_SCAN_NT", 0);
+    v.u_cap = env_int("EVI_SCAN_U", 4);
+    return v;
+}
+
+struct ScoreArgs {
+    int grid;
+    size_t lds;
+    hipStream_t st;
+    const float* qfrag;
+    const float* idx;
+    int64_t b, e;
+    int D, Q;
+    const float* row_scale;
+    const float* tau;
+    float* cs;
+    int32_t* ci;
+    int32_t* cc;
+    int64_t cap;
+    int dense, capq;
+};
+
+template <int NQB, int U, int THREADS, int NT>
+static int launch_score(const ScoreArgs& a) {
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cosine_score<NQB, U>),
+        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cosine_score<NQB, U, THREADS, NT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cosine_score<NQB, U>), dim3(grid), dim3(kScoreThreads), lds, st, qfrag, idx,
-                       b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+    hipLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT>), dim3(a.grid), dim3(THREADS), a.lds, a.st,
+                       a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci, a.cc, a.cap,
+                       a.dense, a.capq);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
 
-template <int NQB>
-static int launch_score_u(int U, int grid, size_t lds, hipStream_t st, const float* qfrag,
-                          const float* idx, int64_t b, int64_t e, int D, int Q, const float* row_scale,
-                          const float* tau, float* cs, int32_t* ci, int32_t* cc, int64_t cap,
-                          int dense) {
+template <int NQB, int THREADS, int NT>
+static int launch_score_u(int U, const ScoreArgs& a) {
     switch (U) {
-        case 8: return launch_score<NQB, 8>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
-        case 4: return launch_score<NQB, 4>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
-        case 2: return launch_score<NQB, 2>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
-        default: return launch_score<NQB, 1>(grid, lds, st, qfrag, idx, b, e, D, Q, row_scale, tau, cs, ci, cc, cap, dense);
+        case 8: return launch_score<NQB, 8, THREADS, NT>(a);
+        case 4: return launch_score<NQB, 4, THREADS, NT>(a);
+        case 2: return launch_score<NQB, 2, THREADS, NT>(a);
+        default: return launch_score<NQB, 1, THREADS, NT>(a);
     }
+}
+
+template <int NQB>
+static int launch_score_v(const ScanVariant& v, int U, const ScoreArgs& a) {
+    if (v.threads == 1024) return v.nt ? launch_score_u<NQB, 1024, 1>(U, a) : launch_score_u<NQB, 1024, 0>(U, a);
+    return v.nt ? launch_score_u<NQB, 512, 1>(U, a) : launch_score_u<NQB, 512, 0>(U, a);
 }
 
 static int device_cu_count() {
@@ -309,8 +382,11 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
     int32_t* ci = reinterpret_cast<int32_t*>(base + w.id_off);
 
     const int chunks = D / 16;
-    const int U = (chunks % 8 == 0) ? 8 : (chunks % 4 == 0) ? 4 : (chunks % 2 == 0) ? 2 : 1;
+    const ScanVariant variant = scan_variant();
+    int U = (chunks % 8 == 0) ? 8 : (chunks % 4 == 0) ? 4 : (chunks % 2 == 0) ? 2 : 1;
+    while (U > variant.u_cap && U > 1) U >>= 1;
     const int cus = device_cu_count();
+    const int waves_per_block = variant.threads == 1024 ? 16 : 8;
 
     for (int q0 = 0; q0 < Q; q0 += kQueryBlock) {
         const int qn = (Q - q0) < kQueryBlock ? (Q - q0) : kQueryBlock;
@@ -331,7 +407,11 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
             EVI_LAUNCH_CHECK();
             continue;
         }
-        const size_t lds = (size_t)chunks * 4 * nq_pad * sizeof(float4);
+        const size_t lds_q_bytes = (size_t)chunks * 4 * nq_pad * sizeof(float4);
+        // staging entries per query: whatever LDS is left, at most 64
+        int capq = (int)((160 * 1024 - lds_q_bytes - kQueryBlock * sizeof(int)) / (kQueryBlock * 8));
+        capq = capq > 64 ? 64 : (capq < 0 ? 0 : capq);
+        const size_t lds = lds_q_bytes + kQueryBlock * sizeof(int) + (size_t)kQueryBlock * capq * 8;
         int64_t begin = 0;
         int64_t seg = clamp_seg(N, kFirstSegment);
         bool first = true;
@@ -339,16 +419,12 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
             int64_t end = begin + seg;
             if (end > N) end = N;
             const int64_t tiles = (end - begin + 15) / 16;
-            int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+            int64_t want = (tiles + waves_per_block - 1) / waves_per_block;
             const int grid = (int)(want < cus ? want : cus);
-            int rc;
+            const ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
+                               cs, ci, cnt, w.cap, first ? 1 : 0, capq};
             const int tok = timing_begin(kTimeCosineScore, st);
-            if (nqb == 1)
-                rc = launch_score_u<1>(U, grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau, cs,
-                                       ci, cnt, w.cap, first ? 1 : 0);
-            else
-                rc = launch_score_u<2>(U, grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau, cs,
-                                       ci, cnt, w.cap, first ? 1 : 0);
+            const int rc = nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa);
             timing_end(tok, st);
             if (rc != EVI_OK) return rc;
             const int final_pass = end >= N ? 1 : 0;
