@@ -1,0 +1,106 @@
+"""Edge scorer oracle (S1-S6): numpy f32 restatement of the reference Retriever forward
+(test infrastructure only).  reference: src/models/components/retriever.py:195-289, 403-553;
+src/models/components/projections.py:9-40.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+from scipy.special import erf
+
+from . import graph as ograph
+
+LN_EPS = 1e-5  # torch.nn.LayerNorm default
+
+
+def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray]) -> np.ndarray:
+    y = np.asarray(x, np.float32) @ np.asarray(w, np.float32).T
+    if b is not None:
+        y = y + np.asarray(b, np.float32)
+    return y.astype(np.float32)
+
+
+def layer_norm(x: np.ndarray, weight: np.ndarray, bias: np.ndarray, eps: float = LN_EPS) -> np.ndarray:
+    x = np.asarray(x, np.float32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=np.float32)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True, dtype=np.float32)
+    return ((x - mu) / np.sqrt(var + np.float32(eps)) * weight + bias).astype(np.float32)
+
+
+def gelu(x: np.ndarray) -> np.ndarray:
+    """Exact (erf) GELU — torch.nn.GELU() default."""
+    x = np.asarray(x, np.float32)
+    return (0.5 * x * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))).astype(np.float32)
+
+
+def sigmoid(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, np.float32)
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+
+
+def projector(x: np.ndarray, w: Dict[str, np.ndarray], name: str) -> np.ndarray:
+    """tanh(x W^T + b).  reference: EmbeddingProjector, src/models/components/projections.py:9-40."""
+    return np.tanh(linear(x, w[f"{name}.network.0.weight"], w[f"{name}.network.0.bias"])).astype(np.float32)
+
+
+def score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_raw):
+    """One direction.  reference: Retriever._score_edges (:453-484), _encode_structure (:486-495)."""
+    gate = sigmoid(linear(query_repr, w["q_gate.0.weight"], w["q_gate.0.bias"]))
+    bias = np.tanh(linear(query_repr, w["q_bias.0.weight"], w["q_bias.0.bias"])).astype(np.float32)
+    r_ctx = (relation_repr * gate + bias).astype(np.float32)
+    s = linear(struct_raw, w["struct_proj.0.weight"], w["struct_proj.0.bias"])
+    s = gelu(layer_norm(s, w["struct_proj.1.weight"], w["struct_proj.1.bias"]))
+    nav = sigmoid(linear(s, w["struct_gate_net.0.weight"], w["struct_gate_net.0.bias"]))
+    inter = (head_repr * r_ctx * tail_repr * nav).astype(np.float32)
+    err = (head_repr + r_ctx - tail_repr).astype(np.float32)
+    dist = -np.sqrt(np.sum(err * err, axis=-1, keepdims=True, dtype=np.float32))
+    combined = np.concatenate([inter, s, err, dist.astype(np.float32)], axis=-1)
+    h = linear(combined, w["state_net.0.weight"], w["state_net.0.bias"])
+    h = gelu(layer_norm(h, w["state_net.1.weight"], w["state_net.1.bias"]))
+    feats = linear(h, w["state_net.4.weight"], w["state_net.4.bias"])  # Dropout (index 3) is identity in eval
+    logits = linear(feats, w["score_head.weight"], w["score_head.bias"])[:, 0]
+    return logits.astype(np.float32), feats.astype(np.float32)
+
+
+def retriever_forward(w: Dict[str, np.ndarray], batch, *, num_rounds: int, num_reverse_rounds: int,
+                      direction_mode: str = "bidirectional") -> Dict[str, np.ndarray]:
+    """Eval-mode forward of the reference Retriever on a flat batch (evi_rag_amd.synthetic
+    SyntheticBatch or any object with the same attributes).
+    reference: Retriever._forward_impl / _prepare_edge_inputs / _project_nodes /
+    _combine_directional_outputs, src/models/components/retriever.py:195-289, 403-451, 497-507, 369-381."""
+    edge_index = np.asarray(batch.edge_index, np.int64)
+    head, tail = edge_index[0], edge_index[1]
+    num_graphs = int(np.asarray(batch.ptr).shape[0] - 1)
+    query_ids, _ = ograph.compute_edge_batch(edge_index, batch.ptr, num_graphs)
+    q_proj = projector(batch.question_emb, w, "query_proj")
+    query_repr = q_proj[query_ids]
+    node_repr = projector(batch.node_embeddings, w, "entity_proj")
+    non_text = projector(w["non_text_entity_emb.weight"], w, "entity_proj")[0]
+    mask = np.asarray(batch.node_embedding_ids, np.int64) == 0
+    if mask.any():
+        node_repr = np.where(mask[:, None], non_text[None, :], node_repr).astype(np.float32)
+    head_repr, tail_repr = node_repr[head], node_repr[tail]
+    relation_repr = projector(batch.edge_embeddings, w, "relation_proj")
+    ns = ograph.node_structure_features(batch.topic_one_hot, edge_index, num_rounds, num_reverse_rounds)
+    struct_fwd = np.concatenate([ns[head], ns[tail]], axis=-1)
+    struct_bwd = np.concatenate([ns[tail], ns[head]], axis=-1)
+    out: Dict[str, np.ndarray] = {"query_ids": query_ids, "node_struct": ns}
+    lf = ff = lb = fb = None
+    if direction_mode in ("forward", "bidirectional"):
+        lf, ff = score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_fwd)
+    if direction_mode in ("backward", "bidirectional"):
+        lb, fb = score_edges(w, query_repr, tail_repr, relation_repr, head_repr, struct_bwd)
+    if direction_mode == "bidirectional":
+        st = np.stack([lf, lb], axis=0).astype(np.float64)
+        e = np.exp(st - st.max(axis=0, keepdims=True))
+        wts = (e / e.sum(axis=0, keepdims=True)).astype(np.float32)
+        logits = (wts * np.stack([lf, lb], axis=0)).sum(axis=0).astype(np.float32)
+        feats = (wts[0][:, None] * ff + wts[1][:, None] * fb).astype(np.float32)
+    elif direction_mode == "forward":
+        logits, feats = lf, ff
+    else:
+        logits, feats = lb, fb
+    out.update(logits=logits, edge_embeddings=feats, logits_fwd=lf, logits_bwd=lb,
+               relation_ids=np.asarray(batch.edge_attr, np.int64))
+    return out

@@ -1,0 +1,416 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE'S OWN FUNCTIONS (build container only).
+
+The reference checkout (/root/reference) never travels to the GPU box; what travels are the
+small input/output vectors written here.  Third-party packages the reference imports but this
+image lacks (lmdb, torch_geometric, torchmetrics, lightning, hydra, ...) are replaced by inert
+stubs: only `torchmetrics.Metric` (a state container) and `torch_geometric.nn.MessagePassing`
+(mean aggregation, restated from PyG's documented semantics — "parity unpinned" at that one
+boundary) carry behaviour.  Everything else in the fixtures is the reference's
+arithmetic, unmodified.
+
+Usage:  python tests/golden/make_golden.py            (writes next to this file)
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("EVI_REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+# ---- inert stubs for absent third-party packages -----------------------------------------------
+_STUB_ROOTS = ("lmdb", "torch_geometric", "torchmetrics", "lightning", "wandb", "openai", "ollama", "tiktoken", "vllm")
+
+
+class _StubModule(types.ModuleType):
+    __path__: list = []
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        cls = type(name, (object,), {"__init__": lambda self, *a, **k: None, "__module__": self.__name__})
+        setattr(self, name, cls)
+        return cls
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split(".")[0] in _STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        return None
+
+
+sys.meta_path.append(_StubFinder())
+
+
+class _Metric:
+    """torchmetrics.Metric as a plain state container (add_state / reset; no sync)."""
+
+    def __init__(self, **kwargs):
+        self._defaults = {}
+
+    def add_state(self, name, default, dist_reduce_fx=None):
+        self._defaults[name] = default.clone()
+        setattr(self, name, default.clone())
+
+    def reset(self):
+        for k, v in self._defaults.items():
+            setattr(self, k, v.clone())
+
+
+class _MessagePassing(torch.nn.Module):
+    """PyG MessagePassing(aggr="mean", flow="source_to_target", node_dim=0), restated:
+    out[i] = mean over edges (j -> i) of message(x_j); 0 where i has no incoming edge."""
+
+    def __init__(self, aggr="mean", node_dim=0, **kwargs):
+        super().__init__()
+        assert aggr == "mean" and node_dim == 0
+
+    def propagate(self, edge_index, x):
+        src, dst = edge_index[0], edge_index[1]
+        msg = self.message(x.index_select(0, src))
+        out = torch.zeros((x.size(0),) + tuple(msg.shape[1:]), dtype=msg.dtype)
+        out.index_add_(0, dst, msg)
+        cnt = torch.zeros(x.size(0), dtype=msg.dtype)
+        cnt.index_add_(0, dst, torch.ones(dst.numel(), dtype=msg.dtype))
+        return out / cnt.clamp(min=1).view(-1, *([1] * (msg.dim() - 1)))
+
+
+importlib.import_module("torchmetrics").Metric = _Metric
+importlib.import_module("torch_geometric.nn").MessagePassing = _MessagePassing
+
+from evi_rag_amd import synthetic  # noqa: E402  (the build's own input generator)
+
+import scripts.build_retrieval_pipeline as brp  # noqa: E402
+import scripts.text_encode_utils as teu  # noqa: E402
+from src.data.components.g_agent_builder import GAgentBuilder  # noqa: E402
+from src.metrics.reachability import AnswerReachability  # noqa: E402
+from src.metrics.retriever_metrics import (  # noqa: E402
+    BridgeEdgeRecallAtK, BridgePositiveCoverage, BridgeProbQuality, EdgeRecallAtK, ScoreMargin)
+from src.models.components.retriever import Retriever  # noqa: E402
+from src.models.reasoner_module import _oracle_metrics_for_sample  # noqa: E402
+from src.utils.graph_utils import compute_edge_batch, compute_qa_edge_mask  # noqa: E402
+from src.utils.metrics import compute_answer_hit, compute_answer_recall  # noqa: E402
+
+K_VALUES = [1, 10, 25, 50, 100, 200, 300, 400, 500]  # configs/window/default.yaml:8
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
+
+
+# ---- C1-C4 ---------------------------------------------------------------------------------------
+def gen_cosine():
+    rng = np.random.default_rng(101)
+    x = rng.standard_normal((37, 48)).astype(np.float32)
+    x[0] = 0.0
+    x[5] *= 1e-9  # norm below eps: the clamp decides
+    out = brp._normalize_embeddings(torch.from_numpy(x), 1e-6).numpy()
+    # canonical edges: parallel edges between the same unordered pair, some with equal relations
+    R, D = 12, 48
+    rel = rng.standard_normal((R, D)).astype(np.float32)
+    rel[3] = rel[7]  # exact tie between two relations
+    q = rng.standard_normal(D).astype(np.float32)
+    edge_src = [0, 1, 0, 2, 2, 3, 1, 0, 4, 4, 4, 2]
+    edge_dst = [1, 0, 1, 3, 3, 2, 0, 1, 5, 5, 5, 3]
+    edge_rel = [3, 7, 1, 2, 9, 4, 7, 3, 5, 5, 6, 9]
+    pos = [True, True, True, True, True, False, True, True, True, True, True, True]
+    reln = brp._normalize_embeddings(torch.from_numpy(rel), 1e-6)
+    qn = brp._normalize_embeddings(torch.from_numpy(q).view(1, -1), 1e-6).view(-1)
+    groups = brp._group_positive_edges_by_pair(edge_src, edge_dst, pos)
+    keep = brp._select_canonical_edge_indices(groups, edge_rel, reln, qn)
+    pair_ids = [0, 1, 2, 6, 7, 3, 4, 11, 8, 9, 10]
+    pair_counts = [5, 3, 3]
+    keep_mask = [False] * len(edge_src)
+    for i in keep:
+        keep_mask[i] = True
+    new_ids, new_counts = brp._filter_pair_edges(pair_ids, pair_counts, keep_mask)
+    save("cosine", x=x, eps=np.float32(1e-6), x_norm=out, rel=rel, q=q, rel_norm=reln.numpy(), q_norm=qn.numpy(),
+         edge_src=edge_src, edge_dst=edge_dst, edge_rel=edge_rel, positive=pos,
+         group_keys=np.asarray(list(groups.keys()), np.int64),
+         group_sizes=np.asarray([len(v) for v in groups.values()], np.int64),
+         group_members=np.concatenate([np.asarray(v, np.int64) for v in groups.values()]),
+         keep_indices=np.asarray(keep, np.int64), pair_ids=pair_ids, pair_counts=pair_counts,
+         new_pair_ids=new_ids, new_pair_counts=new_counts)
+
+
+# ---- G1-G5 ---------------------------------------------------------------------------------------
+def gen_bfs():
+    rng = np.random.default_rng(202)
+    cases = {}
+    for c, (n, e) in enumerate([(12, 14), (40, 55), (64, 31), (150, 400), (9, 0)]):
+        src = rng.integers(0, n, size=e).tolist()
+        dst = rng.integers(0, n, size=e).tolist()
+        if e > 4:
+            src[1], dst[1] = 3, 3          # self loop
+            src[2], dst[2] = -1, 2         # out-of-range edges are skipped
+            src[3], dst[3] = 1, n + 5
+        seeds = sorted(set(rng.integers(0, n, size=2).tolist())) + [n + 3]  # one invalid seed
+        answers = rng.integers(0, n, size=4).tolist()
+        adj = brp._build_undirected_adjacency(n, src, dst)
+        dadj = brp._build_directed_adjacency(n, src, dst)
+        dist = brp._bfs_dist(n, adj, seeds)
+        ddist = brp._bfs_dist(n, dadj, seeds)
+        mask, ps, pa, pe, pc, pl = brp._shortest_path_union_mask_by_pair(n, src, dst, seeds, answers)
+        dmask, dps, dpa, dpe, dpc, dpl = brp._shortest_path_union_mask_by_pair_directed(n, src, dst, seeds, answers)
+        sp_edges, sp_nodes = brp._shortest_path_single(n, src, dst, seeds, answers)
+        cases.update({
+            f"c{c}_n": n, f"c{c}_src": np.asarray(src, np.int64), f"c{c}_dst": np.asarray(dst, np.int64),
+            f"c{c}_seeds": np.asarray(seeds, np.int64), f"c{c}_answers": np.asarray(answers, np.int64),
+            f"c{c}_adj_ptr": np.cumsum([0] + [len(a) for a in adj]).astype(np.int64),
+            f"c{c}_adj": np.asarray([v for a in adj for v in a], np.int64),
+            f"c{c}_dadj_ptr": np.cumsum([0] + [len(a) for a in dadj]).astype(np.int64),
+            f"c{c}_dadj": np.asarray([v for a in dadj for v in a], np.int64),
+            f"c{c}_dist": np.asarray(dist, np.int64), f"c{c}_ddist": np.asarray(ddist, np.int64),
+            f"c{c}_mask": np.asarray(mask, bool), f"c{c}_pair_start": np.asarray(ps, np.int64),
+            f"c{c}_pair_answer": np.asarray(pa, np.int64), f"c{c}_pair_edges": np.asarray(pe, np.int64),
+            f"c{c}_pair_counts": np.asarray(pc, np.int64), f"c{c}_pair_len": np.asarray(pl, np.int64),
+            f"c{c}_dmask": np.asarray(dmask, bool), f"c{c}_dpair_start": np.asarray(dps, np.int64),
+            f"c{c}_dpair_answer": np.asarray(dpa, np.int64), f"c{c}_dpair_edges": np.asarray(dpe, np.int64),
+            f"c{c}_dpair_counts": np.asarray(dpc, np.int64), f"c{c}_dpair_len": np.asarray(dpl, np.int64),
+            f"c{c}_sp_edges": np.asarray(sp_edges, np.int64), f"c{c}_sp_nodes": np.asarray(sp_nodes, np.int64),
+        })
+    # has_connectivity on string triples
+    triples = [("a", "r", "b"), ("b", "r", "c"), ("d", "r", "e"), ("c", "r2", "a")]
+    conn = [
+        brp.has_connectivity(triples, ["a"], ["c"]), brp.has_connectivity(triples, ["a"], ["e"]),
+        brp.has_connectivity(triples, ["c"], ["b"], path_mode="qa_directed"),
+        brp.has_connectivity(triples, ["e"], ["d"], path_mode="qa_directed"),
+        brp.has_connectivity(triples, ["zz"], ["a"]), brp.has_connectivity([], ["a"], ["b"]),
+    ]
+    cases["num_cases"] = 5
+    cases["has_connectivity"] = np.asarray(conn, bool)
+    save("bfs", **cases)
+
+
+# ---- G11 -----------------------------------------------------------------------------------------
+def gen_graph_utils(batch):
+    ns = synthetic.as_namespace(batch)
+    eb, eptr = compute_edge_batch(ns.edge_index, node_ptr=ns.ptr, num_graphs=batch.num_graphs,
+                                  device=torch.device("cpu"))
+    near = compute_qa_edge_mask(ns.edge_index, num_nodes=batch.num_nodes,
+                                q_local_indices=ns.q_local_indices, a_local_indices=ns.a_local_indices)
+    return eb.numpy(), eptr.numpy(), near.numpy()
+
+
+# ---- S1-S7 + G6/G7 -----------------------------------------------------------------------------------
+def batch_arrays(batch, prefix=""):
+    out = {}
+    for name in ("edge_index", "ptr", "edge_ptr", "edge_attr", "labels", "node_global_ids", "node_embedding_ids",
+                 "topic_one_hot", "question_emb", "q_local_indices", "q_ptr", "a_local_indices", "a_ptr",
+                 "answer_entity_ids", "answer_ptr", "node_embeddings", "edge_embeddings"):
+        out[prefix + name] = getattr(batch, name)
+    return out
+
+
+def gen_retriever(name, D, H, batch, seed, rounds=(2, 2), direction="bidirectional"):
+    torch.manual_seed(seed)
+    model = Retriever(emb_dim=D, hidden_dim=H, topic_pe=True, num_topics=2,
+                      dde_cfg={"num_rounds": rounds[0], "num_reverse_rounds": rounds[1]}, dropout_p=0.1,
+                      direction_mode=direction,
+                      hide_seek_cfg={"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0,
+                                     "bias_far": -0.5, "apply_in_eval": False})
+    model.eval()
+    # random-init biases/LayerNorm affine so that every parameter matters
+    with torch.no_grad():
+        for p_name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    ns = synthetic.as_namespace(batch)
+    with torch.no_grad():
+        out = model(ns)
+        node_struct = model._build_node_structure_features(ns, edge_index=ns.edge_index, num_nodes=batch.num_nodes)
+        feats = model.extract_edge_tokens(ns)
+    arrays = batch_arrays(batch, "b_")
+    sd = model.state_dict()
+    for k, v in sd.items():
+        arrays["w_" + k] = v.numpy()
+    arrays.update(
+        D=D, H=H, rounds=np.asarray(rounds), direction=direction,
+        logits=out.logits.numpy(), logits_fwd=out.logits_fwd.numpy() if out.logits_fwd is not None else np.zeros(0),
+        logits_bwd=out.logits_bwd.numpy() if out.logits_bwd is not None else np.zeros(0),
+        edge_embeddings=out.edge_embeddings.numpy(), query_ids=out.query_ids.numpy(),
+        relation_ids=out.relation_ids.numpy(), node_struct=node_struct.numpy(), edge_tokens=feats.numpy(),
+        state_dict_keys=np.asarray(list(sd.keys())),
+    )
+    save(name, **arrays)
+    return out
+
+
+# ---- T1-T5 -----------------------------------------------------------------------------------------
+def gen_metrics(batch, logits, tag):
+    ns = synthetic.as_namespace(batch)
+    scores = logits.detach().view(-1)
+    target = ns.labels > 0.5
+    eb, _ = compute_edge_batch(ns.edge_index, node_ptr=ns.ptr, num_graphs=batch.num_graphs, device=torch.device("cpu"))
+    kw = dict(preds=scores, target=target, indexes=eb, batch=ns, num_graphs=batch.num_graphs)
+    out = {}
+    m = EdgeRecallAtK(k_values=K_VALUES)
+    m.update(**kw)
+    out.update({k: float(v) for k, v in m.compute().items()})
+    m = AnswerReachability(k_values=K_VALUES)
+    m.update(preds=scores, batch=ns, query_ids=eb, num_graphs=batch.num_graphs)
+    out.update({k: float(v) for k, v in m.compute().items()})
+    reach_total = float(m.total)
+    for cls in (BridgeEdgeRecallAtK,):
+        m = cls(k_values=K_VALUES)
+        m.update(**kw)
+        out.update({k: float(v) for k, v in m.compute().items()})
+    for cls in (BridgePositiveCoverage, ScoreMargin, BridgeProbQuality):
+        m = cls()
+        m.update(**kw)
+        out.update({k: float(v) for k, v in m.compute().items()})
+    # T4: answer hit / recall over ranked edge lists
+    samples, oracle_rows = [], []
+    for g in range(batch.num_graphs):
+        lo, hi = int(batch.edge_ptr[g]), int(batch.edge_ptr[g + 1])
+        heads = ns.node_global_ids[ns.edge_index[0, lo:hi]]
+        tails = ns.node_global_ids[ns.edge_index[1, lo:hi]]
+        ans = ns.answer_entity_ids[int(batch.answer_ptr[g]): int(batch.answer_ptr[g + 1])]
+        samples.append({"scores": scores[lo:hi], "head_ids": heads, "tail_ids": tails, "answer_ids": ans})
+        order = torch.argsort(scores[lo:hi], descending=True, stable=True)[:500]
+        row = _oracle_metrics_for_sample(head_entity_ids=heads[order], tail_entity_ids=tails[order],
+                                         answer_entity_ids=ans, k_values=K_VALUES)
+        oracle_rows.append([row[f"answer_hit@{k}"] for k in K_VALUES] + [row[f"answer_recall@{k}"] for k in K_VALUES])
+    out.update(compute_answer_hit(samples, K_VALUES))
+    out.update(compute_answer_recall(samples, K_VALUES))
+    keys = sorted(out.keys())
+    save(f"metrics_{tag}", keys=np.asarray(keys), values=np.asarray([out[k] for k in keys], np.float64),
+         reach_total=reach_total, scores=scores.numpy(), oracle_rows=np.asarray(oracle_rows, np.float64),
+         k_values=np.asarray(K_VALUES), **batch_arrays(batch, "b_"))
+
+
+# ---- G8/G9 -------------------------------------------------------------------------------------------
+def gen_g_agent(batch, logits):
+    ns = synthetic.as_namespace(batch)
+    scores = logits.detach().view(-1)
+    arrays = {"num_graphs": batch.num_graphs}
+    for g in range(batch.num_graphs):
+        lo, hi = int(batch.edge_ptr[g]), int(batch.edge_ptr[g + 1])
+        n0, n1 = int(batch.ptr[g]), int(batch.ptr[g + 1])
+        heads = ns.edge_index[0, lo:hi] - n0
+        tails = ns.edge_index[1, lo:hi] - n0
+        s = scores[lo:hi]
+        seeds = ns.q_local_indices[int(batch.q_ptr[g]): int(batch.q_ptr[g + 1])] - n0
+        logit = GAgentBuilder._node_softmax_logit(edge_scores=s, edge_head_locals=heads, edge_tail_locals=tails,
+                                                  num_nodes=n1 - n0)
+        for tk in (5, 500):
+            arrays[f"g{g}_topk{tk}"] = GAgentBuilder._select_topk_edges(edge_scores=logit, edge_top_k=tk).numpy()
+        for ri, (ratio, mn, mx) in enumerate([(0.25, 1, None), (0.5, 2, 3), (0.0, 0, None), (1.0, 1, 0)]):
+            arrays[f"g{g}_start{ri}"] = GAgentBuilder._select_start_edges(
+                heads=heads, tails=tails, edge_scores=logit, start_node_locals=seeds, num_nodes=n1 - n0,
+                start_keep_ratio=ratio, start_min_edges=mn, start_max_edges=mx).numpy()
+        arrays[f"g{g}_logit"] = logit.numpy()
+    arrays["start_params"] = np.asarray([[0.25, 1, -1], [0.5, 2, 3], [0.0, 0, -1], [1.0, 1, 0]], np.float64)
+    save("g_agent_select", scores=scores.numpy(), **arrays, **batch_arrays(batch, "b_"))
+
+
+# ---- E2/E3 -------------------------------------------------------------------------------------------
+class _FakeTokenizer:
+    """Whitespace tokenizer with padding=True semantics (pad id 0, mask 0 on pads)."""
+
+    def __call__(self, texts, padding=True, truncation=True, return_tensors="pt"):
+        ids = [[(sum(map(ord, w)) % 97) + 1 for w in t.split()][:8] for t in texts]
+        L = max(1, max(len(i) for i in ids))
+        input_ids = torch.zeros((len(ids), L), dtype=torch.long)
+        mask = torch.zeros((len(ids), L), dtype=torch.long)
+        for r, row in enumerate(ids):
+            input_ids[r, : len(row)] = torch.tensor(row, dtype=torch.long)
+            mask[r, : len(row)] = 1
+        return {"input_ids": input_ids, "attention_mask": mask}
+
+
+class _FakeModel(torch.nn.Module):
+    """last_hidden_state = table[input_ids] + position ramp: pins pooling, not a real encoder."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.table = table
+
+    def forward(self, input_ids, attention_mask):
+        hid = self.table[input_ids] + 0.01 * torch.arange(input_ids.size(1), dtype=torch.float32).view(1, -1, 1)
+        return types.SimpleNamespace(last_hidden_state=hid)
+
+
+def gen_encode(tmpdir):
+    torch.manual_seed(7)
+    D = 24
+    table = torch.randn(98, D)
+    texts = ["alpha beta", "gamma", "delta epsilon zeta eta", "", "theta iota", "kappa lambda mu", "nu",
+             "xi omicron pi rho sigma tau upsilon phi chi psi omega", "alpha", "beta beta beta"]
+    arrays = {"table": table.numpy(), "D": D}
+    tok = _FakeTokenizer()
+    for fp16 in (False, True):
+        enc = object.__new__(teu.TextEncoder)  # bypass __init__ (needs a network fetch)
+        enc.tokenizer, enc.model, enc.device = tok, _FakeModel(table), "cpu"
+        enc.dtype = torch.float16 if fp16 else torch.float32
+        enc.progress = False
+        pooled = enc.encode(texts, batch_size=4)
+        arrays[f"pooled_fp16_{int(fp16)}"] = pooled.numpy()
+        if not fp16:
+            emb_ids = [3, 1, 7, 12, 2, 9, 40, 5, 11, 6]  # 40 > max_embedding_id: skipped
+            path = os.path.join(tmpdir, "entity_embeddings.pt")
+            from pathlib import Path
+
+            tensor = teu.encode_to_memmap(enc, texts, emb_ids, batch_size=4, max_embedding_id=12,
+                                          out_path=Path(path), desc=None, show_progress=False)
+            arrays["memmap_table"] = tensor.numpy().copy()
+            arrays["emb_ids"] = np.asarray(emb_ids, np.int64)
+            arrays["max_embedding_id"] = 12
+            assert torch.equal(torch.load(path), tensor)
+    # per-batch token ids / masks so the build's pooling kernel sees the same inputs
+    for bi, (s, e) in enumerate(teu._iter_batches(len(texts), 4)):
+        t = tok(texts[s:e])
+        arrays[f"ids_{bi}"] = t["input_ids"].numpy()
+        arrays[f"mask_{bi}"] = t["attention_mask"].numpy()
+        arrays[f"hidden_{bi}"] = _FakeModel(table)(**t).last_hidden_state.numpy()
+    arrays["num_batches"] = bi + 1
+    arrays["empty_shape"] = np.asarray(object.__new__(teu.TextEncoder).encode.__wrapped__(enc, [], 4).shape) \
+        if hasattr(teu.TextEncoder.encode, "__wrapped__") else np.asarray(enc.encode([], 4).shape)
+    save("encode", **arrays)
+
+
+def main():
+    import tempfile
+
+    gen_cosine()
+    gen_bfs()
+    # toy batch (BASELINE config 1 graph shape: 32 graphs, N_g = 64, E_g ~ 31), D = H = 32
+    toy = synthetic.make_batch(32, nodes_per_graph=64, edges_per_graph=31, emb_dim=32, num_relations=16, seed=0)
+    eb, eptr, near = gen_graph_utils(toy)
+    out = gen_retriever("retriever_toy", 32, 32, toy, seed=0)
+    save("graph_utils_toy", edge_batch=eb, edge_ptr=eptr, near_mask=near, **batch_arrays(toy, "b_"))
+    gen_metrics(toy, out.logits, "toy")
+    gen_g_agent(toy, out.logits)
+    # denser graphs, D != H, more DDE rounds, k window smaller than E_g
+    mid = synthetic.make_batch(6, nodes_per_graph=300, edges_per_graph=900, emb_dim=64, num_relations=40, seed=3)
+    out_mid = gen_retriever("retriever_mid", 64, 48, mid, seed=1, rounds=(3, 1))
+    gen_metrics(mid, out_mid.logits, "mid")
+    fwd = synthetic.make_batch(4, nodes_per_graph=40, edges_per_graph=80, emb_dim=16, num_relations=8, seed=5)
+    gen_retriever("retriever_fwd", 16, 16, fwd, seed=2, rounds=(2, 2), direction="forward")
+    gen_retriever("retriever_bwd", 16, 16, fwd, seed=2, rounds=(0, 4), direction="backward")
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_encode(tmp)
+
+
+if __name__ == "__main__":
+    main()
