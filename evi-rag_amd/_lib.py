@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Dict, List, Optional
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +25,36 @@ EVI_TOPK_MAX_K = 2048
 
 _P = c_void_p
 
+
+
+class EviRetrieverWeights(Structure):
+    """Mirror of `EviRetrieverWeights` in include/evi_hip.h."""
+
+    _fields_ = [("emb_dim", c_int), ("hidden_dim", c_int), ("num_topics", c_int), ("dde_rounds", c_int),
+                ("dde_reverse_rounds", c_int)] + [(name, c_void_p) for name in (
+                    "entity_w", "entity_b", "relation_w", "relation_b", "query_w", "query_b", "non_text_emb",
+                    "q_gate_w", "q_gate_b", "q_bias_w", "q_bias_b", "struct_w", "struct_b", "struct_ln_w",
+                    "struct_ln_b", "struct_gate_w", "struct_gate_b", "state0_w", "state0_b", "state_ln_w",
+                    "state_ln_b", "state4_w", "state4_b", "score_w", "score_b")]
+
+
+class EviRetrieverBatch(Structure):
+    """Mirror of `EviRetrieverBatch` in include/evi_hip.h."""
+
+    _fields_ = [("num_nodes", c_int64), ("num_edges", c_int64), ("num_graphs", c_int),
+                ("edge_index", c_void_p), ("node_ptr", c_void_p), ("edge_ptr", c_void_p), ("edge_batch", c_void_p),
+                ("question_emb", c_void_p), ("node_embeddings", c_void_p), ("node_embedding_ids", c_void_p),
+                ("edge_embeddings", c_void_p), ("edge_attr", c_void_p), ("num_relations", c_int64),
+                ("topic_one_hot", c_void_p), ("topic_stride", c_int)]
+
+
+class EviRetrieverOutput(Structure):
+    """Mirror of `EviRetrieverOutput` in include/evi_hip.h."""
+
+    _fields_ = [("logits", c_void_p), ("logits_fwd", c_void_p), ("logits_bwd", c_void_p),
+                ("edge_features", c_void_p), ("node_struct", c_void_p)]
+
+
 # name -> (restype, argtypes)
 _SIGNATURES = {
     "evi_version": (c_int, []),
@@ -38,6 +68,15 @@ _SIGNATURES = {
     "evi_cosine_topk": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "evi_topk_merge": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "evi_segment_topk": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "evi_edge_batch": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P]),
+    "evi_qa_edge_mask": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P]),
+    "evi_graph_csr_workspace_bytes": (c_size_t, [c_int64]),
+    "evi_graph_csr": (c_int, [_P, c_int64, _P, _P, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "evi_dde_node_struct": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "evi_gemm_nt_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, c_int64, _P, c_int, _P, c_int64, _P]),
+    "evi_retriever_forward_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64]),
+    "evi_retriever_forward": (c_int, [POINTER(EviRetrieverWeights), POINTER(EviRetrieverBatch), c_int,
+                                      POINTER(EviRetrieverOutput), _P, c_size_t, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -40,11 +40,16 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------
 // When enabled, launch sites bracket their dominant kernel with hipEvents on the call's stream;
 // evi_timing_read() synchronises those events and returns the summed durations per class.
-enum TimingClass { kTimeCosineScore = 0, kTimeSelect = 1, kTimeClasses = 8 };
+enum TimingClass { kTimeCosineScore = 0, kTimeSelect = 1, kTimeGemm = 2, kTimeEdge = 3, kTimeClasses = 8 };
 bool timing_enabled();
 // Records a start event on `st`; returns a token (or -1 when timing is off).
 int timing_begin(int cls, hipStream_t st);
 void timing_end(int token, hipStream_t st);
+
+// ---- shared launchers ------------------------------------------------------------------------
+// C[M,N] = act(A[M,K] W[N,K]^T + bias); act: 0 none, 1 tanh, 2 sigmoid (gemm.hip).
+int launch_gemm_nt(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                   const float* bias, int act, float* C, int64_t ldc, hipStream_t st);
 
 // ---- ordered keys ---------------------------------------------------------------------------
 // A 64-bit key whose unsigned order is the ranking order used everywhere in this library:

@@ -1,0 +1,522 @@
+// Retriever edge scorer (S1-S6): the eval-mode forward of
+//   src/models/components/retriever.py:195-289 (Retriever._forward_impl) on a flat PyG-style batch.
+//
+// Pipeline (all on the caller's stream, intermediates in the caller's workspace):
+//   1. projections  tanh(x W^T + b): nodes [N,D], questions [B,D] (then q_gate / q_bias on the B
+//      projected questions instead of per edge — :464 gathers first, which is the same arithmetic
+//      per row), relations either per unique relation id (when the caller states num_relations <= E;
+//      a row's projection depends on nothing but the row) or per edge.          -> gemm.hip (MFMA f32)
+//   2. structure    CSR + DDE mean propagation -> node_struct [N, 2*(1+R+RR)]    -> graph.hip
+//   3. edge features, one wave per edge, both directions: struct MLP (K = 20, LN, exact GELU),
+//      nav gate, DistMult / TransE terms, written as rows of X [2*Ec, 3D+4]     -> k_edge_features
+//   4. state_net.0 (GEMM, K = 3D+1 zero-padded to 3D+4) -> LayerNorm + GELU in place -> state_net.4
+//      (GEMM) -> score_head + 2-way softmax combine                              -> gemm.hip, k_*
+// Bound: MFMA f32 (steps 1 and 4: 2*(2(3D+1)H + 2H^2) flops per edge); steps 2-3 are gathers.
+#include "common.hpp"
+
+namespace evi {
+
+constexpr int kEdgeChunk = 65536;
+constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default
+
+__device__ inline float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// node_repr[v,:] = non_text[:] where node_embedding_ids[v] == 0   (retriever.py:497-507)
+__global__ void k_overwrite_non_text(float* __restrict__ node_repr, const int64_t* __restrict__ emb_ids,
+                                     const float* __restrict__ non_text, int64_t N, int D) {
+    const int64_t v = blockIdx.x;
+    if (v >= N || emb_ids[v] != 0) return;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) node_repr[v * D + d] = non_text[d];
+}
+
+// ---- relation de-duplication ---------------------------------------------------------------------
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_first_edge_of_relation(const int64_t* __restrict__ edge_attr, int64_t E, int64_t R,
+                                         int32_t* __restrict__ first, int32_t* __restrict__ status) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t r = edge_attr[e];
+    if (r < 0 || r >= R) {
+        atomicOr(status, 1);
+        return;
+    }
+    atomicMin(&first[r], (int32_t)e);
+}
+// rows[r,:] = edge_embeddings[first[r],:] (zeros for relation ids no edge of the batch uses)
+__global__ void k_gather_relation_rows(const float* __restrict__ edge_emb, const int32_t* __restrict__ first,
+                                       int D, float* __restrict__ rows) {
+    const int64_t r = blockIdx.x;
+    const int32_t e = first[r];
+    for (int d = threadIdx.x; d < D; d += blockDim.x)
+        rows[r * D + d] = e == 0x7FFFFFFF ? 0.f : edge_emb[(int64_t)e * D + d];
+}
+
+// state_net.0.weight [H, 3D+1] -> zero-padded [H, Kp]
+__global__ void k_pad_rows(const float* __restrict__ src, int rows, int K, int Kp, float* __restrict__ dst) {
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) dst[(int64_t)r * Kp + k] = k < K ? src[(int64_t)r * K + k] : 0.f;
+}
+
+// struct_proj.0.weight [D, F] -> transposed [F, D] so lanes read consecutive d
+__global__ void k_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) dst[(i % cols) * rows + (i / cols)] = src[i];
+}
+
+// ---- edge features ----------------------------------------------------------------------------------
+// One wave per edge; lane owns features d = lane + 64 i (i < DPL).  Writes two rows of X.
+struct EdgeFeatArgs {
+    const int64_t* edge_index;  // [2, E]
+    int64_t E;
+    const int64_t* edge_batch;  // [E]
+    const int64_t* edge_attr;   // [E]
+    int rel_by_edge;            // 1: rel_repr row = edge; 0: rel_repr row = edge_attr
+    const float* node_repr;     // [N, D]
+    const float* rel_repr;
+    const float* gate_q;        // [B, D]
+    const float* bias_q;        // [B, D]
+    const float* node_struct;   // [N, F/2]
+    int F;                      // 2 * C * S
+    const float* struct_wt;     // [F, D] (transposed struct_proj.0.weight)
+    const float* struct_b;
+    const float* struct_ln_w;
+    const float* struct_ln_b;
+    const float* struct_gate_w;  // [D]
+    const float* struct_gate_b;  // [1]
+    int D, Kp;
+    int64_t e_begin, e_count;  // chunk
+    int dir_fwd, dir_bwd;
+    float* X;  // [(dir_fwd + dir_bwd) * e_count, Kp]
+};
+
+template <int DPL>
+__global__ __launch_bounds__(256) void k_edge_features(EdgeFeatArgs a) {
+    extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
+    const int D = a.D, F = a.F;
+    for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds_wt[i] = a.struct_wt[i];
+    float* l_b = lds_wt + F * D;
+    float* l_lw = l_b + D;
+    float* l_lb = l_lw + D;
+    float* l_gw = l_lb + D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        l_b[i] = a.struct_b[i];
+        l_lw[i] = a.struct_ln_w[i];
+        l_lb[i] = a.struct_ln_b[i];
+        l_gw[i] = a.struct_gate_w[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const float gate_b = a.struct_gate_b[0];
+    const int half = F >> 1;
+    const float inv_d = 1.0f / (float)D;
+
+    for (int64_t le = (int64_t)blockIdx.x * waves + wave; le < a.e_count; le += (int64_t)gridDim.x * waves) {
+        const int64_t e = a.e_begin + le;
+        const int64_t hv = a.edge_index[e], tv = a.edge_index[a.E + e];
+        const int64_t g = a.edge_batch[e];
+        const int64_t rrow = a.rel_by_edge ? e : a.edge_attr[e];
+        const float* hp = a.node_repr + hv * D;
+        const float* tp = a.node_repr + tv * D;
+        const float* rp = a.rel_repr + rrow * D;
+        const float* gp = a.gate_q + g * D;
+        const float* bp = a.bias_q + g * D;
+        float h[DPL], t[DPL], rc[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) {
+                h[i] = hp[d];
+                t[i] = tp[d];
+                rc[i] = rp[d] * gp[d] + bp[d];
+            } else {
+                h[i] = t[i] = rc[i] = 0.f;
+            }
+        }
+        // raw structure features of head and tail (lane j < half holds element j of each)
+        const float sh_ = lane < half ? a.node_struct[hv * half + lane] : 0.f;
+        const float st_ = lane < half ? a.node_struct[tv * half + lane] : 0.f;
+
+        int out_row = 0;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
+            // struct_raw = cat(ns[a], ns[b]); a = head for fwd, tail for bwd
+            float s[DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                s[i] = d < D ? l_b[d] : 0.f;
+            }
+            for (int j = 0; j < F; ++j) {
+                const float first_half = dir == 0 ? sh_ : st_;
+                const float second_half = dir == 0 ? st_ : sh_;
+                const float raw = j < half ? __shfl(first_half, j, 64) : __shfl(second_half, j - half, 64);
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    const int d = lane + 64 * i;
+                    if (d < D) s[i] = fmaf(lds_wt[j * D + d], raw, s[i]);
+                }
+            }
+            // LayerNorm over D, exact GELU
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) sum += (lane + 64 * i < D) ? s[i] : 0.f;
+            const float mean = wsum(sum) * inv_d;
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const float c = (lane + 64 * i < D) ? s[i] - mean : 0.f;
+                var += c * c;
+            }
+            const float rstd = 1.0f / sqrtf(wsum(var) * inv_d + kLnEps);
+            float gacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                if (d < D) {
+                    s[i] = gelu_erf((s[i] - mean) * rstd * l_lw[d] + l_lb[d]);
+                    gacc = fmaf(l_gw[d], s[i], gacc);
+                }
+            }
+            const float nav = sigmoidf_(wsum(gacc) + gate_b);
+            float* x = a.X + ((int64_t)out_row * a.e_count + le) * a.Kp;
+            float dsq = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                if (d < D) {
+                    const float ha = dir == 0 ? h[i] : t[i];
+                    const float hb = dir == 0 ? t[i] : h[i];
+                    const float err = ha + rc[i] - hb;
+                    x[d] = ha * rc[i] * hb * nav;
+                    x[D + d] = s[i];
+                    x[2 * D + d] = err;
+                    dsq = fmaf(err, err, dsq);
+                }
+            }
+            dsq = wsum(dsq);
+            if (lane < a.Kp - 3 * D) x[3 * D + lane] = lane == 0 ? -sqrtf(dsq) : 0.f;
+            ++out_row;
+        }
+    }
+}
+
+// rows <- GELU(LayerNorm(rows)) in place, one wave per row.
+template <int DPL>
+__global__ __launch_bounds__(256) void k_layernorm_gelu(float* __restrict__ x, int64_t M, int H,
+                                                        const float* __restrict__ w, const float* __restrict__ b) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* p = x + row * H;
+    float v[DPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int d = lane + 64 * i;
+        v[i] = d < H ? p[d] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wsum(sum) / (float)H;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const float c = (lane + 64 * i < H) ? v[i] - mean : 0.f;
+        var += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(wsum(var) / (float)H + kLnEps);
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int d = lane + 64 * i;
+        if (d < H) p[d] = gelu_erf((v[i] - mean) * rstd * w[d] + b[d]);
+    }
+}
+
+// score_head + directional combine (retriever.py:369-381, 482-483), one wave per edge.
+template <int DPL>
+__global__ __launch_bounds__(256) void k_score_combine(
+    const float* __restrict__ feats, int64_t e_begin, int64_t e_count, int H, int dir_fwd, int dir_bwd,
+    const float* __restrict__ score_w, const float* __restrict__ score_b, float* __restrict__ logits,
+    float* __restrict__ logits_fwd, float* __restrict__ logits_bwd, float* __restrict__ edge_features) {
+    const int lane = threadIdx.x & 63;
+    const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (le >= e_count) return;
+    const int64_t e = e_begin + le;
+    const float* ff = feats + le * H;
+    const float* fb = feats + ((dir_fwd ? e_count : 0) + le) * H;
+    float vf[DPL], vb[DPL];
+    float af = 0.f, ab = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int d = lane + 64 * i;
+        vf[i] = (d < H && dir_fwd) ? ff[d] : 0.f;
+        vb[i] = (d < H && dir_bwd) ? fb[d] : 0.f;
+        const float w = d < H ? score_w[d] : 0.f;
+        af = fmaf(vf[i], w, af);
+        ab = fmaf(vb[i], w, ab);
+    }
+    const float lf = wsum(af) + score_b[0];
+    const float lb = wsum(ab) + score_b[0];
+    float wf = 1.f, wb = 0.f, lg = lf;
+    if (dir_fwd && dir_bwd) {
+        const float m = fmaxf(lf, lb);
+        const float ef = expf(lf - m), eb = expf(lb - m);
+        wf = ef / (ef + eb);
+        wb = eb / (ef + eb);
+        lg = wf * lf + wb * lb;
+    } else if (dir_bwd) {
+        wf = 0.f;
+        wb = 1.f;
+        lg = lb;
+    }
+    if (lane == 0) {
+        logits[e] = lg;
+        if (logits_fwd && dir_fwd) logits_fwd[e] = lf;
+        if (logits_bwd && dir_bwd) logits_bwd[e] = lb;
+    }
+    if (edge_features) {
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < H) edge_features[e * H + d] = (dir_fwd && dir_bwd) ? wf * vf[i] + wb * vb[i] : (dir_fwd ? vf[i] : vb[i]);
+        }
+    }
+}
+
+static int dpl_for(int d) {
+    const int need = (d + 63) / 64;
+    const int opts[] = {1, 2, 4, 8, 12, 16, 20};
+    for (int o : opts)
+        if (o >= need) return o;
+    return 0;
+}
+
+#define EVI_DPL_DISPATCH(dpl, CALL)              \
+    switch (dpl) {                               \
+        case 1: { constexpr int DPL = 1; CALL; } break;   \
+        case 2: { constexpr int DPL = 2; CALL; } break;   \
+        case 4: { constexpr int DPL = 4; CALL; } break;   \
+        case 8: { constexpr int DPL = 8; CALL; } break;   \
+        case 12: { constexpr int DPL = 12; CALL; } break; \
+        case 16: { constexpr int DPL = 16; CALL; } break; \
+        default: { constexpr int DPL = 20; CALL; } break; \
+    }
+
+struct FwdLayout {
+    size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
+        in_eid, out_ptr, out_nbr, out_eid, csr_ws, w1p, wt, X, h1, feats, total;
+    int64_t ec;
+    int Kp;
+    int dedupe;
+};
+
+static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, int64_t R, int dirs) {
+    FwdLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    L.dedupe = (R > 0 && R <= E) ? 1 : 0;
+    L.Kp = 3 * D + 4;
+    L.ec = E < kEdgeChunk ? (E > 0 ? E : 1) : kEdgeChunk;
+    const size_t f = sizeof(float);
+    L.node_repr = take((size_t)(N > 0 ? N : 1) * D * f);
+    L.non_text = take((size_t)D * f);
+    L.q_proj = take((size_t)B * D * f);
+    L.gate_q = take((size_t)B * D * f);
+    L.bias_q = take((size_t)B * D * f);
+    L.rel_repr = take((size_t)(L.dedupe ? R : (E > 0 ? E : 1)) * D * f);
+    L.rel_rows = take(L.dedupe ? (size_t)R * D * f : 256);
+    L.rel_first = take(L.dedupe ? (size_t)R * 4 : 256);
+    L.status = take(256);
+    L.ns = take((size_t)(N > 0 ? N : 1) * (F / 2) * f);
+    L.in_ptr = take((size_t)(N + 1) * 4);
+    L.in_nbr = take((size_t)(E > 0 ? E : 1) * 4);
+    L.in_eid = take((size_t)(E > 0 ? E : 1) * 4);
+    L.out_ptr = take((size_t)(N + 1) * 4);
+    L.out_nbr = take((size_t)(E > 0 ? E : 1) * 4);
+    L.out_eid = take((size_t)(E > 0 ? E : 1) * 4);
+    L.csr_ws = take((size_t)(N > 0 ? N : 1) * 8);
+    L.w1p = take((size_t)H * L.Kp * f);
+    L.wt = take((size_t)F * D * f);
+    L.X = take((size_t)dirs * L.ec * L.Kp * f);
+    L.h1 = take((size_t)dirs * L.ec * H * f);
+    L.feats = take((size_t)dirs * L.ec * H * f);
+    L.total = off;
+    return L;
+}
+
+}  // namespace evi
+
+using namespace evi;
+
+extern "C" int evi_graph_csr(const int64_t*, int64_t, const int64_t*, const int64_t*, int, int64_t, int32_t*, int32_t*,
+                             int32_t*, int32_t*, int32_t*, int32_t*, void*, size_t, void*);
+extern "C" int evi_dde_node_struct(const float*, int, int, const int64_t*, int, const int32_t*, const int32_t*,
+                                   const int32_t*, const int32_t*, int, int, float*, void*);
+
+extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
+                                                        int dde_reverse_rounds, int64_t num_relations) {
+    if (N < 0 || E < 0 || B < 1 || D < 1 || H < 1) return 0;
+    const int F = 2 * 2 * (1 + dde_rounds + dde_reverse_rounds);
+    return fwd_layout(N, E, B, D, H, F, num_relations, 2).total;
+}
+
+extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
+                                     const EviRetrieverOutput* out, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    EVI_REQUIRE(w && b && out, "evi_retriever_forward: null struct pointer");
+    const int D = w->emb_dim, H = w->hidden_dim;
+    const int64_t N = b->num_nodes, E = b->num_edges;
+    const int B = b->num_graphs;
+    EVI_REQUIRE(D >= 1 && H >= 1, "evi_retriever_forward: bad dims emb_dim=%d hidden_dim=%d", D, H);
+    if (D % 4 != 0 || H % 4 != 0 || D > 1280 || H > 1280)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_retriever_forward: emb_dim/hidden_dim must be multiples of 4 and <= 1280, got %d/%d", D, H);
+    if (w->num_topics != 2) return fail(EVI_ERR_INVALID, "num_topics must be 2 (seed vs non-seed), got %d", w->num_topics);
+    EVI_REQUIRE(w->dde_rounds >= 0 && w->dde_rounds <= 4 && w->dde_reverse_rounds >= 0 && w->dde_reverse_rounds <= 4,
+                "DDE supports at most 4 rounds per direction; got num_rounds=%d, num_reverse_rounds=%d.",
+                w->dde_rounds, w->dde_reverse_rounds);
+    EVI_REQUIRE(direction_mode >= 0 && direction_mode <= 2,
+                "direction_mode must be one of {'bidirectional', 'forward', 'backward'}");
+    EVI_REQUIRE(B >= 1, "num_graphs must be positive, got %d", B);
+    EVI_REQUIRE(N >= 1, "total_nodes must be positive, got %lld", (long long)N);
+    EVI_REQUIRE(E >= 0, "evi_retriever_forward: negative edge count");
+    if (E == 0) return EVI_OK;  // reference returns empty outputs (:206-207)
+    EVI_REQUIRE(b->edge_index, "Batch missing edge_index required for scoring.");
+    EVI_REQUIRE(b->question_emb && b->node_embedding_ids && b->edge_attr,
+                "Batch must provide question_emb, node_embedding_ids, and edge_attr.");
+    EVI_REQUIRE(b->node_embeddings && b->edge_embeddings, "Batch must provide node_embeddings and edge_embeddings.");
+    EVI_REQUIRE(b->topic_one_hot, "topic_one_hot is required for DDE-based structure features.");
+    EVI_REQUIRE(b->topic_stride >= 2, "topic_one_hot feature dim %d < num_topics=2", b->topic_stride);
+    EVI_REQUIRE(b->node_ptr && b->edge_ptr && b->edge_batch, "evi_retriever_forward: node_ptr/edge_ptr/edge_batch required");
+    EVI_REQUIRE(out->logits, "evi_retriever_forward: output logits pointer is null");
+    const int dir_fwd = direction_mode != 2, dir_bwd = direction_mode != 1;
+    const int dirs = dir_fwd + dir_bwd;
+    const int S = 1 + w->dde_rounds + w->dde_reverse_rounds;
+    const int F = 2 * 2 * S;
+    const FwdLayout L = fwd_layout(N, E, B, D, H, F, b->num_relations, 2);
+    EVI_REQUIRE(workspace, "evi_retriever_forward: null workspace");
+    if (workspace_bytes < L.total)
+        return fail(EVI_ERR_NOMEM, "evi_retriever_forward: workspace %zu B < %zu B", workspace_bytes, L.total);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* base = static_cast<char*>(workspace);
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
+    float* node_repr = F32(L.node_repr);
+    float* non_text = F32(L.non_text);
+    float* q_proj = F32(L.q_proj);
+    float* gate_q = F32(L.gate_q);
+    float* bias_q = F32(L.bias_q);
+    float* rel_repr = F32(L.rel_repr);
+    float* ns = out->node_struct ? out->node_struct : F32(L.ns);
+    int rc;
+
+    // 1. projections
+    if ((rc = launch_gemm_nt(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, st))) return rc;
+    if ((rc = launch_gemm_nt(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, st))) return rc;
+    hipLaunchKernelGGL(k_overwrite_non_text, dim3((unsigned)N), dim3(256), 0, st, node_repr, b->node_embedding_ids,
+                       non_text, N, D);
+    EVI_LAUNCH_CHECK();
+    if ((rc = launch_gemm_nt(b->question_emb, B, D, D, w->query_w, D, D, w->query_b, 1, q_proj, D, st))) return rc;
+    if ((rc = launch_gemm_nt(q_proj, B, D, D, w->q_gate_w, D, D, w->q_gate_b, 2, gate_q, D, st))) return rc;
+    if ((rc = launch_gemm_nt(q_proj, B, D, D, w->q_bias_w, D, D, w->q_bias_b, 1, bias_q, D, st))) return rc;
+    if (L.dedupe) {
+        const int64_t R = b->num_relations;
+        int32_t* first = I32(L.rel_first);
+        int32_t* status = I32(L.status);
+        EVI_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
+        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, first, R, 0x7FFFFFFF);
+        hipLaunchKernelGGL(k_first_edge_of_relation, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr,
+                           E, R, first, status);
+        hipLaunchKernelGGL(k_gather_relation_rows, dim3((unsigned)R), dim3(256), 0, st, b->edge_embeddings, first, D,
+                           F32(L.rel_rows));
+        EVI_LAUNCH_CHECK();
+        if ((rc = launch_gemm_nt(F32(L.rel_rows), R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, st))) return rc;
+    } else {
+        if ((rc = launch_gemm_nt(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, st))) return rc;
+    }
+
+    // 2. structure features
+    if ((rc = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
+                            I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
+                            (size_t)N * 8, stream)))
+        return rc;
+    if ((rc = evi_dde_node_struct(b->topic_one_hot, b->topic_stride, 2, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
+                                  I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
+        return rc;
+
+    // 3-4. per edge chunk
+    const int K1 = 3 * D + 1;
+    hipLaunchKernelGGL(k_pad_rows, dim3(H), dim3(256), 0, st, w->state0_w, H, K1, L.Kp, F32(L.w1p));
+    hipLaunchKernelGGL(k_transpose, dim3((F * D + 255) / 256), dim3(256), 0, st, w->struct_w, D, F, F32(L.wt));
+    EVI_LAUNCH_CHECK();
+    const int dpl_d = dpl_for(D), dpl_h = dpl_for(H);
+    const size_t feat_lds = (size_t)(F + 4) * D * sizeof(float);
+    for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
+        const int64_t ec = (E - e0) < L.ec ? (E - e0) : L.ec;
+        EdgeFeatArgs a;
+        a.edge_index = b->edge_index;
+        a.E = E;
+        a.edge_batch = b->edge_batch;
+        a.edge_attr = b->edge_attr;
+        a.rel_by_edge = L.dedupe ? 0 : 1;
+        a.node_repr = node_repr;
+        a.rel_repr = rel_repr;
+        a.gate_q = gate_q;
+        a.bias_q = bias_q;
+        a.node_struct = ns;
+        a.F = F;
+        a.struct_wt = F32(L.wt);
+        a.struct_b = w->struct_b;
+        a.struct_ln_w = w->struct_ln_w;
+        a.struct_ln_b = w->struct_ln_b;
+        a.struct_gate_w = w->struct_gate_w;
+        a.struct_gate_b = w->struct_gate_b;
+        a.D = D;
+        a.Kp = L.Kp;
+        a.e_begin = e0;
+        a.e_count = ec;
+        a.dir_fwd = dir_fwd;
+        a.dir_bwd = dir_bwd;
+        a.X = F32(L.X);
+        int64_t blocks = (ec + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        const int tok = timing_begin(kTimeEdge, st);
+        EVI_DPL_DISPATCH(dpl_d, {
+            static thread_local bool attr = false;
+            if (!attr) {
+                EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(256), feat_lds, st, a);
+        });
+        timing_end(tok, st);
+        EVI_LAUNCH_CHECK();
+        const int64_t M = (int64_t)dirs * ec;
+        if ((rc = launch_gemm_nt(F32(L.X), M, L.Kp, L.Kp, F32(L.w1p), H, L.Kp, w->state0_b, 0, F32(L.h1), H, st))) return rc;
+        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_layernorm_gelu<DPL>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st,
+                                                   F32(L.h1), M, H, w->state_ln_w, w->state_ln_b));
+        EVI_LAUNCH_CHECK();
+        if ((rc = launch_gemm_nt(F32(L.h1), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, st))) return rc;
+        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_score_combine<DPL>, dim3((unsigned)((ec + 3) / 4)), dim3(256), 0, st,
+                                                   F32(L.feats), e0, ec, H, dir_fwd, dir_bwd, w->score_w, w->score_b,
+                                                   out->logits, out->logits_fwd, out->logits_bwd, out->edge_features));
+        EVI_LAUNCH_CHECK();
+    }
+    return EVI_OK;
+}

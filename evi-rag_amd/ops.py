@@ -194,3 +194,115 @@ def segment_topk(scores: torch.Tensor, edge_ptr: torch.Tensor, k: int, *, want_s
         lib.evi_segment_topk(_ptr(s), _ptr(ptr), B, int(k), _ptr(out_index), _ptr(out_score), _ptr(out_count), _stream(dev))
     )
     return out_index, out_score, out_count
+
+
+# ---- graph structure -----------------------------------------------------------------------------
+
+def _i64c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.int64:
+        raise ValueError(f"{name} must be int64, got {t.dtype}")
+    return t.contiguous()
+
+
+def edge_batch(edge_index: torch.Tensor, node_ptr: torch.Tensor):
+    """(edge_batch [E] i64, edge_ptr [B+1] i64, status int) — see evi_edge_batch.  Reading `status`
+    synchronises the stream, as the reference's `.item()` checks do (src/utils/graph_utils.py:65-99)."""
+    dev = _require_gpu(edge_index, node_ptr)
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+    ei = _i64c(edge_index, "edge_index")
+    ptr = _i64c(node_ptr.view(-1), "node_ptr")
+    E, B = ei.size(1), ptr.numel() - 1
+    eb = torch.empty(E, dtype=torch.int64, device=dev)
+    eptr = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(B + 1, dtype=torch.int32, device=dev)  # [B] counts + [1] status
+    lib = _lib.load()
+    _lib.check(lib.evi_edge_batch(_ptr(ei), E, _ptr(ptr), B, _ptr(eb), _ptr(eptr), scratch.data_ptr(),
+                                  scratch.data_ptr() + 4 * B, _stream(dev)))
+    return eb, eptr, scratch[B:]
+
+
+def qa_edge_mask(edge_index: torch.Tensor, num_nodes: int, q_local_indices: torch.Tensor,
+                 a_local_indices: torch.Tensor) -> torch.Tensor:
+    dev = _require_gpu(edge_index)
+    ei = _i64c(edge_index, "edge_index")
+    E = ei.size(1)
+    q = _i64c(q_local_indices.to(dev).view(-1), "q_local_indices")
+    a = _i64c(a_local_indices.to(dev).view(-1), "a_local_indices")
+    out = torch.empty(E, dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(num_nodes) + 4, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.evi_qa_edge_mask(_ptr(ei), E, int(num_nodes), _ptr(q), q.numel(), _ptr(a), a.numel(), ws.data_ptr(),
+                                    _ptr(out), status.data_ptr(), _stream(dev)))
+    if int(status.item()) != 0:
+        raise ValueError("q/a local indices exceed num_nodes; batch collation is invalid.")
+    return out.bool()
+
+
+class GraphCSR:
+    """In-/out-edge CSR of a batch (device int32 arrays)."""
+
+    def __init__(self, in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid):
+        self.in_ptr, self.in_nbr, self.in_eid = in_ptr, in_nbr, in_eid
+        self.out_ptr, self.out_nbr, self.out_eid = out_ptr, out_nbr, out_eid
+
+
+def graph_csr(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr: torch.Tensor) -> GraphCSR:
+    dev = _require_gpu(edge_index, node_ptr, edge_ptr)
+    ei = _i64c(edge_index, "edge_index")
+    ptr = _i64c(node_ptr.view(-1), "node_ptr")
+    eptr = _i64c(edge_ptr.view(-1), "edge_ptr")
+    E, B = ei.size(1), ptr.numel() - 1
+    N = int(ptr[-1].item())
+    mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)  # noqa: E731
+    csr = GraphCSR(mk(N + 1), mk(E), mk(E), mk(N + 1), mk(E), mk(E))
+    lib = _lib.load()
+    ws = _workspace(dev, "graph_csr", int(lib.evi_graph_csr_workspace_bytes(N)))
+    _lib.check(lib.evi_graph_csr(_ptr(ei), E, _ptr(ptr), _ptr(eptr), B, N, csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
+                                 csr.in_eid.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
+                                 csr.out_eid.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+    return csr
+
+
+def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: GraphCSR, num_rounds: int,
+                    num_reverse_rounds: int, num_topics: int = 2) -> torch.Tensor:
+    dev = _require_gpu(topic_one_hot, node_ptr)
+    t = _f32c(topic_one_hot, "topic_one_hot")
+    if t.dim() == 1:
+        t = t.unsqueeze(-1)
+    ptr = _i64c(node_ptr.view(-1), "node_ptr")
+    N, B = t.size(0), ptr.numel() - 1
+    S = 1 + int(num_rounds) + int(num_reverse_rounds)
+    ns = torch.empty((N, num_topics * S), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.evi_dde_node_struct(_ptr(t), t.size(1), int(num_topics), _ptr(ptr), B, csr.in_ptr.data_ptr(),
+                                       csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
+                                       int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))
+    return ns
+
+
+# ---- dense building block --------------------------------------------------------------------------
+
+_ACT = {None: 0, "none": 0, "tanh": 1, "sigmoid": 2}
+
+
+def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str] = None) -> torch.Tensor:
+    """act(x @ weight.T + bias) on the MFMA f32 GEMM (rows of x and weight must be 16-byte multiples)."""
+    dev = _require_gpu(x, weight, bias)
+    x2 = _f32c(x.reshape(-1, x.shape[-1]), "x")
+    w = _f32c(weight, "weight")
+    M, K = x2.shape
+    N = w.size(0)
+    if w.size(1) != K:
+        raise ValueError(f"weight in_features {w.size(1)} != input dim {K}")
+    if K % 4 != 0:  # zero-pad K to a 16-byte multiple
+        pad = 4 - K % 4
+        x2 = torch.nn.functional.pad(x2, (0, pad))
+        w = torch.nn.functional.pad(w, (0, pad))
+        K += pad
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.evi_gemm_nt_f32(_ptr(x2), M, K, K, _ptr(w), N, K, _ptr(_f32c(bias, "bias")) if bias is not None else None,
+                                   _ACT[act], _ptr(out), N, _stream(dev)))
+    return out.reshape(*x.shape[:-1], N)

@@ -1,0 +1,348 @@
+"""Host-side mirror of `src.models.components.retriever.Retriever` (the reference's `_target_` at
+configs/model/retriever_module.yaml:8-25) backed by libevi_hip.so.
+
+Same constructor kwargs, same `state_dict` keys and shapes (so `load_state_dict(strict=True)` of a
+reference checkpoint works, src/eval.py:80-111), same `forward(batch) -> RetrieverOutput` and
+`extract_edge_tokens(batch)` contracts, same error types and messages.  The arithmetic runs in
+`evi_retriever_forward`; this module only owns the parameters and marshals pointers.
+
+Scope: the evaluation path (eval mode, no autograd).  Training (dropout, hide-and-seek bias,
+backward) is out of scope for this build and raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+_NUM_TOPICS_BINARY = 2
+_MAX_DDE_ROUNDS = 4
+_DIRECTION_CODE = {"bidirectional": 0, "forward": 1, "backward": 2}
+
+
+@dataclass
+class RetrieverOutput:
+    """reference: RetrieverOutput, src/models/components/retriever.py:80-99."""
+
+    logits: torch.Tensor
+    query_ids: torch.Tensor
+    relation_ids: Optional[torch.Tensor] = None
+    logits_fwd: Optional[torch.Tensor] = None
+    logits_bwd: Optional[torch.Tensor] = None
+    edge_embeddings: Optional[torch.Tensor] = None
+
+    def detach(self) -> "RetrieverOutput":
+        d = lambda t: t.detach() if t is not None else None  # noqa: E731
+        return RetrieverOutput(d(self.logits), d(self.query_ids), d(self.relation_ids), d(self.logits_fwd),
+                               d(self.logits_bwd), d(self.edge_embeddings))
+
+
+class EmbeddingProjector(nn.Module):
+    """Linear + Tanh; parameters live under `.network.0` as in
+    src/models/components/projections.py:9-40.  forward() runs on the MFMA f32 GEMM."""
+
+    def __init__(self, output_dim: int, *, input_dim: Optional[int] = None, finetune: bool = False) -> None:
+        super().__init__()
+        if input_dim is None or input_dim <= 0:
+            raise ValueError("EmbeddingProjector requires a positive input_dim; lazy layers are disallowed.")
+        self.network = nn.Sequential(nn.Linear(input_dim, output_dim), nn.Tanh())
+        if not finetune:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def forward(self, tensor: torch.Tensor) -> torch.Tensor:
+        lin = self.network[0]
+        return ops.linear_act(tensor, lin.weight.detach(), lin.bias.detach(), "tanh")
+
+
+class DDE(nn.Module):
+    """Parameter-free holder of the DDE round counts (src/models/components/graph.py:26-40)."""
+
+    def __init__(self, num_rounds: int = 2, num_reverse_rounds: int = 2) -> None:
+        super().__init__()
+        self.num_rounds = int(max(0, num_rounds))
+        self.num_reverse_rounds = int(max(0, num_reverse_rounds))
+        if self.num_rounds > _MAX_DDE_ROUNDS or self.num_reverse_rounds > _MAX_DDE_ROUNDS:
+            raise ValueError(
+                f"DDE supports at most {_MAX_DDE_ROUNDS} rounds per direction; "
+                f"got num_rounds={self.num_rounds}, num_reverse_rounds={self.num_reverse_rounds}."
+            )
+
+
+def compute_edge_batch(edge_index: torch.Tensor, *, node_ptr: torch.Tensor, num_graphs: int,
+                       device: Optional[torch.device] = None, debug_batch: object = None):
+    """(edge_batch, edge_ptr) with the reference's validation errors.
+    reference: compute_edge_batch, src/utils/graph_utils.py:50-104."""
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+    if node_ptr.numel() != num_graphs + 1:
+        raise ValueError(f"node_ptr length mismatch: got {node_ptr.numel()} expected {num_graphs + 1}")
+    eb, eptr, status = ops.edge_batch(edge_index, node_ptr)
+    st = int(status.item())
+    if st & 1:
+        raise ValueError(f"edge_batch contains out-of-range indices; num_graphs={num_graphs}.")
+    if st & 2:
+        raise ValueError("edge_index crosses graph boundaries; head/tail graph assignments differ. ")
+    if st & 4:
+        raise ValueError(
+            "edge_batch is not non-decreasing along the flattened edge list, which breaks per-graph slicing; "
+            "Ensure edges are concatenated per-graph (PyG Batch)."
+        )
+    return eb, eptr
+
+
+def compute_qa_edge_mask(edge_index: torch.Tensor, *, num_nodes: int, q_local_indices: torch.Tensor,
+                         a_local_indices: torch.Tensor) -> torch.Tensor:
+    """reference: compute_qa_edge_mask, src/utils/graph_utils.py:107-153."""
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+    if int(num_nodes) <= 0:
+        raise ValueError(f"num_nodes must be positive, got {num_nodes}")
+    q = torch.as_tensor(q_local_indices, dtype=torch.long)
+    a = torch.as_tensor(a_local_indices, dtype=torch.long)
+    return ops.qa_edge_mask(edge_index, int(num_nodes), q, a)
+
+
+class Retriever(nn.Module):
+    """Drop-in for src.models.components.retriever.Retriever (eval path)."""
+
+    def __init__(
+        self,
+        emb_dim: int,
+        hidden_dim: int,
+        topic_pe: bool = True,
+        num_topics: int = 2,
+        dde_cfg: Optional[Dict[str, int]] = None,
+        dropout_p: float = 0.1,
+        core_mode: str = "geometry",
+        direction_mode: str = "bidirectional",
+        hide_seek_cfg: Optional[Dict[str, Any]] = None,
+        dedupe_relations: bool = True,
+        **_: Any,
+    ) -> None:
+        super().__init__()
+        self.emb_dim = int(emb_dim)
+        self.hidden_dim = int(hidden_dim)
+        self.use_topic_pe = bool(topic_pe)
+        if not self.use_topic_pe:
+            raise ValueError("topic_pe must be enabled; retriever requires topic_one_hot + DDE.")
+        self.num_topics = int(num_topics)
+        if self.num_topics != _NUM_TOPICS_BINARY:
+            raise ValueError(f"num_topics must be {_NUM_TOPICS_BINARY} (seed vs non-seed), got {self.num_topics}")
+        if str(core_mode or "").strip().lower() not in {"geometry", "structured", "full"}:
+            raise ValueError(f"core_mode must be 'geometry' for DDE-based retriever, got {core_mode!r}")
+        mode = str(direction_mode or "").strip().lower()
+        if mode not in _DIRECTION_CODE:
+            raise ValueError(
+                "direction_mode must be one of {'bidirectional', 'forward', 'backward'}, " f"got {direction_mode!r}."
+            )
+        self.direction_mode = mode
+        self.dedupe_relations = bool(dedupe_relations)
+
+        # construction order == the reference's, so the same torch seed gives the same init
+        D, H = self.emb_dim, self.hidden_dim
+        self.entity_proj = EmbeddingProjector(D, input_dim=D, finetune=True)
+        self.relation_proj = EmbeddingProjector(D, input_dim=D, finetune=True)
+        self.query_proj = EmbeddingProjector(D, input_dim=D, finetune=True)
+        self.non_text_entity_emb = nn.Embedding(1, D)
+        self.dde = DDE(**(dde_cfg or {}))
+        rounds, rev = self.dde.num_rounds, self.dde.num_reverse_rounds
+        self._topic_struct_dim = self.num_topics * (1 + rounds + rev)
+        self.register_buffer("parity_meta", torch.tensor([1, self.num_topics, rounds, rev], dtype=torch.long))
+        self.q_gate = nn.Sequential(nn.Linear(D, D), nn.Sigmoid())
+        self.q_bias = nn.Sequential(nn.Linear(D, D), nn.Tanh())
+        self.struct_proj = nn.Sequential(nn.Linear(2 * self._topic_struct_dim, D), nn.LayerNorm(D), nn.GELU())
+        self.struct_gate_net = nn.Sequential(nn.Linear(D, 1), nn.Sigmoid())
+        self.state_net = nn.Sequential(nn.Linear(3 * D + 1, H), nn.LayerNorm(H), nn.GELU(), nn.Dropout(dropout_p),
+                                       nn.Linear(H, H))
+        self.score_head = nn.Linear(H, 1)
+        cfg = hide_seek_cfg or {}
+        self.hide_seek_enabled = bool(cfg.get("enabled", False))
+        self.hide_seek_apply_in_eval = bool(cfg.get("apply_in_eval", False))
+        for name in ("p_near", "p_far"):
+            prob = float(cfg.get(name, 0.0))
+            if prob < 0.0 or prob > 1.0:
+                raise ValueError(f"hide_seek_cfg.{name} must be in [0, 1], got {prob}")
+        for name in ("bias_near", "bias_far"):
+            bias = float(cfg.get(name, 0.0))
+            if bias > 0.0:
+                raise ValueError(f"hide_seek_cfg.{name} must be <= 0 (penalty), got {bias}")
+
+    # ---- public API ----------------------------------------------------------------------------------
+    def forward(self, batch: Any) -> RetrieverOutput:
+        output, _ = self._forward_impl(batch, return_features=False)
+        return output
+
+    def extract_edge_tokens(self, batch: Any) -> torch.Tensor:
+        _, features = self._forward_impl(batch, return_features=True)
+        if features is None:
+            raise RuntimeError("extract_edge_tokens expected non-empty features but got None.")
+        return features
+
+    # ---- internals -----------------------------------------------------------------------------------
+    def _weights_struct(self) -> _lib.EviRetrieverWeights:
+        p = lambda t: t.detach().data_ptr()  # noqa: E731
+        w = _lib.EviRetrieverWeights()
+        w.emb_dim, w.hidden_dim, w.num_topics = self.emb_dim, self.hidden_dim, self.num_topics
+        w.dde_rounds, w.dde_reverse_rounds = self.dde.num_rounds, self.dde.num_reverse_rounds
+        for name, mod in (("entity", self.entity_proj), ("relation", self.relation_proj), ("query", self.query_proj)):
+            setattr(w, f"{name}_w", p(mod.network[0].weight))
+            setattr(w, f"{name}_b", p(mod.network[0].bias))
+        w.non_text_emb = p(self.non_text_entity_emb.weight)
+        w.q_gate_w, w.q_gate_b = p(self.q_gate[0].weight), p(self.q_gate[0].bias)
+        w.q_bias_w, w.q_bias_b = p(self.q_bias[0].weight), p(self.q_bias[0].bias)
+        w.struct_w, w.struct_b = p(self.struct_proj[0].weight), p(self.struct_proj[0].bias)
+        w.struct_ln_w, w.struct_ln_b = p(self.struct_proj[1].weight), p(self.struct_proj[1].bias)
+        w.struct_gate_w, w.struct_gate_b = p(self.struct_gate_net[0].weight), p(self.struct_gate_net[0].bias)
+        w.state0_w, w.state0_b = p(self.state_net[0].weight), p(self.state_net[0].bias)
+        w.state_ln_w, w.state_ln_b = p(self.state_net[1].weight), p(self.state_net[1].bias)
+        w.state4_w, w.state4_b = p(self.state_net[4].weight), p(self.state_net[4].bias)
+        w.score_w, w.score_b = p(self.score_head.weight), p(self.score_head.bias)
+        return w
+
+    def _empty_output(self, head_idx: torch.Tensor, return_features: bool):
+        dev = head_idx.device
+        empty = torch.empty(0, device=dev, dtype=torch.float32)
+        feats = torch.empty((0, self.hidden_dim), device=dev, dtype=torch.float32)
+        out = RetrieverOutput(logits=empty, query_ids=head_idx.new_empty(0), relation_ids=None, logits_fwd=empty,
+                              logits_bwd=empty, edge_embeddings=feats)
+        return out, (feats if return_features else None)
+
+    def _forward_impl(self, batch: Any, *, return_features: bool):
+        if self.training:
+            raise NotImplementedError(
+                "evi_rag_amd.Retriever implements the evaluation path only; call .eval() "
+                "(training / hide-and-seek / backward are out of scope for this build)."
+            )
+        if self.hide_seek_enabled and self.hide_seek_apply_in_eval:
+            raise NotImplementedError("hide_seek_cfg.apply_in_eval=true is not supported by the HIP eval path.")
+        param = self.score_head.weight
+        dev = param.device
+        if dev.type != "cuda":
+            raise RuntimeError("evi_rag_amd.Retriever runs on the MI355X only: move the module to a GPU "
+                               "(there is no CPU fallback).")
+        if param.dtype != torch.float32:
+            raise ValueError("evi_rag_amd.Retriever computes in float32 (trainer precision 32-true)")
+        edge_index = getattr(batch, "edge_index", None)
+        if edge_index is None:
+            raise ValueError("Batch missing edge_index required for scoring.")
+        edge_index = edge_index.to(device=dev, dtype=torch.long).contiguous()
+        head_idx = edge_index[0]
+        if head_idx.numel() == 0:
+            return self._empty_output(head_idx, return_features)
+
+        question_emb = getattr(batch, "question_emb", None)
+        node_embedding_ids = getattr(batch, "node_embedding_ids", None)
+        edge_attr = getattr(batch, "edge_attr", None)
+        if question_emb is None or node_embedding_ids is None or edge_attr is None:
+            raise ValueError("Batch must provide question_emb, node_embedding_ids, and edge_attr.")
+        node_embeddings = getattr(batch, "node_embeddings", None)
+        edge_embeddings = getattr(batch, "edge_embeddings", None)
+        if node_embeddings is None or edge_embeddings is None:
+            raise ValueError("Batch must provide node_embeddings and edge_embeddings.")
+        topic_one_hot = getattr(batch, "topic_one_hot", None)
+        if topic_one_hot is None:
+            raise ValueError("topic_one_hot is required for DDE-based structure features.")
+        if getattr(batch, "reverse_edge_index", None) is not None:
+            raise NotImplementedError("a custom reverse_edge_index is not supported; the reverse rounds use edge_index.flip(0)")
+        node_ptr = getattr(batch, "ptr", None)
+        if node_ptr is None:
+            raise ValueError("Batch missing ptr required for edge_batch computation.")
+
+        f32 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()  # noqa: E731
+        i64 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.long, non_blocking=True).contiguous()  # noqa: E731
+        question_emb, node_embeddings, edge_embeddings = f32(question_emb), f32(node_embeddings), f32(edge_embeddings)
+        node_embedding_ids, edge_attr, node_ptr = i64(node_embedding_ids).view(-1), i64(edge_attr).view(-1), i64(node_ptr).view(-1)
+        topic_one_hot = f32(topic_one_hot)
+        if topic_one_hot.dim() == 1:
+            topic_one_hot = topic_one_hot.unsqueeze(-1)
+        if topic_one_hot.dim() != 2:
+            raise ValueError(f"topic_one_hot must be 2D (N, C), got shape {tuple(topic_one_hot.shape)}")
+        E = int(edge_index.size(1))
+        N = int(node_embeddings.size(0))
+        B = int(node_ptr.numel() - 1)
+        D, H = self.emb_dim, self.hidden_dim
+        if B <= 0:
+            raise ValueError(f"num_graphs must be positive, got {B}")
+        if topic_one_hot.size(0) != N:
+            raise ValueError(f"topic_one_hot first dim {topic_one_hot.size(0)} != num_nodes {N}")
+        if topic_one_hot.size(-1) < self.num_topics:
+            raise ValueError(
+                f"topic_one_hot feature dim {topic_one_hot.size(-1)} < num_topics={self.num_topics}; "
+                "rebuild g_retrieval caches or update configs/build_retrieval_pipeline.yaml."
+            )
+        for name, t, rows in (("question_emb", question_emb, B), ("node_embeddings", node_embeddings, N),
+                              ("edge_embeddings", edge_embeddings, E)):
+            if t.dim() != 2 or t.size(0) != rows or t.size(1) != D:
+                raise ValueError(f"{name} must have shape [{rows}, {D}], got {tuple(t.shape)}")
+        if node_embedding_ids.numel() != N or edge_attr.numel() != E:
+            raise ValueError("node_embedding_ids / edge_attr length mismatch with node_embeddings / edge_index")
+
+        # query ids (edge -> graph), validated as the reference validates them (:572-620)
+        edge_batch = getattr(batch, "edge_batch", None)
+        edge_ptr = getattr(batch, "edge_ptr", None)
+        if edge_batch is None or edge_ptr is None:
+            total_nodes = int(node_ptr[-1].item())
+            if total_nodes <= 0:
+                raise ValueError(f"total_nodes must be positive, got {total_nodes}")
+            mn, mx = int(edge_index.min().item()), int(edge_index.max().item())
+            if mn < 0 or mx >= total_nodes:
+                raise ValueError(f"Invalid edge_index range; edge_index out of range: min={mn} max={mx} "
+                                 f"total_nodes={total_nodes} num_graphs={B}.")
+            edge_batch, edge_ptr = compute_edge_batch(edge_index, node_ptr=node_ptr, num_graphs=B, device=dev)
+            try:
+                batch.edge_batch = edge_batch  # the reference caches it on the batch too (:612)
+            except Exception:  # pragma: no cover - read-only batch objects
+                pass
+        edge_batch, edge_ptr = i64(edge_batch).view(-1), i64(edge_ptr).view(-1)
+        if edge_batch.numel() != E:
+            raise ValueError(f"edge_batch length mismatch: {edge_batch.numel()} vs edges {E}")
+
+        num_relations = 0
+        if self.dedupe_relations:
+            hint = getattr(batch, "num_relations", None)
+            num_relations = int(hint) if hint is not None else int(edge_attr.max().item()) + 1
+            if num_relations > E or int(edge_attr.min().item()) < 0:
+                num_relations = 0
+
+        lib = _lib.load()
+        logits = torch.empty(E, dtype=torch.float32, device=dev)
+        both = self.direction_mode == "bidirectional"
+        logits_fwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "backward" else None
+        logits_bwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "forward" else None
+        features = torch.empty((E, H), dtype=torch.float32, device=dev)
+        w = self._weights_struct()
+        b = _lib.EviRetrieverBatch()
+        b.num_nodes, b.num_edges, b.num_graphs = N, E, B
+        b.edge_index, b.node_ptr, b.edge_ptr, b.edge_batch = (edge_index.data_ptr(), node_ptr.data_ptr(),
+                                                             edge_ptr.data_ptr(), edge_batch.data_ptr())
+        b.question_emb, b.node_embeddings = question_emb.data_ptr(), node_embeddings.data_ptr()
+        b.node_embedding_ids, b.edge_embeddings = node_embedding_ids.data_ptr(), edge_embeddings.data_ptr()
+        b.edge_attr, b.num_relations = edge_attr.data_ptr(), num_relations
+        b.topic_one_hot, b.topic_stride = topic_one_hot.data_ptr(), int(topic_one_hot.size(1))
+        o = _lib.EviRetrieverOutput()
+        o.logits = logits.data_ptr()
+        o.logits_fwd = logits_fwd.data_ptr() if logits_fwd is not None else None
+        o.logits_bwd = logits_bwd.data_ptr() if logits_bwd is not None else None
+        o.edge_features = features.data_ptr()
+        o.node_struct = None
+        need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,
+                                                             self.dde.num_reverse_rounds, num_relations))
+        ws = ops._workspace(dev, "retriever_forward", need)
+        _lib.check(lib.evi_retriever_forward(ctypes.byref(w), ctypes.byref(b), _DIRECTION_CODE[self.direction_mode],
+                                             ctypes.byref(o), ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream(dev).cuda_stream))
+        if not both:  # single-direction modes: logits IS the directional logit (:267-276)
+            logits_fwd = logits if self.direction_mode == "forward" else None
+            logits_bwd = logits if self.direction_mode == "backward" else None
+        output = RetrieverOutput(logits=logits, query_ids=edge_batch, relation_ids=getattr(batch, "edge_attr", None),
+                                 logits_fwd=logits_fwd, logits_bwd=logits_bwd, edge_embeddings=features)
+        return output, (features if return_features else None)
+
+
+__all__ = ["Retriever", "RetrieverOutput", "EmbeddingProjector", "DDE", "compute_edge_batch", "compute_qa_edge_mask"]

@@ -127,6 +127,136 @@ int evi_topk_merge(const float* scores, const int64_t* ids, int P, int Q, int k,
 int evi_segment_topk(const float* scores, const int64_t* edge_ptr, int B, int k,
                      int32_t* out_index, float* out_score, int32_t* out_count, void* stream);
 
+/* ---- G11: edge -> graph assignment and the Q/A "near" mask --------------------------------- */
+
+/* edge_batch[e] = bucketize(edge_index[0, e], node_ptr[1:], right=True) (node_ptr[g] <= v <
+ * node_ptr[g+1]); edge_ptr = exclusive prefix of the per-graph edge counts.  `status` (one int32
+ * on the device) receives a bit mask the host shim turns into the reference's ValueErrors:
+ * 1 = graph id out of range, 2 = head and tail in different graphs ("edge_index crosses graph
+ * boundaries"), 4 = edge list not grouped by graph ("edge_batch is not non-decreasing").
+ *   edge_index [2, E] i64; node_ptr [B+1] i64; edge_batch [E] i64; edge_ptr [B+1] i64;
+ *   edge_count_ws [B] i32 scratch.
+ * Replaces compute_edge_batch, src/utils/graph_utils.py:50-104. */
+int evi_edge_batch(const int64_t* edge_index, int64_t E, const int64_t* node_ptr, int B,
+                   int64_t* edge_batch, int64_t* edge_ptr, int32_t* edge_count_ws, int32_t* status,
+                   void* stream);
+
+/* out_mask[e] = head in (Q u A) or tail in (Q u A); status bit 1 = a q/a index outside
+ * [0, num_nodes).  node_mask_ws: [num_nodes] bytes of scratch.
+ * Replaces compute_qa_edge_mask, src/utils/graph_utils.py:107-153. */
+int evi_qa_edge_mask(const int64_t* edge_index, int64_t E, int64_t num_nodes, const int64_t* q_idx,
+                     int64_t nq, const int64_t* a_idx, int64_t na, uint8_t* node_mask_ws,
+                     uint8_t* out_mask, int32_t* status, void* stream);
+
+/* ---- G1: adjacency as CSR ------------------------------------------------------------------- */
+
+/* In-edge and out-edge CSR of every graph of the batch (one workgroup per graph).  Row v of the
+ * in-CSR lists (source node, edge id) of the edges u -> v; the out-CSR lists (target, edge id) of
+ * v -> w.  Together they are the undirected adjacency of _build_undirected_adjacency
+ * (scripts/build_retrieval_pipeline.py:570-586); self loops appear once in each half.  Node and
+ * edge ids are batch-global int32; the order inside a row is unspecified.
+ *   *_ptr [N+1] i32, *_nbr [E] i32, *_eid [E] i32; workspace: evi_graph_csr_workspace_bytes(N). */
+size_t evi_graph_csr_workspace_bytes(int64_t N);
+int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t* node_ptr, const int64_t* edge_ptr,
+                  int B, int64_t N, int32_t* in_ptr, int32_t* in_nbr, int32_t* in_eid, int32_t* out_ptr,
+                  int32_t* out_nbr, int32_t* out_eid, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- G6/G7: DDE structure features ----------------------------------------------------------- */
+
+/* node_struct[v, c*S + j], S = 1 + rounds + rev_rounds (topic-major, as
+ * stack([topic, f1.., r1..], -1).reshape(N, -1) at src/models/components/retriever.py:546-553):
+ * j = 0 the topic one-hot, j = 1..rounds mean propagation along edges (PyG MessagePassing
+ * aggr="mean", source_to_target), then rev_rounds rounds along reversed edges restarted from the
+ * one-hot.  A node without in-edges gets 0.  Sums are formed in f64 and rounded once.
+ * Replaces PEConv/DDE, src/models/components/graph.py:13-74. */
+int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics,
+                        const int64_t* node_ptr, int B, const int32_t* in_ptr, const int32_t* in_nbr,
+                        const int32_t* out_ptr, const int32_t* out_nbr, int rounds, int rev_rounds,
+                        float* node_struct, void* stream);
+
+/* ---- S1-S6: the edge scorer ------------------------------------------------------------------- */
+
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias), f32 in / f32 accumulate on MFMA (exact f32 FMA chains).
+ * act: 0 none, 1 tanh, 2 sigmoid.  K, lda, ldw multiples of 4.  The building block of every
+ * Linear in the reference Retriever (EmbeddingProjector, src/models/components/projections.py:9-40;
+ * q_gate/q_bias/state_net, src/models/components/retriever.py:157-182). */
+int evi_gemm_nt_f32(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                    const float* bias, int act, float* C, int64_t ldc, void* stream);
+
+/* Parameters of src.models.components.retriever.Retriever as device pointers, in state_dict
+ * order (every tensor f32, row-major, exactly the checkpoint's shapes). */
+typedef struct EviRetrieverWeights {
+    int emb_dim;             /* D */
+    int hidden_dim;          /* H */
+    int num_topics;          /* 2 */
+    int dde_rounds;          /* parity_meta[2] */
+    int dde_reverse_rounds;  /* parity_meta[3] */
+    const float* entity_w;       /* entity_proj.network.0.weight   [D, D] */
+    const float* entity_b;       /* entity_proj.network.0.bias     [D]    */
+    const float* relation_w;     /* relation_proj.network.0.weight [D, D] */
+    const float* relation_b;
+    const float* query_w;        /* query_proj.network.0.weight    [D, D] */
+    const float* query_b;
+    const float* non_text_emb;   /* non_text_entity_emb.weight     [1, D] */
+    const float* q_gate_w;       /* q_gate.0.weight [D, D] */
+    const float* q_gate_b;
+    const float* q_bias_w;       /* q_bias.0.weight [D, D] */
+    const float* q_bias_b;
+    const float* struct_w;       /* struct_proj.0.weight [D, 4*(1+rounds+rev)] */
+    const float* struct_b;
+    const float* struct_ln_w;    /* struct_proj.1.weight [D] */
+    const float* struct_ln_b;
+    const float* struct_gate_w;  /* struct_gate_net.0.weight [1, D] */
+    const float* struct_gate_b;  /* [1] */
+    const float* state0_w;       /* state_net.0.weight [H, 3D+1] */
+    const float* state0_b;
+    const float* state_ln_w;     /* state_net.1.weight [H] */
+    const float* state_ln_b;
+    const float* state4_w;       /* state_net.4.weight [H, H] */
+    const float* state4_b;
+    const float* score_w;        /* score_head.weight [1, H] */
+    const float* score_b;        /* [1] */
+} EviRetrieverWeights;
+
+/* The flat PyG batch the reference's loader produces (src/data/components/loader.py:43-99), as
+ * device pointers.  edge_batch / edge_ptr come from evi_edge_batch. */
+typedef struct EviRetrieverBatch {
+    int64_t num_nodes, num_edges;
+    int num_graphs;
+    const int64_t* edge_index;          /* [2, E], batch-global node ids */
+    const int64_t* node_ptr;            /* [B+1] */
+    const int64_t* edge_ptr;            /* [B+1] */
+    const int64_t* edge_batch;          /* [E] */
+    const float* question_emb;          /* [B, D] */
+    const float* node_embeddings;       /* [N, D] */
+    const int64_t* node_embedding_ids;  /* [N], 0 = non-text entity */
+    const float* edge_embeddings;       /* [E, D] (= relation_table[edge_attr]) */
+    const int64_t* edge_attr;           /* [E] relation ids */
+    int64_t num_relations;  /* if 0 < num_relations <= E: every edge_attr < num_relations and equal ids
+                               carry equal edge_embeddings rows, so each relation is projected once;
+                               0 = project per edge, as the reference does */
+    const float* topic_one_hot;         /* [N, topic_stride] */
+    int topic_stride;
+} EviRetrieverBatch;
+
+/* RetrieverOutput (src/models/components/retriever.py:80-99); any pointer but logits may be NULL. */
+typedef struct EviRetrieverOutput {
+    float* logits;         /* [E] */
+    float* logits_fwd;     /* [E] */
+    float* logits_bwd;     /* [E] */
+    float* edge_features;  /* [E, H]  (RetrieverOutput.edge_embeddings / extract_edge_tokens) */
+    float* node_struct;    /* [N, 2*(1+rounds+rev)] */
+} EviRetrieverOutput;
+
+/* Eval-mode Retriever._forward_impl (src/models/components/retriever.py:195-289): dropout is the
+ * identity, the hide-and-seek bias is off (apply_in_eval: false,
+ * configs/model/retriever_module.yaml:25).  direction_mode: 0 bidirectional, 1 forward, 2 backward. */
+size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
+                                             int dde_reverse_rounds, int64_t num_relations);
+int evi_retriever_forward(const EviRetrieverWeights* weights, const EviRetrieverBatch* batch,
+                          int direction_mode, const EviRetrieverOutput* out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,63 @@
+"""CPU-side checks of the host mirror of the reference interface (no compute calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_retriever_state_dict_matches_reference_checkpoint_layout():
+    """Keys, order and shapes of the reference Retriever's state_dict (fixture written by the
+    reference's own module) — eval loads checkpoints with strict=True (src/eval.py:111)."""
+    from evi_rag_amd.retriever import Retriever
+
+    z = np.load(os.path.join(GOLD, "retriever_mid.npz"), allow_pickle=False)
+    rounds = z["rounds"].tolist()
+    m = Retriever(emb_dim=int(z["D"]), hidden_dim=int(z["H"]),
+                  dde_cfg={"num_rounds": rounds[0], "num_reverse_rounds": rounds[1]},
+                  hide_seek_cfg={"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0, "bias_far": -0.5,
+                                 "apply_in_eval": False}, some_future_kwarg=1)
+    sd = m.state_dict()
+    assert list(sd.keys()) == z["state_dict_keys"].tolist()
+    for k, v in sd.items():
+        assert tuple(v.shape) == z["w_" + k].shape, k
+    assert sd["parity_meta"].tolist() == z["w_parity_meta"].tolist()
+    m.load_state_dict({k: torch.from_numpy(z["w_" + k]) for k in sd}, strict=True)
+
+
+def test_same_seed_gives_the_reference_initialisation():
+    """Construction order mirrors the reference, so torch.manual_seed reproduces its random init."""
+    from evi_rag_amd.retriever import Retriever
+
+    z = np.load(os.path.join(GOLD, "retriever_fwd.npz"), allow_pickle=False)
+    torch.manual_seed(2)  # tests/golden/make_golden.py: gen_retriever(..., seed=2)
+    m = Retriever(emb_dim=16, hidden_dim=16, dde_cfg={"num_rounds": 2, "num_reverse_rounds": 2})
+    # 2-D parameters were left at their seeded init by the generator (1-D ones were perturbed)
+    for k in ("entity_proj.network.0.weight", "state_net.0.weight", "score_head.weight", "non_text_entity_emb.weight"):
+        assert np.array_equal(m.state_dict()[k].numpy(), z["w_" + k]), k
+
+
+def test_cpu_module_refuses_to_run():
+    from evi_rag_amd import synthetic
+    from evi_rag_amd.retriever import Retriever
+
+    m = Retriever(emb_dim=16, hidden_dim=16).eval()
+    sb = synthetic.make_batch(2, nodes_per_graph=10, edges_per_graph=12, emb_dim=16, seed=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(synthetic.as_namespace(sb))
+
+
+def test_synthetic_batch_is_a_valid_pyg_style_batch():
+    from evi_rag_amd import synthetic
+    from oracle import graph as ograph
+
+    sb = synthetic.make_batch(8, nodes_per_graph=50, edges_per_graph=120, emb_dim=8, seed=4)
+    eb, eptr = ograph.compute_edge_batch(sb.edge_index, sb.ptr, sb.num_graphs)  # raises if malformed
+    assert np.array_equal(eptr, sb.edge_ptr)
+    assert sb.topic_one_hot.sum(axis=1).tolist() == [1.0] * sb.num_nodes
+    for g in range(sb.num_graphs):  # no duplicate (h, r, t) inside a graph
+        lo, hi = sb.edge_ptr[g], sb.edge_ptr[g + 1]
+        trip = np.stack([sb.edge_index[0, lo:hi], sb.edge_attr[lo:hi], sb.edge_index[1, lo:hi]], 1)
+        assert np.unique(trip, axis=0).shape[0] == hi - lo

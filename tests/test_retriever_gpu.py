@@ -1,0 +1,198 @@
+"""GPU parity of the scorer path (S1-S6, G1, G6, G7, G11) against the golden fixtures produced by
+the reference's own Retriever and against the numpy oracle on larger synthetic batches."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from evi_rag_amd import synthetic
+from oracle import graph as ograph
+from oracle import scorer as oscorer
+from oracle.ranking import stable_desc_order
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def _batch_from(z, dev, prefix="b_"):
+    b = types.SimpleNamespace()
+    for k in z.files:
+        if k.startswith(prefix):
+            setattr(b, k[len(prefix):], torch.from_numpy(z[k]).to(dev))
+    b.num_graphs = int(b.ptr.numel() - 1)
+    b.num_nodes = int(b.ptr[-1].item())
+    b._slice_dict = {"edge_index": b.edge_ptr}
+    return b
+
+
+def _model_from(z, dev, direction="bidirectional"):
+    from evi_rag_amd.retriever import Retriever
+
+    rounds = z["rounds"].tolist()
+    m = Retriever(emb_dim=int(z["D"]), hidden_dim=int(z["H"]),
+                  dde_cfg={"num_rounds": rounds[0], "num_reverse_rounds": rounds[1]}, direction_mode=direction)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")}
+    m.load_state_dict(sd, strict=True)  # the reference's eval loads strict=True (src/eval.py:111)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1, 32, 32, "tanh"), (37, 48, 20, None), (300, 768, 768, "sigmoid"),
+                                        (1000, 2308, 96, None), (129, 16, 130, "tanh"), (64, 30, 16, None)])
+def test_gemm_matches_torch_fp32(dev, M, K, N, act):
+    """fp32 reference of the same op: torch CPU float64 accumulate, compared at f32 rounding level."""
+    from evi_rag_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + K)
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((N, K), generator=g) / K ** 0.5
+    b = torch.randn((N,), generator=g)
+    got = ops.linear_act(x.to(dev), w.to(dev), b.to(dev), act).cpu()
+    ref = (x.double() @ w.double().T + b.double())
+    ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda v: v}[act](ref).float()
+    torch.testing.assert_close(got, ref, rtol=0, atol=3e-6)
+
+
+def test_gemm_rejects_unaligned(dev):
+    from evi_rag_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.evi_gemm_nt_f32(None, 4, 6, 6, None, 4, 6, None, 0, None, 4, None)
+    assert rc == _lib.EVI_ERR_INVALID and "multiples of 4" in _lib.last_error()
+
+
+def test_edge_batch_and_qa_mask_match_golden(dev):
+    from evi_rag_amd import retriever as R
+
+    z = _load("graph_utils_toy")
+    b = _batch_from(z, dev)
+    eb, eptr = R.compute_edge_batch(b.edge_index, node_ptr=b.ptr, num_graphs=b.num_graphs, device=dev)
+    assert np.array_equal(eb.cpu().numpy(), z["edge_batch"])
+    assert np.array_equal(eptr.cpu().numpy(), z["edge_ptr"])
+    near = R.compute_qa_edge_mask(b.edge_index, num_nodes=b.num_nodes, q_local_indices=b.q_local_indices,
+                                  a_local_indices=b.a_local_indices)
+    assert np.array_equal(near.cpu().numpy(), z["near_mask"])
+    bad = b.edge_index.clone()
+    bad[1, 0] = b.ptr[-1] - 1
+    with pytest.raises(ValueError, match="crosses graph boundaries"):
+        R.compute_edge_batch(bad, node_ptr=b.ptr, num_graphs=b.num_graphs)
+    with pytest.raises(ValueError, match="non-decreasing"):
+        R.compute_edge_batch(b.edge_index.flip(1).contiguous(), node_ptr=b.ptr, num_graphs=b.num_graphs)
+    with pytest.raises(ValueError, match="exceed num_nodes"):
+        R.compute_qa_edge_mask(b.edge_index, num_nodes=b.num_nodes, q_local_indices=torch.tensor([b.num_nodes]),
+                               a_local_indices=torch.tensor([], dtype=torch.long))
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 31), (4, 3000, 10000), (3, 50, 4000)])
+def test_csr_and_dde_match_oracle(dev, shape):
+    from evi_rag_amd import ops
+
+    B, n, e = shape
+    sb = synthetic.make_batch(B, nodes_per_graph=n, edges_per_graph=e, emb_dim=8, seed=B + n, attach_embeddings=False)
+    ei = torch.from_numpy(sb.edge_index).to(dev)
+    ptr = torch.from_numpy(sb.ptr).to(dev)
+    eptr = torch.from_numpy(sb.edge_ptr).to(dev)
+    csr = ops.graph_csr(ei, ptr, eptr)
+    # CSR content == adjacency lists of the oracle (rows are unordered: compare as sorted multisets)
+    in_ptr, in_nbr, in_eid = (t.cpu().numpy() for t in (csr.in_ptr, csr.in_nbr, csr.in_eid))
+    out_ptr, out_nbr, out_eid = (t.cpu().numpy() for t in (csr.out_ptr, csr.out_nbr, csr.out_eid))
+    N, E = sb.num_nodes, sb.num_edges
+    assert in_ptr[0] == 0 and in_ptr[N] == E and out_ptr[N] == E
+    assert np.array_equal(np.diff(in_ptr[: N + 1]), np.bincount(sb.edge_index[1], minlength=N))
+    assert np.array_equal(np.diff(out_ptr[: N + 1]), np.bincount(sb.edge_index[0], minlength=N))
+    assert np.array_equal(np.sort(in_eid[:E]), np.arange(E)) and np.array_equal(np.sort(out_eid[:E]), np.arange(E))
+    assert np.array_equal(sb.edge_index[0][in_eid[:E]], in_nbr[:E])
+    assert np.array_equal(sb.edge_index[1][out_eid[:E]], out_nbr[:E])
+    rows_in = np.repeat(np.arange(N), np.diff(in_ptr[: N + 1]))
+    assert np.array_equal(sb.edge_index[1][in_eid[:E]], rows_in)
+    for rounds in [(2, 2), (4, 0), (1, 3)]:
+        ns = ops.dde_node_struct(torch.from_numpy(sb.topic_one_hot).to(dev), ptr, csr, *rounds).cpu().numpy()
+        ref = ograph.node_structure_features(sb.topic_one_hot, sb.edge_index, *rounds)
+        np.testing.assert_allclose(ns, ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["retriever_toy", "retriever_mid", "retriever_fwd", "retriever_bwd"])
+def test_retriever_forward_matches_reference_golden(dev, name):
+    """Outputs of the reference Retriever (random-init, seeded) on the committed batches.
+    Tolerance 2e-4 absolute on logits/features (north_star: fp scores within 1e-3)."""
+    z = _load(name)
+    direction = str(z["direction"])
+    model = _model_from(z, dev, direction)
+    assert list(model.state_dict().keys()) == z["state_dict_keys"].tolist()
+    batch = _batch_from(z, dev)
+    with torch.no_grad():
+        out = model(batch)
+        tokens = model.extract_edge_tokens(batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.query_ids.cpu().numpy(), z["query_ids"])
+    assert np.array_equal(out.relation_ids.cpu().numpy(), z["relation_ids"])
+    np.testing.assert_allclose(out.logits.cpu().numpy(), z["logits"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), z["edge_embeddings"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(tokens.cpu().numpy(), z["edge_tokens"], rtol=0, atol=2e-4)
+    if direction == "bidirectional":
+        np.testing.assert_allclose(out.logits_fwd.cpu().numpy(), z["logits_fwd"], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(out.logits_bwd.cpu().numpy(), z["logits_bwd"], rtol=0, atol=2e-4)
+    # per-graph rankings agree with the reference's except across near-ties
+    got, ref = out.logits.cpu().numpy(), z["logits"]
+    eptr = z["b_edge_ptr"]
+    for g in range(len(eptr) - 1):
+        lo, hi = int(eptr[g]), int(eptr[g + 1])
+        og, orf = stable_desc_order(got[lo:hi]), stable_desc_order(ref[lo:hi])
+        diff = np.nonzero(og != orf)[0]
+        if diff.size:
+            assert np.max(np.abs(ref[lo:hi][og[diff]] - ref[lo:hi][orf[diff]])) < 4e-4
+
+
+@pytest.mark.parametrize("dedupe", [True, False])
+def test_retriever_forward_matches_oracle_webqsp_shape(dev, dedupe):
+    """A WebQSP-shaped batch slice at the bench dims (D = H = 768) against the numpy oracle."""
+    from evi_rag_amd.retriever import Retriever
+
+    D = H = 768
+    sb = synthetic.make_batch(3, nodes_per_graph=400, edges_per_graph=1200, emb_dim=D, num_relations=64, seed=9)
+    torch.manual_seed(3)
+    model = Retriever(emb_dim=D, hidden_dim=H, dedupe_relations=dedupe).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    w = {k: v.numpy() for k, v in model.state_dict().items()}
+    ref = oscorer.retriever_forward(w, sb, num_rounds=2, num_reverse_rounds=2)
+    model = model.to(dev)
+    out = model(synthetic.as_namespace(sb, device=dev))
+    np.testing.assert_allclose(out.logits.cpu().numpy(), ref["logits"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.logits_fwd.cpu().numpy(), ref["logits_fwd"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=3e-4)
+    assert np.array_equal(out.query_ids.cpu().numpy(), ref["query_ids"])
+
+
+def test_retriever_error_contract(dev):
+    from evi_rag_amd.retriever import Retriever
+
+    with pytest.raises(ValueError, match="num_topics must be 2"):
+        Retriever(emb_dim=16, hidden_dim=16, num_topics=3)
+    with pytest.raises(ValueError, match="topic_pe must be enabled"):
+        Retriever(emb_dim=16, hidden_dim=16, topic_pe=False)
+    with pytest.raises(ValueError, match="direction_mode must be one of"):
+        Retriever(emb_dim=16, hidden_dim=16, direction_mode="sideways")
+    with pytest.raises(ValueError, match="at most 4 rounds"):
+        Retriever(emb_dim=16, hidden_dim=16, dde_cfg={"num_rounds": 5})
+    m = Retriever(emb_dim=16, hidden_dim=16).to(dev).eval()
+    with pytest.raises(ValueError, match="Batch missing edge_index"):
+        m(types.SimpleNamespace())
+    sb = synthetic.make_batch(2, nodes_per_graph=10, edges_per_graph=12, emb_dim=16, seed=1)
+    ns = synthetic.as_namespace(sb, device=dev)
+    del ns.topic_one_hot
+    with pytest.raises(ValueError, match="topic_one_hot is required"):
+        m(ns)
+    ns = synthetic.as_namespace(sb, device=dev)
+    ns.edge_index = ns.edge_index[:, :0]
+    out = m(ns)  # empty edge list -> empty outputs (reference :206-207)
+    assert out.logits.numel() == 0 and out.edge_embeddings.shape == (0, 16)
+    with pytest.raises(NotImplementedError):
+        m.train()(synthetic.as_namespace(sb, device=dev))
