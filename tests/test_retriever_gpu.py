@@ -55,7 +55,8 @@ def test_gemm_matches_torch_fp32(dev, M, K, N, act):
     got = ops.linear_act(x.to(dev), w.to(dev), b.to(dev), act).cpu()
     ref = (x.double() @ w.double().T + b.double())
     ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda v: v}[act](ref).float()
-    torch.testing.assert_close(got, ref, rtol=0, atol=3e-6)
+    # one f32 FMA chain of length K per output: error grows ~ K * 2^-24 * |terms|
+    torch.testing.assert_close(got, ref, rtol=0, atol=3e-6 * max(1.0, K / 256))
 
 
 def test_gemm_rejects_unaligned(dev):
