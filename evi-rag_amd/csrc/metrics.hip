@@ -1,0 +1,289 @@
+// Per-graph ranking metrics of the retriever evaluation, fused: one workgroup per question graph
+// takes the graph's edge scores once, selects the exact top-k_max (score desc, position asc) in
+// LDS and derives every metric of the k window from that one ranked list.
+//
+//   edge/recall@k          EdgeRecallAtK._update_graph_recall, src/metrics/retriever_metrics.py:132-157
+//   answer/reachability@k  AnswerReachability._compute_reachability_at_k (undirected union-find with
+//                          checkpoints), src/metrics/reachability.py:330-381; validity rules :129-179
+//   answer_hit@k, answer_recall@k   _oracle_metrics_for_sample, src/models/reasoner_module.py:17-68;
+//                          compute_answer_hit / compute_answer_recall, src/utils/metrics.py:167-238
+//   edge/score_margin      ScoreMargin._update_graph_margin, src/metrics/retriever_metrics.py:376-391
+//   top-k lists            RetrieverTopKEdgeWriter._select_topk_edges,
+//                          src/callbacks/retriever_topk_edge_writer.py:294-320
+//
+// Per-graph values are written to [B, nk] arrays; the host mirror adds them up in graph order (the
+// reference's own accumulation order), so nothing here uses float atomics.  HBM-bound: the scores,
+// labels and endpoints of each graph are read once (E * (4 + 1) bytes + 16 B per ranked edge).
+#include "common.hpp"
+
+namespace evi {
+
+constexpr int kMaxKValues = 16;
+constexpr int kUfLdsNodes = 12288;  // union-find parents kept in LDS up to this many nodes (48 KiB)
+constexpr int kMaxAnswers = 2048;
+
+struct KWindow {
+    int nk;
+    int k[kMaxKValues];  // ascending, positive
+};
+
+struct MetricsArgs {
+    const float* scores;          // [E]
+    const uint8_t* target;        // [E] 0/1 (labels > 0.5), may be NULL
+    const int64_t* edge_index;    // [2, E] batch-global node ids
+    int64_t E;
+    const int64_t* edge_ptr;      // [B+1]
+    const int64_t* node_ptr;      // [B+1]
+    const int64_t* q_idx;         // seeds, batch-global (q_local_indices after PyG collate)
+    const int64_t* q_ptr;         // [B+1]
+    const int64_t* a_idx;         // answers, batch-global
+    const int64_t* a_ptr;         // [B+1]
+    const int64_t* node_global_ids;  // [N] entity ids, may be NULL
+    const int64_t* answer_ids;       // entity ids of the answers, may be NULL
+    const int64_t* answer_ptr;       // [B+1]
+    KWindow kw;
+    int k_max;
+    float* edge_recall;      // [B, nk]
+    uint8_t* recall_valid;   // [B]  graph has >= 1 edge
+    uint8_t* reach;          // [B, nk]
+    uint8_t* reach_valid;    // [B]
+    uint8_t* answer_hit;     // [B, nk]
+    float* answer_recall;    // [B, nk]
+    uint8_t* answer_valid;   // [B]
+    float* score_margin;     // [B]
+    uint8_t* margin_valid;   // [B]
+    int32_t* topk_index;     // [B, k_max] local edge position, -1 padding (may be NULL)
+    float* topk_score;       // [B, k_max] (may be NULL)
+    int32_t* topk_count;     // [B] (may be NULL)
+    int32_t* uf_ws;          // [N] union-find parents for graphs too large for LDS
+};
+
+struct MetricsShared {
+    SelectShared sel;
+    int parent[kUfLdsNodes];
+    int first_rank[kMaxAnswers];
+    int misc[8];  // 0: positives, 1: reach rank
+    unsigned int s_min_pos, s_max_neg;
+};
+
+__device__ inline int uf_find(int* parent, int x) {
+    while (parent[x] != x) {
+        parent[x] = parent[parent[x]];
+        x = parent[x];
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(kSelectThreads) void k_retriever_metrics(MetricsArgs a) {
+    extern __shared__ char smem_raw[];
+    MetricsShared& sh = *reinterpret_cast<MetricsShared*>(smem_raw);
+    const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int nk = a.kw.nk;
+    const int64_t e0 = a.edge_ptr[g], e1 = a.edge_ptr[g + 1];
+    const int64_t cnt = e1 > e0 ? e1 - e0 : 0;
+    const int64_t n0 = a.node_ptr[g], n1 = a.node_ptr[g + 1];
+    const int num_nodes = (int)(n1 > n0 ? n1 - n0 : 0);
+    const float* s = a.scores + e0;
+
+    if (tid < 8) sh.misc[tid] = 0;
+    if (tid == 1) sh.misc[1] = 0x7FFFFFFF;
+    __syncthreads();
+
+    // ---- ranked list ---------------------------------------------------------------------------
+    auto load = [&](int64_t i) -> uint64_t { return make_key(s[i], (uint32_t)i); };
+    const int m = block_topk(sh.sel, load, cnt, a.k_max);  // sh.sel.keys[0..m) sorted, barrier done
+    for (int i = tid; i < a.k_max; i += nt) {
+        const bool ok = i < m;
+        const uint32_t pos = ok ? key_index(sh.sel.keys[i]) : 0u;
+        if (a.topk_index) a.topk_index[(int64_t)g * a.k_max + i] = ok ? (int32_t)pos : -1;
+        if (a.topk_score) a.topk_score[(int64_t)g * a.k_max + i] = ok ? s[pos] : -INFINITY;
+    }
+    if (a.topk_count && tid == 0) a.topk_count[g] = m;
+
+    // ---- edge recall@k + score margin -----------------------------------------------------------
+    if (a.target) {
+        int local_pos = 0;
+        float min_pos = INFINITY, max_neg = -INFINITY;
+        for (int64_t i = tid; i < cnt; i += nt) {
+            const bool p = a.target[e0 + i] != 0;
+            local_pos += p ? 1 : 0;
+            const float v = s[i];
+            if (p) min_pos = fminf(min_pos, v); else max_neg = fmaxf(max_neg, v);
+        }
+        // block reductions through LDS atomics (ints) and ordered-uint atomics (floats)
+        if (local_pos) atomicAdd(&sh.misc[0], local_pos);
+        if (tid == 0) {
+            sh.s_min_pos = float_to_ordered(INFINITY);
+            sh.s_max_neg = float_to_ordered(-INFINITY);
+        }
+        __syncthreads();
+        atomicMin(&sh.s_min_pos, float_to_ordered(min_pos));
+        atomicMax(&sh.s_max_neg, float_to_ordered(max_neg));
+        __syncthreads();
+        const int positives = sh.misc[0];
+        if (tid == 0) {
+            const bool has_pos = positives > 0, has_neg = positives < cnt;
+            a.margin_valid[g] = (has_pos && has_neg) ? 1 : 0;
+            a.score_margin[g] = (has_pos && has_neg) ? ordered_to_float(sh.s_min_pos) - ordered_to_float(sh.s_max_neg) : 0.f;
+            a.recall_valid[g] = cnt > 0 ? 1 : 0;
+        }
+        // hits among the first min(k, m) ranked edges: one wave per k value
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int ki = wave; ki < nk; ki += nt / 64) {
+            const int k_eff = a.kw.k[ki] < m ? a.kw.k[ki] : m;
+            int hits = 0;
+            for (int i = lane; i < k_eff; i += 64) hits += a.target[e0 + key_index(sh.sel.keys[i])] ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off, 64);
+            if (lane == 0) {
+                const float denom = positives > 0 ? (float)positives : 1.0f;
+                a.edge_recall[(int64_t)g * nk + ki] = cnt > 0 ? (float)hits / denom : 0.f;
+            }
+        }
+    }
+
+    else if (tid == 0) {
+        a.recall_valid[g] = 0;
+        a.margin_valid[g] = 0;
+    }
+
+    // ---- answer reachability@k --------------------------------------------------------------------
+    {
+        const int64_t q0 = a.q_ptr[g], q1 = a.q_ptr[g + 1], a0 = a.a_ptr[g], a1 = a.a_ptr[g + 1];
+        int* parent = num_nodes <= kUfLdsNodes ? sh.parent : (a.uf_ws + n0);
+        for (int v = tid; v < num_nodes; v += nt) parent[v] = v;
+        __syncthreads();
+        if (tid == 0) {
+            // valid iff edges, nodes, and at least one in-range seed and answer (reachability.py:129-179)
+            int nq = 0, na = 0;
+            for (int64_t i = q0; i < q1; ++i) nq += (a.q_idx[i] >= n0 && a.q_idx[i] < n1) ? 1 : 0;
+            for (int64_t i = a0; i < a1; ++i) na += (a.a_idx[i] >= n0 && a.a_idx[i] < n1) ? 1 : 0;
+            const bool valid = cnt > 0 && num_nodes > 0 && nq > 0 && na > 0 && (q1 > q0) && (a1 > a0);
+            a.reach_valid[g] = valid ? 1 : 0;
+            int reach_rank = 0x7FFFFFFF;  // smallest number of ranked edges after which seeds meet answers
+            if (valid) {
+                auto connected = [&]() -> bool {
+                    for (int64_t i = a0; i < a1; ++i) {
+                        const int64_t av = a.a_idx[i];
+                        if (av < n0 || av >= n1) continue;
+                        const int ra = uf_find(parent, (int)(av - n0));
+                        for (int64_t j = q0; j < q1; ++j) {
+                            const int64_t qv = a.q_idx[j];
+                            if (qv < n0 || qv >= n1) continue;
+                            if (uf_find(parent, (int)(qv - n0)) == ra) return true;
+                        }
+                    }
+                    return false;
+                };
+                if (connected()) {
+                    reach_rank = 0;  // a seed is itself an answer
+                } else {
+                    for (int i = 0; i < m; ++i) {
+                        const int64_t e = e0 + key_index(sh.sel.keys[i]);
+                        const int64_t u = a.edge_index[e] - n0, v = a.edge_index[a.E + e] - n0;
+                        if (u < 0 || v < 0 || u >= num_nodes || v >= num_nodes) continue;
+                        const int ru = uf_find(parent, (int)u), rv = uf_find(parent, (int)v);
+                        if (ru == rv) continue;
+                        parent[rv] = ru;  // connectivity only: union order / rank do not change the answer
+                        if (connected()) {
+                            reach_rank = i + 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            sh.misc[1] = reach_rank;
+        }
+        __syncthreads();
+        if (tid < nk) {
+            const int k_eff = a.kw.k[tid] < m ? a.kw.k[tid] : m;
+            a.reach[(int64_t)g * nk + tid] = (a.reach_valid[g] && sh.misc[1] <= k_eff && k_eff > 0) ? 1 : 0;
+        }
+    }
+
+    // ---- answer hit@k / answer recall@k over entity ids ---------------------------------------------
+    if (a.node_global_ids && a.answer_ids) {
+        const int64_t b0 = a.answer_ptr[g], b1 = a.answer_ptr[g + 1];
+        const bool too_many = (b1 - b0) > kMaxAnswers;  // reported as answer_valid = 2; the host raises
+        const int na = (int)(too_many ? kMaxAnswers : (b1 - b0));
+        for (int j = tid; j < na; j += nt) {
+            // duplicates of an earlier answer id never count (the reference works on the id set)
+            bool dup = false;
+            for (int j2 = 0; j2 < j; ++j2) dup |= a.answer_ids[b0 + j2] == a.answer_ids[b0 + j];
+            sh.first_rank[j] = dup ? -1 : 0x7FFFFFFF;
+        }
+        __syncthreads();
+        for (int i = tid; i < m; i += nt) {
+            const int64_t e = e0 + key_index(sh.sel.keys[i]);
+            const int64_t hg = a.node_global_ids[a.edge_index[e]], tg = a.node_global_ids[a.edge_index[a.E + e]];
+            for (int j = 0; j < na; ++j) {
+                if (sh.first_rank[j] < 0) continue;
+                const int64_t aid = a.answer_ids[b0 + j];
+                if (hg == aid || tg == aid) atomicMin(&sh.first_rank[j], i + 1);
+            }
+        }
+        __syncthreads();
+        if (tid < nk) {
+            int uniq = 0, found = 0;
+            for (int j = 0; j < na; ++j) {
+                if (sh.first_rank[j] < 0) continue;
+                ++uniq;
+                found += sh.first_rank[j] <= a.kw.k[tid] ? 1 : 0;
+            }
+            a.answer_hit[(int64_t)g * nk + tid] = found > 0 ? 1 : 0;
+            a.answer_recall[(int64_t)g * nk + tid] = uniq > 0 ? (float)((double)found / (double)uniq) : 0.f;
+            if (tid == 0) a.answer_valid[g] = too_many ? 2 : (uniq > 0 ? 1 : 0);
+        }
+    }
+}
+
+}  // namespace evi
+
+using namespace evi;
+
+extern "C" int evi_retriever_metrics(
+    const float* scores, const uint8_t* target, const int64_t* edge_index, int64_t E, const int64_t* edge_ptr,
+    const int64_t* node_ptr, int B, const int64_t* q_idx, const int64_t* q_ptr, const int64_t* a_idx,
+    const int64_t* a_ptr, const int64_t* node_global_ids, const int64_t* answer_ids, const int64_t* answer_ptr,
+    const int32_t* k_values_host, int num_k, float* edge_recall, uint8_t* recall_valid, uint8_t* reach,
+    uint8_t* reach_valid, uint8_t* answer_hit, float* answer_recall, uint8_t* answer_valid, float* score_margin,
+    uint8_t* margin_valid, int32_t* topk_index, float* topk_score, int32_t* topk_count, int32_t* uf_workspace,
+    void* stream) {
+    EVI_REQUIRE(B >= 0 && E >= 0, "evi_retriever_metrics: bad sizes B=%d E=%lld", B, (long long)E);
+    EVI_REQUIRE(num_k >= 1 && num_k <= kMaxKValues, "evi_retriever_metrics: need 1..%d k values, got %d", kMaxKValues,
+                num_k);
+    EVI_REQUIRE(k_values_host, "evi_retriever_metrics: null k_values");
+    if (B == 0) return EVI_OK;
+    MetricsArgs a;
+    a.kw.nk = num_k;
+    for (int i = 0; i < num_k; ++i) {
+        a.kw.k[i] = k_values_host[i];
+        EVI_REQUIRE(a.kw.k[i] >= 1 && (i == 0 || a.kw.k[i] > a.kw.k[i - 1]),
+                    "evi_retriever_metrics: k values must be positive and strictly ascending");
+    }
+    a.k_max = a.kw.k[num_k - 1];
+    EVI_REQUIRE(a.k_max <= EVI_TOPK_MAX_K, "evi_retriever_metrics: max k %d exceeds %d", a.k_max, EVI_TOPK_MAX_K);
+    EVI_REQUIRE(edge_ptr && node_ptr && q_ptr && a_ptr && edge_recall && recall_valid && reach && reach_valid &&
+                    score_margin && margin_valid && uf_workspace,
+                "evi_retriever_metrics: null pointer");
+    EVI_REQUIRE(E == 0 || (scores && edge_index), "evi_retriever_metrics: null scores/edge_index");
+    EVI_REQUIRE(!(node_global_ids && answer_ids) || (answer_ptr && answer_hit && answer_recall && answer_valid),
+                "evi_retriever_metrics: answer-hit outputs missing");
+    a.scores = scores; a.target = target; a.edge_index = edge_index; a.E = E; a.edge_ptr = edge_ptr;
+    a.node_ptr = node_ptr; a.q_idx = q_idx; a.q_ptr = q_ptr; a.a_idx = a_idx; a.a_ptr = a_ptr;
+    a.node_global_ids = node_global_ids; a.answer_ids = answer_ids; a.answer_ptr = answer_ptr;
+    a.edge_recall = edge_recall; a.recall_valid = recall_valid; a.reach = reach; a.reach_valid = reach_valid;
+    a.answer_hit = answer_hit; a.answer_recall = answer_recall; a.answer_valid = answer_valid;
+    a.score_margin = score_margin; a.margin_valid = margin_valid; a.topk_index = topk_index;
+    a.topk_score = topk_score; a.topk_count = topk_count; a.uf_ws = uf_workspace;
+    static thread_local bool attr = false;
+    if (!attr) {
+        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_retriever_metrics),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MetricsShared)));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_retriever_metrics, dim3(B), dim3(kSelectThreads), sizeof(MetricsShared),
+                       reinterpret_cast<hipStream_t>(stream), a);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}

@@ -1,0 +1,352 @@
+"""Host-side mirrors of the reference's retriever metrics, backed by `evi_retriever_metrics`.
+
+Same class names, constructor kwargs, `update(...)` keyword contract, `compute()` keys and
+`reset()` as src/metrics/reachability.py and src/metrics/retriever_metrics.py (torchmetrics-style;
+`RetrieverModule._update_metrics` calls `update(preds=, target=, indexes=, batch=, query_ids=,
+num_graphs=, features=)`, src/models/retriever_module.py:146-176).  States are f64 scalars summed
+in graph order; `sync()` all-reduces them (the reference's `dist_reduce_fx="sum"`).
+
+One fused kernel pass per batch ranks every graph once; the metric objects of one
+`RetrieverMetricCollection` share that pass.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+
+
+def normalize_k_values(raw_values: Any, default: Optional[Sequence[int]] = None) -> List[int]:
+    """reference: normalize_k_values, src/utils/metrics.py:25-40."""
+    if raw_values is None:
+        items: list = []
+    elif isinstance(raw_values, (list, tuple, set, range)):
+        items = list(raw_values)
+    elif isinstance(raw_values, str):
+        items = [raw_values]
+    else:
+        try:
+            items = list(raw_values)
+        except TypeError:
+            items = [raw_values]
+    out, seen = [], set()
+    for item in items:
+        try:
+            k = int(item)
+        except (TypeError, ValueError):
+            continue
+        if k <= 0 or k in seen:
+            continue
+        out.append(k)
+        seen.add(k)
+    if not out and default is not None:
+        return normalize_k_values(default)
+    return sorted(out)
+
+
+def _attr(obj: Any, name: str) -> Any:
+    return obj.get(name) if isinstance(obj, dict) else getattr(obj, name, None)
+
+
+class RankedBatch:
+    """Per-graph results of one `evi_retriever_metrics` pass (device tensors)."""
+
+    def __init__(self, k_values, **tensors):
+        self.k_values = list(k_values)
+        self.__dict__.update(tensors)
+
+
+def rank_batch(preds: torch.Tensor, target: Optional[torch.Tensor], batch: Any, k_values: Sequence[int], *,
+               num_graphs: Optional[int] = None, indexes: Optional[torch.Tensor] = None,
+               want_topk: bool = False) -> RankedBatch:
+    """Run the fused ranking-metrics kernel on one batch."""
+    ks = normalize_k_values(k_values)
+    if not ks:
+        raise ValueError("k_values must contain at least one positive integer")
+    scores = preds.detach().reshape(-1)
+    dev = ops._require_gpu(scores)
+    scores = ops._f32c(scores, "preds")
+    edge_index = _attr(batch, "edge_index")
+    node_ptr = _attr(batch, "ptr")
+    if edge_index is None:
+        raise ValueError("Batch missing edge_index required for reachability metrics.")
+    if node_ptr is None:
+        raise ValueError("Batch missing ptr required for reachability metrics.")
+    i64 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.long).contiguous().view(-1)  # noqa: E731
+    edge_index = torch.as_tensor(edge_index).to(device=dev, dtype=torch.long).contiguous()
+    node_ptr = i64(node_ptr)
+    B = int(num_graphs) if num_graphs is not None else int(node_ptr.numel() - 1)
+    E = int(scores.numel())
+    if edge_index.size(1) != E:
+        raise ValueError(f"preds/edge_index mismatch: {E} scores vs {edge_index.size(1)} edges")
+    slice_dict = _attr(batch, "_slice_dict")
+    slice_dict = slice_dict if isinstance(slice_dict, dict) else {}
+    edge_ptr = _attr(batch, "edge_ptr")
+    if edge_ptr is None:
+        edge_ptr = slice_dict.get("edge_index")
+    if edge_ptr is None:
+        ids = indexes if indexes is not None else _attr(batch, "edge_batch")
+        if ids is None:
+            raise ValueError("query_ids required for reachability metrics when edge ptr is unavailable.")
+        ids = i64(ids)
+        if ids.numel() != E:
+            raise ValueError(f"query_ids/scores mismatch: {tuple(ids.shape)} vs {tuple(scores.shape)}")
+        counts = torch.bincount(ids, minlength=B)
+        edge_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+    edge_ptr = i64(edge_ptr)
+    if edge_ptr.numel() != B + 1:
+        raise ValueError(f"edge ptr length mismatch: {edge_ptr.numel()} vs expected {B + 1}")
+
+    def ptr_of(name):
+        p = _attr(batch, name + "_ptr")
+        if p is None:
+            p = slice_dict.get(name)
+        return p
+
+    q_idx, a_idx = _attr(batch, "q_local_indices"), _attr(batch, "a_local_indices")
+    q_ptr, a_ptr = ptr_of("q_local_indices"), ptr_of("a_local_indices")
+    if q_idx is None or a_idx is None or q_ptr is None or a_ptr is None:
+        raise ValueError("Batch missing q_local_indices/a_local_indices required for reachability metrics.")
+    q_idx, a_idx, q_ptr, a_ptr = i64(q_idx), i64(a_idx), i64(q_ptr), i64(a_ptr)
+    if q_ptr.numel() != B + 1:
+        raise ValueError(f"q_local_indices_ptr length mismatch: {q_ptr.numel()} vs expected {B + 1}")
+    if a_ptr.numel() != B + 1:
+        raise ValueError(f"a_local_indices_ptr length mismatch: {a_ptr.numel()} vs expected {B + 1}")
+    gids, ans, ans_ptr = _attr(batch, "node_global_ids"), _attr(batch, "answer_entity_ids"), ptr_of("answer_entity_ids")
+    have_answers = gids is not None and ans is not None and ans_ptr is not None
+    if have_answers:
+        gids, ans, ans_ptr = i64(gids), i64(ans), i64(ans_ptr)
+    tgt = None
+    if target is not None:
+        tgt = target.detach().reshape(-1).to(device=dev)
+        tgt = (tgt > 0.5) if tgt.dtype != torch.bool else tgt
+        tgt = tgt.to(torch.uint8).contiguous()
+        if tgt.numel() != E:
+            raise ValueError(f"preds/target/indexes mismatch: {tuple(scores.shape)} vs {tuple(tgt.shape)}")
+
+    nk, k_max = len(ks), ks[-1]
+    N = int(node_ptr[-1].item()) if node_ptr.numel() else 0
+    f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+    u8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)  # noqa: E731
+    res = dict(edge_recall=f32(B, nk), recall_valid=u8(B), reach=u8(B, nk), reach_valid=u8(B), answer_hit=u8(B, nk),
+               answer_recall=f32(B, nk), answer_valid=u8(B), score_margin=f32(B), margin_valid=u8(B))
+    if want_topk:
+        res.update(topk_index=torch.empty((B, k_max), dtype=torch.int32, device=dev),
+                   topk_score=torch.empty((B, k_max), dtype=torch.float32, device=dev),
+                   topk_count=torch.empty((B,), dtype=torch.int32, device=dev))
+    uf_ws = ops._workspace(dev, "metrics_uf", 4 * max(N, 1))
+    karr = (ctypes.c_int32 * nk)(*ks)
+    p = ops._ptr
+    lib = _lib.load()
+    _lib.check(lib.evi_retriever_metrics(
+        p(scores), p(tgt), p(edge_index), E, p(edge_ptr), p(node_ptr), B, p(q_idx), p(q_ptr), p(a_idx), p(a_ptr),
+        p(gids) if have_answers else None, p(ans) if have_answers else None, p(ans_ptr) if have_answers else None,
+        karr, nk, p(res["edge_recall"]), p(res["recall_valid"]), p(res["reach"]), p(res["reach_valid"]),
+        p(res["answer_hit"]), p(res["answer_recall"]), p(res["answer_valid"]), p(res["score_margin"]),
+        p(res["margin_valid"]), p(res.get("topk_index")), p(res.get("topk_score")), p(res.get("topk_count")),
+        uf_ws.data_ptr(), ops._stream(dev)))
+    if have_answers and bool((res["answer_valid"] == 2).any().item()):
+        raise NotImplementedError("a graph has more than 2048 answer entities")
+    return RankedBatch(ks, edge_ptr=edge_ptr, have_answers=have_answers, **res)
+
+
+class _SumMetric:
+    """Minimal torchmetrics-style base: named f64 sum states, reset(), sync()."""
+
+    def __init__(self, **_: Any) -> None:
+        self._states: Dict[str, float] = {}
+        self._shared: Optional[RankedBatch] = None  # set by RetrieverMetricCollection for the current batch
+
+    def _add_state(self, name: str) -> None:
+        self._states[name] = 0.0
+
+    def reset(self) -> None:
+        for k in self._states:
+            self._states[k] = 0.0
+
+    def sync(self, group=None) -> None:
+        """All-reduce (SUM) the states across ranks — the reference's dist_reduce_fx="sum"."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        names = sorted(self._states)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([self._states[n] for n in names], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        for n, v in zip(names, t.tolist()):
+            self._states[n] = v
+
+    def _ranked(self, preds, target, batch, k_values, num_graphs, indexes) -> RankedBatch:
+        sh = self._shared
+        if sh is not None and all(k in sh.k_values for k in k_values):
+            return sh
+        return rank_batch(preds, target, batch, k_values, num_graphs=num_graphs, indexes=indexes)
+
+    @staticmethod
+    def _col(rb: RankedBatch, k: int) -> int:
+        return rb.k_values.index(k)
+
+
+class EdgeRecallAtK(_SumMetric):
+    """reference: EdgeRecallAtK, src/metrics/retriever_metrics.py:83-166."""
+
+    def __init__(self, k_values: Optional[Sequence[int]] = None, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.k_values = normalize_k_values(k_values)
+        for k in self.k_values:
+            self._add_state(f"recall_sum_at_{k}")
+        self._add_state("graph_count")
+
+    def update(self, preds, target, indexes, batch, num_graphs: Optional[int] = None, **_: Any) -> None:
+        if not self.k_values or preds.numel() == 0:
+            return
+        rb = self._ranked(preds, target, batch, self.k_values, num_graphs, indexes)
+        valid = rb.recall_valid.bool()
+        self._states["graph_count"] += float(valid.sum().item())
+        sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0).tolist()
+        for k in self.k_values:
+            self._states[f"recall_sum_at_{k}"] += sums[self._col(rb, k)]
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        denom = max(self._states["graph_count"], 1.0)
+        return {f"edge/recall@{k}": torch.tensor(self._states[f"recall_sum_at_{k}"] / denom, dtype=torch.float32)
+                for k in self.k_values}
+
+
+class AnswerReachability(_SumMetric):
+    """reference: AnswerReachability, src/metrics/reachability.py:9-381."""
+
+    def __init__(self, k_values: Optional[Sequence[int]] = None, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.k_values = normalize_k_values(k_values)
+        for k in self.k_values:
+            self._add_state(f"hits_at_{k}")
+        self._add_state("total")
+
+    def update(self, preds, batch, query_ids=None, num_graphs: Optional[int] = None, target=None, **_: Any) -> None:
+        if not self.k_values or preds.numel() == 0:
+            return
+        rb = self._ranked(preds, target, batch, self.k_values, num_graphs, query_ids)
+        valid = rb.reach_valid.bool()
+        n_valid = float(valid.sum().item())
+        if n_valid <= 0:
+            return
+        self._states["total"] += n_valid
+        hits = (rb.reach.double() * valid.unsqueeze(1)).sum(0).tolist()
+        for k in self.k_values:
+            self._states[f"hits_at_{k}"] += hits[self._col(rb, k)]
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        denom = max(self._states["total"], 1.0)
+        return {f"answer/reachability@{k}": torch.tensor(self._states[f"hits_at_{k}"] / denom, dtype=torch.float32)
+                for k in self.k_values}
+
+
+class AnswerHitAtK(_SumMetric):
+    """Hits@k / answer-recall@k over entity ids, averaged over graphs that have answers.
+    reference: compute_answer_hit / compute_answer_recall, src/utils/metrics.py:167-238;
+    _oracle_metrics_for_sample, src/models/reasoner_module.py:17-68, averaged at :190-214."""
+
+    def __init__(self, k_values: Optional[Sequence[int]] = None, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.k_values = normalize_k_values(k_values)
+        for k in self.k_values:
+            self._add_state(f"hit_sum_at_{k}")
+            self._add_state(f"recall_sum_at_{k}")
+        self._add_state("sample_count")
+
+    def update(self, preds, batch, target=None, indexes=None, num_graphs: Optional[int] = None, **_: Any) -> None:
+        if not self.k_values or preds.numel() == 0:
+            return
+        rb = self._ranked(preds, target, batch, self.k_values, num_graphs, indexes)
+        if not rb.have_answers:
+            raise ValueError("Batch missing node_global_ids/answer_entity_ids required for answer hit metrics.")
+        valid = rb.answer_valid.bool()
+        self._states["sample_count"] += float(valid.sum().item())
+        hit = (rb.answer_hit.double() * valid.unsqueeze(1)).sum(0).tolist()
+        rec = (rb.answer_recall.double() * valid.unsqueeze(1)).sum(0).tolist()
+        for k in self.k_values:
+            self._states[f"hit_sum_at_{k}"] += hit[self._col(rb, k)]
+            self._states[f"recall_sum_at_{k}"] += rec[self._col(rb, k)]
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        n = self._states["sample_count"]
+        out = {}
+        for k in self.k_values:
+            out[f"answer_hit@{k}"] = torch.tensor(self._states[f"hit_sum_at_{k}"] / n if n else 0.0, dtype=torch.float32)
+            out[f"answer_recall@{k}"] = torch.tensor(self._states[f"recall_sum_at_{k}"] / n if n else 0.0,
+                                                     dtype=torch.float32)
+        return out
+
+
+class ScoreMargin(_SumMetric):
+    """reference: ScoreMargin, src/metrics/retriever_metrics.py:330-397."""
+
+    def __init__(self, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self._add_state("margin_sum")
+        self._add_state("graph_count")
+
+    def update(self, preds, target, indexes, batch, num_graphs: Optional[int] = None, **_: Any) -> None:
+        if preds.numel() == 0:
+            return
+        rb = self._ranked(preds, target, batch, [1], num_graphs, indexes)
+        valid = rb.margin_valid.bool()
+        self._states["graph_count"] += float(valid.sum().item())
+        self._states["margin_sum"] += float((rb.score_margin.double() * valid).sum().item())
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        denom = max(self._states["graph_count"], 1.0)
+        return {"edge/score_margin": torch.tensor(self._states["margin_sum"] / denom, dtype=torch.float32)}
+
+
+class RetrieverMetricCollection:
+    """The metric set RetrieverModule builds (src/models/retriever_module.py:100-131), sharing one
+    ranking pass per batch.  `update` takes the module's keyword set; `compute` merges the dicts."""
+
+    def __init__(self, k_values: Sequence[int], *, answer_hit: bool = True, prefix: str = "") -> None:
+        self.k_values = normalize_k_values(k_values)
+        self.prefix = prefix
+        self.metrics: Dict[str, _SumMetric] = {
+            "edge_recall": EdgeRecallAtK(self.k_values),
+            "reachability": AnswerReachability(self.k_values),
+            "score_margin": ScoreMargin(),
+        }
+        if answer_hit:
+            self.metrics["answer_hit"] = AnswerHitAtK(self.k_values)
+
+    def update(self, *, preds, target, indexes, batch, query_ids=None, num_graphs=None, features=None, **_: Any) -> None:
+        if preds.numel() == 0:
+            return
+        shared = rank_batch(preds, target, batch, self.k_values, num_graphs=num_graphs, indexes=indexes)
+        for name, m in self.metrics.items():
+            if name == "answer_hit" and not shared.have_answers:
+                continue
+            m._shared = shared
+            try:
+                m.update(preds=preds, target=target, indexes=indexes, batch=batch, query_ids=query_ids,
+                         num_graphs=num_graphs)
+            finally:
+                m._shared = None
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        out: Dict[str, torch.Tensor] = {}
+        for m in self.metrics.values():
+            out.update({self.prefix + k: v for k, v in m.compute().items()})
+        return out
+
+    def reset(self) -> None:
+        for m in self.metrics.values():
+            m.reset()
+
+    def sync(self, group=None) -> None:
+        for m in self.metrics.values():
+            m.sync(group)
+
+
+__all__ = ["normalize_k_values", "rank_batch", "RankedBatch", "EdgeRecallAtK", "AnswerReachability", "AnswerHitAtK",
+           "ScoreMargin", "RetrieverMetricCollection"]

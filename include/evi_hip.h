@@ -127,6 +127,40 @@ int evi_topk_merge(const float* scores, const int64_t* ids, int P, int Q, int k,
 int evi_segment_topk(const float* scores, const int64_t* edge_ptr, int B, int k,
                      int32_t* out_index, float* out_score, int32_t* out_count, void* stream);
 
+/* ---- T1-T5: fused per-graph ranking metrics ------------------------------------------------- */
+
+/* One pass per graph over its edge scores: exact top-k_max (score desc, position asc), then for
+ * every k of the window (k_values_host: num_k <= 16 strictly ascending ints on the HOST,
+ * k_max = the last one <= EVI_TOPK_MAX_K):
+ *   edge_recall  [B, nk] f32   hits among the first min(k, E_g) ranked edges / max(positives, 1)
+ *                              (EdgeRecallAtK, src/metrics/retriever_metrics.py:132-157);
+ *                              recall_valid [B] = graph has edges
+ *   reach        [B, nk] u8    some answer node shares an undirected component with some seed node
+ *                              after the first min(k, E_g) ranked edges (AnswerReachability,
+ *                              src/metrics/reachability.py:129-179, 330-381); reach_valid [B] = graph
+ *                              has edges, nodes, and an in-range seed and answer
+ *   answer_hit   [B, nk] u8,  answer_recall [B, nk] f32   an / the fraction of answer ENTITY ids seen
+ *                              as head or tail within the first k ranked edges
+ *                              (_oracle_metrics_for_sample, src/models/reasoner_module.py:17-68;
+ *                              compute_answer_hit, src/utils/metrics.py:206-238); answer_valid [B] =
+ *                              1 if the graph has answers, 2 if it has more than 2048 (unsupported);
+ *                              skipped when node_global_ids or answer_ids is NULL
+ *   score_margin [B] f32       min positive score - max negative score; margin_valid [B] = both
+ *                              classes present (ScoreMargin, retriever_metrics.py:376-391)
+ *   topk_index [B, k_max] i32 (-1 padding), topk_score [B, k_max] f32 (-inf padding), topk_count [B]
+ *                              the ranked list itself (RetrieverTopKEdgeWriter._select_topk_edges,
+ *                              src/callbacks/retriever_topk_edge_writer.py:294-320); each may be NULL
+ * target [E] u8 = labels > 0.5 (NULL skips recall and margin); q_idx / a_idx are the batch-global
+ * q_local_indices / a_local_indices with their [B+1] pointers; uf_workspace: [num_nodes] i32. */
+int evi_retriever_metrics(
+    const float* scores, const uint8_t* target, const int64_t* edge_index, int64_t E,
+    const int64_t* edge_ptr, const int64_t* node_ptr, int B, const int64_t* q_idx, const int64_t* q_ptr,
+    const int64_t* a_idx, const int64_t* a_ptr, const int64_t* node_global_ids, const int64_t* answer_ids,
+    const int64_t* answer_ptr, const int32_t* k_values_host, int num_k, float* edge_recall,
+    uint8_t* recall_valid, uint8_t* reach, uint8_t* reach_valid, uint8_t* answer_hit, float* answer_recall,
+    uint8_t* answer_valid, float* score_margin, uint8_t* margin_valid, int32_t* topk_index,
+    float* topk_score, int32_t* topk_count, int32_t* uf_workspace, void* stream);
+
 /* ---- G11: edge -> graph assignment and the Q/A "near" mask --------------------------------- */
 
 /* edge_batch[e] = bucketize(edge_index[0, e], node_ptr[1:], right=True) (node_ptr[g] <= v <
