@@ -70,6 +70,17 @@ _SIGNATURES = {
     "evi_segment_topk": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P]),
     "evi_retriever_metrics": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int]
                               + [_P] * 14),
+    "evi_bfs_levels": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "evi_shortest_path_pairs": (c_int, [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P,
+                                        _P, _P, _P]),
+    "evi_node_softmax_logit_workspace_bytes": (c_size_t, [c_int64]),
+    "evi_node_softmax_logit": (c_int, [_P, _P, c_int64, c_int64, _P, _P, c_size_t, _P]),
+    "evi_select_start_edges": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_float, c_int, c_int, _P,
+                                       _P, _P]),
+    "evi_seed_onehop_stats": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "evi_masked_mean_pool": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    "evi_scatter_rows_workspace_bytes": (c_size_t, [c_int64]),
+    "evi_scatter_rows": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, c_size_t, _P]),
     "evi_edge_batch": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P]),
     "evi_qa_edge_mask": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P]),
     "evi_graph_csr_workspace_bytes": (c_size_t, [c_int64]),

@@ -1,0 +1,185 @@
+// BFS levels and shortest-path edge labelling on the per-graph CSR (G2, G3).
+//
+//   evi_bfs_levels          _bfs_dist, scripts/build_retrieval_pipeline.py:610-631 (multi-source BFS
+//                           levels, unreachable = -1), over the undirected adjacency (:570-586) or
+//                           one directed half (:589-603)
+//   evi_shortest_path_pairs _shortest_path_union_mask_by_pair / ..._directed + the edge predicates
+//                           _select_shortest_edges_undirected/_directed, :650-815: for every
+//                           (seed, answer) pair with a path, the edges u->v with
+//                           dist_s[u] + 1 + dist_a[v] == dist_s[a] (either orientation when undirected)
+//
+// One workgroup per BFS job (a graph and a source set): level-synchronous, the frontier is found by
+// scanning the graph's dist slice (coalesced) and expanded by a CSR row gather; levels are separated
+// by workgroup barriers, never by launches.  Integer work, HBM/L2-latency-bound:
+// per level N_g * 4 bytes (scan) + sum_frontier deg * 4 (neighbours) + deg * 4 (dist probes).
+#include "common.hpp"
+
+namespace evi {
+
+constexpr int kBfsThreads = 1024;
+
+// mode 0: undirected (out- and in-rows), 1: follow edges (out-rows), 2: against edges (in-rows)
+__global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
+    const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
+    const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ in_ptr,
+    const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
+    int mode, int32_t* __restrict__ dist_out) {
+    __shared__ int changed;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int g = job_graph[j];
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    int32_t* dist = dist_out + dist_off[j];  // local node id -> level
+    for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
+    __syncthreads();
+    for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
+        const int64_t s = src_idx[i];
+        if (s >= n0 && s < n1) dist[s - n0] = 0;  // out-of-range sources are ignored (:619)
+    }
+    for (int level = 0;; ++level) {
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        bool any = false;
+        for (int v = tid; v < ng; v += kBfsThreads) {
+            if (dist[v] != level) continue;
+            const int64_t gv = n0 + v;
+            if (mode != 2)
+                for (int p = out_ptr[gv]; p < out_ptr[gv + 1]; ++p) {
+                    const int w = out_nbr[p] - (int)n0;
+                    if (dist[w] < 0) {
+                        dist[w] = level + 1;
+                        any = true;
+                    }
+                }
+            if (mode != 1)
+                for (int p = in_ptr[gv]; p < in_ptr[gv + 1]; ++p) {
+                    const int w = in_nbr[p] - (int)n0;
+                    if (dist[w] < 0) {
+                        dist[w] = level + 1;
+                        any = true;
+                    }
+                }
+        }
+        if (any) changed = 1;
+        __syncthreads();
+        if (!changed) break;  // every wave reaches this: the frontier is empty
+        __syncthreads();
+    }
+}
+
+// One workgroup per dense pair slot p = (graph g, i-th seed job of g, j-th answer job of g).
+//   pair_seed_job[p], pair_answer_job[p]: BFS job ids whose dist slices are dist_from / dist_to
+//   pair_answer_node[p]: batch-global answer node
+// PASS 0: pair_len[p] = dist_s[a] (or -1), pair_edge_count[p], mask |= edges.  PASS 1: write the
+// pair's edge ids (batch-global, ascending) at pair_edge_ids[pair_edge_off[p] ...].
+template <int PASS>
+__global__ __launch_bounds__(kBfsThreads) void k_shortest_path_pairs(
+    const int32_t* __restrict__ pair_graph, const int32_t* __restrict__ pair_seed_job,
+    const int32_t* __restrict__ pair_answer_job, const int64_t* __restrict__ pair_answer_node,
+    const int64_t* __restrict__ dist_off, const int32_t* __restrict__ dist, const int64_t* __restrict__ edge_index,
+    int64_t E, const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr, int directed,
+    int32_t* __restrict__ pair_len, int32_t* __restrict__ pair_edge_count, uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ pair_edge_off, int64_t* __restrict__ pair_edge_ids) {
+    __shared__ int scan[kBfsThreads];
+    __shared__ int base;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int g = pair_graph[p];
+    const int64_t n0 = node_ptr[g];
+    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    const int32_t* ds = dist + dist_off[pair_seed_job[p]];
+    const int32_t* da = dist + dist_off[pair_answer_job[p]];
+    const int dsa = ds[pair_answer_node[p] - n0];
+    if (PASS == 0 && tid == 0) pair_len[p] = dsa;
+    if (dsa < 0) {
+        if (PASS == 0 && tid == 0) pair_edge_count[p] = 0;
+        return;
+    }
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int64_t c0 = e0; c0 < e1; c0 += kBfsThreads) {
+        const int64_t e = c0 + tid;
+        bool keep = false;
+        if (e < e1) {
+            const int u = (int)(edge_index[e] - n0), v = (int)(edge_index[E + e] - n0);
+            const int su = ds[u], av = da[v];
+            keep = su >= 0 && av >= 0 && su + 1 + av == dsa;
+            if (!directed && !keep) {
+                const int sv = ds[v], au = da[u];
+                keep = sv >= 0 && au >= 0 && sv + 1 + au == dsa;
+            }
+        }
+        if (PASS == 0) {
+            if (keep) mask[e] = 1;
+            // count
+            scan[tid] = keep ? 1 : 0;
+            __syncthreads();
+            for (int off = kBfsThreads >> 1; off > 0; off >>= 1) {
+                if (tid < off) scan[tid] += scan[tid + off];
+                __syncthreads();
+            }
+            if (tid == 0) base += scan[0];
+            __syncthreads();
+        } else {
+            // ordered compaction: inclusive scan of the keep flags
+            scan[tid] = keep ? 1 : 0;
+            __syncthreads();
+            for (int off = 1; off < kBfsThreads; off <<= 1) {
+                const int add = tid >= off ? scan[tid - off] : 0;
+                __syncthreads();
+                scan[tid] += add;
+                __syncthreads();
+            }
+            if (keep) pair_edge_ids[pair_edge_off[p] + base + scan[tid] - 1] = e;
+            __syncthreads();
+            if (tid == kBfsThreads - 1) base += scan[tid];
+            __syncthreads();
+        }
+    }
+    if (PASS == 0 && tid == 0) pair_edge_count[p] = base;
+}
+
+}  // namespace evi
+
+using namespace evi;
+
+extern "C" int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
+                              const int64_t* dist_off, int num_jobs, const int64_t* node_ptr, const int32_t* in_ptr,
+                              const int32_t* in_nbr, const int32_t* out_ptr, const int32_t* out_nbr, int mode,
+                              int32_t* dist_out, void* stream) {
+    EVI_REQUIRE(num_jobs >= 0, "evi_bfs_levels: num_jobs must be >= 0");
+    EVI_REQUIRE(mode >= 0 && mode <= 2, "evi_bfs_levels: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
+    if (num_jobs == 0) return EVI_OK;
+    EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels: null pointer");
+    hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), 0, reinterpret_cast<hipStream_t>(stream),
+                       job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, mode, dist_out);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_shortest_path_pairs(int pass, const int32_t* pair_graph, const int32_t* pair_seed_job,
+                                       const int32_t* pair_answer_job, const int64_t* pair_answer_node, int num_pairs,
+                                       const int64_t* dist_off, const int32_t* dist, const int64_t* edge_index,
+                                       int64_t E, const int64_t* node_ptr, const int64_t* edge_ptr, int directed,
+                                       int32_t* pair_len, int32_t* pair_edge_count, uint8_t* edge_mask,
+                                       const int64_t* pair_edge_off, int64_t* pair_edge_ids, void* stream) {
+    EVI_REQUIRE(pass == 0 || pass == 1, "evi_shortest_path_pairs: pass must be 0 (count + mask) or 1 (fill)");
+    EVI_REQUIRE(num_pairs >= 0 && E >= 0, "evi_shortest_path_pairs: bad sizes");
+    if (num_pairs == 0) return EVI_OK;
+    EVI_REQUIRE(pair_graph && pair_seed_job && pair_answer_job && pair_answer_node && dist_off && dist && node_ptr &&
+                    edge_ptr && (E == 0 || edge_index),
+                "evi_shortest_path_pairs: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (pass == 0) {
+        EVI_REQUIRE(pair_len && pair_edge_count && (E == 0 || edge_mask), "evi_shortest_path_pairs: null output");
+        hipLaunchKernelGGL(k_shortest_path_pairs<0>, dim3(num_pairs), dim3(kBfsThreads), 0, st, pair_graph, pair_seed_job,
+                           pair_answer_job, pair_answer_node, dist_off, dist, edge_index, E, node_ptr, edge_ptr, directed,
+                           pair_len, pair_edge_count, edge_mask, pair_edge_off, pair_edge_ids);
+    } else {
+        EVI_REQUIRE(pair_edge_off && pair_edge_ids, "evi_shortest_path_pairs: null output");
+        hipLaunchKernelGGL(k_shortest_path_pairs<1>, dim3(num_pairs), dim3(kBfsThreads), 0, st, pair_graph, pair_seed_job,
+                           pair_answer_job, pair_answer_node, dist_off, dist, edge_index, E, node_ptr, edge_ptr, directed,
+                           pair_len, pair_edge_count, edge_mask, pair_edge_off, pair_edge_ids);
+    }
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}

@@ -1,0 +1,137 @@
+"""Host-side mirror of scripts/text_encode_utils.py (TextEncoder, encode_to_memmap).
+
+The transformer forward stays in PyTorch-ROCm (third-party `transformers`, exactly as the
+reference runs it); the tail — masked mean pooling and the id-addressed scatter into the embedding
+table — runs in libevi_hip.so (`evi_masked_mean_pool`, `evi_scatter_rows`), and the table is built
+in HBM instead of a host memmap with a Python row loop (scripts/text_encode_utils.py:137-146).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+
+ENCODER_EPS = 1e-6  # scripts/text_encode_utils.py:10
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def masked_mean_pool(hidden: torch.Tensor, attention_mask: torch.Tensor, *, fp16: bool = False,
+                     eps: float = ENCODER_EPS) -> torch.Tensor:
+    """[b, L, D] x [b, L] -> [b, D] f32 on the device (reference arithmetic: text_encode_utils.py:60-64)."""
+    dev = ops._require_gpu(hidden, attention_mask)
+    if hidden.dim() != 3 or attention_mask.dim() != 2 or hidden.shape[:2] != attention_mask.shape:
+        raise ValueError(f"hidden {tuple(hidden.shape)} / attention_mask {tuple(attention_mask.shape)} mismatch")
+    if hidden.dtype not in _DTYPE_CODE:
+        raise ValueError(f"unsupported hidden dtype {hidden.dtype}")
+    hid = hidden.contiguous()
+    mask = attention_mask.to(torch.int64).contiguous()
+    b, L, D = hid.shape
+    out = torch.empty((b, D), dtype=torch.float32, device=dev)
+    if b == 0 or D == 0:
+        return out
+    lib = _lib.load()
+    _lib.check(lib.evi_masked_mean_pool(ops._ptr(hid), _DTYPE_CODE[hid.dtype], ops._ptr(mask), b, L, D, int(bool(fp16)),
+                                        float(eps), ops._ptr(out), ops._stream(dev)))
+    return out
+
+
+def scatter_rows(table: torch.Tensor, rows: torch.Tensor, ids: torch.Tensor) -> None:
+    """table[ids[i]] = rows[i] for ids inside [0, table.size(0)); later rows win on repeats."""
+    dev = ops._require_gpu(table, rows, ids)
+    if table.dtype != torch.float32 or not table.is_contiguous():
+        raise ValueError("table must be a contiguous float32 tensor")
+    rows = ops._f32c(rows, "rows")
+    ids = ids.to(torch.int64).contiguous().view(-1)
+    if rows.dim() != 2 or rows.size(0) != ids.numel() or rows.size(1) != table.size(1):
+        raise ValueError("rows must be [len(ids), table.size(1)]")
+    max_id = table.size(0) - 1
+    if max_id < 0 or ids.numel() == 0 or table.size(1) == 0:
+        return
+    lib = _lib.load()
+    ws = ops._workspace(dev, "scatter_rows", int(lib.evi_scatter_rows_workspace_bytes(max_id)))
+    _lib.check(lib.evi_scatter_rows(ops._ptr(rows), ops._ptr(ids), ids.numel(), table.size(1), ops._ptr(table), max_id,
+                                    ws.data_ptr(), ws.numel(), ops._stream(dev)))
+
+
+def _iter_batches(total: int, batch_size: int, offset: int = 0) -> Iterable[Tuple[int, int]]:
+    for start in range(offset, total, batch_size):
+        yield start, min(start + batch_size, total)
+
+
+class TextEncoder:
+    """Same constructor and `encode` contract as the reference wrapper
+    (scripts/text_encode_utils.py:13-67): returns a CPU float32 [n, D] tensor."""
+
+    def __init__(self, model_name: str, device: str, fp16: bool, progress: bool) -> None:
+        try:
+            from transformers import AutoModel, AutoTokenizer
+        except ImportError as exc:
+            raise SystemExit("transformers is required for text encoding. pip install transformers.") from exc
+        self.tokenizer = AutoTokenizer.from_pretrained(model_name, trust_remote_code=True)
+        self.model = AutoModel.from_pretrained(model_name, trust_remote_code=True)
+        self.model.to(device)
+        self.model.eval()
+        self.device = device
+        self.dtype = torch.float16 if fp16 else torch.float32
+        self.progress = progress
+
+    @classmethod
+    def from_components(cls, tokenizer, model, device: str, fp16: bool = False, progress: bool = False) -> "TextEncoder":
+        """Build from an already-loaded tokenizer/model (offline use, tests)."""
+        self = object.__new__(cls)
+        self.tokenizer, self.model, self.device = tokenizer, model, device
+        self.dtype = torch.float16 if fp16 else torch.float32
+        self.progress = progress
+        return self
+
+    @torch.no_grad()
+    def encode_to_device(self, texts: Sequence[str], batch_size: int) -> torch.Tensor:
+        """As `encode`, but the result stays in HBM: no per-batch device-to-host sync."""
+        if not texts:
+            return torch.empty((0, 0), dtype=torch.float32, device=self.device)
+        pooled: List[torch.Tensor] = []
+        for start, end in _iter_batches(len(texts), batch_size):
+            inputs = self.tokenizer(list(texts[start:end]), padding=True, truncation=True, return_tensors="pt")
+            inputs = {k: v.to(self.device) for k, v in inputs.items()}
+            hidden = self.model(**inputs).last_hidden_state
+            pooled.append(masked_mean_pool(hidden, inputs["attention_mask"], fp16=self.dtype == torch.float16))
+        return torch.cat(pooled, dim=0)
+
+    @torch.no_grad()
+    def encode(self, texts: Sequence[str], batch_size: int, show_progress: Optional[bool] = None,
+               desc: Optional[str] = None) -> torch.Tensor:
+        if not texts:
+            return torch.empty((0, 0), dtype=torch.float32)
+        return self.encode_to_device(texts, batch_size).to("cpu", dtype=torch.float32)
+
+
+def encode_to_memmap(encoder: TextEncoder, texts: Sequence[str], emb_ids: Sequence[int], batch_size: int,
+                     max_embedding_id: int, out_path: Path, desc: Optional[str], show_progress: bool) -> torch.Tensor:
+    """Same contract as the reference (scripts/text_encode_utils.py:70-112): a zero-initialised
+    [(max_id + 1), D] f32 table with row emb_id = embedding, saved with torch.save to out_path and
+    returned (CPU).  The table is assembled in HBM; no host memmap is needed."""
+    if max_embedding_id < 0:
+        return torch.empty((0, 0), dtype=torch.float32)
+    if len(texts) != len(emb_ids):
+        raise ValueError("texts and emb_ids must have the same length")
+    if not texts:
+        tensor = torch.zeros((max_embedding_id + 1, 0), dtype=torch.float32)
+        torch.save(tensor, out_path)
+        return tensor
+    table = None
+    for start, end in _iter_batches(len(texts), batch_size):
+        emb = encoder.encode_to_device(list(texts[start:end]), batch_size)
+        if table is None:
+            dim = int(emb.shape[1]) if emb.numel() > 0 else 0
+            table = torch.zeros((max_embedding_id + 1, dim), dtype=torch.float32, device=emb.device)
+        ids = torch.as_tensor(list(emb_ids[start:end]), dtype=torch.int64, device=emb.device)
+        scatter_rows(table, emb, ids)
+    tensor = table.to("cpu")
+    torch.save(tensor, out_path)
+    return tensor
+
+
+__all__ = ["TextEncoder", "encode_to_memmap", "masked_mean_pool", "scatter_rows", "ENCODER_EPS"]

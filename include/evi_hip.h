@@ -195,6 +195,81 @@ int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t* node_ptr,
                   int B, int64_t N, int32_t* in_ptr, int32_t* in_nbr, int32_t* in_eid, int32_t* out_ptr,
                   int32_t* out_nbr, int32_t* out_eid, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- G2/G3: BFS levels and shortest-path labelling --------------------------------------------- */
+
+/* num_jobs independent multi-source BFS runs, one workgroup each.  Job j explores graph
+ * job_graph[j] from the batch-global source nodes src_idx[src_ptr[j] .. src_ptr[j+1]) (sources
+ * outside the graph are ignored) and writes levels (unreachable = -1) for the graph's nodes, in
+ * local node order, at dist_out + dist_off[j].  mode 0: undirected adjacency (both CSR halves),
+ * 1: along edges, 2: against edges.
+ * Replaces _bfs_dist over _build_undirected_adjacency / _build_directed_adjacency,
+ * scripts/build_retrieval_pipeline.py:570-631. */
+int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
+                   const int64_t* dist_off, int num_jobs, const int64_t* node_ptr, const int32_t* in_ptr,
+                   const int32_t* in_nbr, const int32_t* out_ptr, const int32_t* out_nbr, int mode,
+                   int32_t* dist_out, void* stream);
+
+/* Shortest-path DAG edges of (seed, answer) pairs.  Pair slot p belongs to graph pair_graph[p]; its
+ * seed / answer distances are the BFS jobs pair_seed_job[p] / pair_answer_job[p] of evi_bfs_levels
+ * (answers explored with mode 2 when directed) and pair_answer_node[p] is the batch-global answer.
+ *   pass 0: pair_len[p] = dist_seed[answer] (-1: no path, the reference emits no pair),
+ *           pair_edge_count[p], and edge_mask[e] = 1 (caller zeroes it) for every edge u->v with
+ *           dist_s[u] + 1 + dist_a[v] == pair_len[p], in either orientation unless `directed`;
+ *   pass 1: the pair's edge ids (batch-global, ascending) at pair_edge_ids[pair_edge_off[p] ...].
+ * Replaces _shortest_path_union_mask_by_pair(_directed) and _select_shortest_edges_*,
+ * scripts/build_retrieval_pipeline.py:650-815. */
+int evi_shortest_path_pairs(int pass, const int32_t* pair_graph, const int32_t* pair_seed_job,
+                            const int32_t* pair_answer_job, const int64_t* pair_answer_node, int num_pairs,
+                            const int64_t* dist_off, const int32_t* dist, const int64_t* edge_index, int64_t E,
+                            const int64_t* node_ptr, const int64_t* edge_ptr, int directed, int32_t* pair_len,
+                            int32_t* pair_edge_count, uint8_t* edge_mask, const int64_t* pair_edge_off,
+                            int64_t* pair_edge_ids, void* stream);
+
+/* ---- G8/G9/G10: seed expansion and score post-processing ----------------------------------------- */
+
+/* logit of p = (softmax of the score over the head's out-edges + softmax over the tail's in-edges)/2,
+ * p clamped to [1e-6, 1 - 1e-6].  Node ids in edge_index only need to be < N (batch-global or local).
+ * Replaces GAgentBuilder._node_softmax_logit, src/data/components/g_agent_builder.py:595-626. */
+size_t evi_node_softmax_logit_workspace_bytes(int64_t N);
+int evi_node_softmax_logit(const float* edge_scores, const int64_t* edge_index, int64_t E, int64_t N,
+                           float* out_logit, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Undirected one-hop seed expansion: for every seed node keep its
+ * min(deg, min(max_edges, max(min_edges, ceil(float(deg) * ratio)))) best incident edges (the seed
+ * as head OR tail; a self loop counts twice) by (score desc, head-incidence before tail-incidence,
+ * edge id asc); out_mask[e] = 1 for the union (the sorted unique ids are its non-zeros).
+ * start_max_edges < 0 = no cap.  status: 1 = a seed outside [0, N), 2 = a partial selection larger
+ * than EVI_TOPK_MAX_K.  CSR from evi_graph_csr.
+ * Replaces GAgentBuilder._select_start_edges, src/data/components/g_agent_builder.py:655-724. */
+int evi_select_start_edges(const float* edge_scores, int64_t E, const int64_t* seed_nodes, int64_t num_seeds,
+                           const int32_t* in_ptr, const int32_t* in_eid, const int32_t* out_ptr,
+                           const int32_t* out_eid, int64_t N, float start_keep_ratio, int start_min_edges,
+                           int start_max_edges, uint8_t* out_mask, int32_t* status, void* stream);
+
+/* Incident edge count and positive incident count of each seed (bincount(heads) + bincount(tails));
+ * -1 for seeds outside [0, N).  Replaces scripts/seed_onehop_stats.py:96-117. */
+int evi_seed_onehop_stats(const int64_t* seed_nodes, int64_t num_seeds, const uint8_t* positive,
+                          const int32_t* in_ptr, const int32_t* in_eid, const int32_t* out_ptr,
+                          const int32_t* out_eid, int64_t N, int32_t* out_degree, int32_t* out_positive_degree,
+                          void* stream);
+
+/* ---- E2/E3: the text-encoding tail ------------------------------------------------------------------ */
+
+/* out[b, d] = sum_l hidden[b, l, d] * mask[b, l] / max(sum_l mask[b, l], eps)  (eps = 1e-6), in the
+ * pooling dtype (f16 when pool_fp16: hidden is rounded to f16, the sum is rounded once to f16 and
+ * the clamp and division happen in f16), returned as f32.  hidden_dtype: 0 f32, 1 f16, 2 bf16;
+ * attention_mask [b, L] i64.  Replaces the pooling of TextEncoder.encode,
+ * scripts/text_encode_utils.py:60-65. */
+int evi_masked_mean_pool(const void* hidden, int hidden_dtype, const int64_t* attention_mask, int b, int L,
+                         int D, int pool_fp16, float eps, float* out, void* stream);
+
+/* table[ids[i], :] = src[i, :] for 0 <= ids[i] <= max_embedding_id (other rows skipped); when an id
+ * repeats, the last row wins, as in the reference's sequential loop.
+ * Replaces _write_chunk, scripts/text_encode_utils.py:137-146. */
+size_t evi_scatter_rows_workspace_bytes(int64_t max_embedding_id);
+int evi_scatter_rows(const float* src, const int64_t* ids, int64_t n, int D, float* table,
+                     int64_t max_embedding_id, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- G6/G7: DDE structure features ----------------------------------------------------------- */
 
 /* node_struct[v, c*S + j], S = 1 + rounds + rev_rounds (topic-major, as

@@ -1,0 +1,181 @@
+"""GPU parity of BFS / shortest-path labelling (G1-G4), seed expansion (G8-G10) and the encoding
+tail (E2/E3) against the reference-generated golden vectors and the oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from evi_rag_amd import synthetic
+from oracle import encode as oenc
+from oracle import graph as ograph
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("c", range(5))
+def test_bfs_and_shortest_path_match_reference_golden(dev, c):
+    from evi_rag_amd import labelling as L
+
+    z = _load("bfs")
+    n = int(z[f"c{c}_n"])
+    src, dst = z[f"c{c}_src"], z[f"c{c}_dst"]
+    seeds, answers = z[f"c{c}_seeds"].tolist(), z[f"c{c}_answers"].tolist()
+    assert L.bfs_dist(n, src, dst, seeds) == z[f"c{c}_dist"].tolist()
+    assert L.bfs_dist(n, src, dst, seeds, directed=True) == z[f"c{c}_ddist"].tolist()
+    for directed, p in ((False, ""), (True, "d")):
+        mask, ps, pa, pe, pc, pl = L.shortest_path_union_mask_by_pair(n, src, dst, seeds, answers, directed=directed)
+        assert mask == z[f"c{c}_{p}mask"].tolist()
+        assert ps == z[f"c{c}_{p}pair_start"].tolist() and pa == z[f"c{c}_{p}pair_answer"].tolist()
+        assert pe == z[f"c{c}_{p}pair_edges"].tolist() and pc == z[f"c{c}_{p}pair_counts"].tolist()
+        assert pl == z[f"c{c}_{p}pair_len"].tolist()
+
+
+def test_batched_labelling_matches_oracle(dev):
+    """CWQ-shaped graphs (N_g ~ 3000, E_g ~ 10000: BASELINE config 3), all graphs in one launch."""
+    from evi_rag_amd import labelling as L
+
+    sb = synthetic.make_batch(6, nodes_per_graph=3000, edges_per_graph=10000, emb_dim=4, seed=2,
+                              attach_embeddings=False, max_seeds=3, max_answers=6)
+    nn, es, ed, seeds, answers = [], [], [], [], []
+    for g in range(sb.num_graphs):
+        n0, n1, e0, e1 = sb.ptr[g], sb.ptr[g + 1], sb.edge_ptr[g], sb.edge_ptr[g + 1]
+        nn.append(int(n1 - n0))
+        es.append(sb.edge_index[0, e0:e1] - n0)
+        ed.append(sb.edge_index[1, e0:e1] - n0)
+        seeds.append((sb.q_local_indices[sb.q_ptr[g]: sb.q_ptr[g + 1]] - n0).tolist())
+        answers.append((sb.a_local_indices[sb.a_ptr[g]: sb.a_ptr[g + 1]] - n0).tolist())
+    gb = L.GraphBatch(nn, es, ed)
+    for mode, directed in ((0, False), (1, True)):
+        dists = L.bfs_dist_batch(gb, seeds, mode=mode)
+        for g in range(sb.num_graphs):
+            adj = (ograph.build_directed_adjacency if directed else ograph.build_undirected_adjacency)(nn[g], es[g], ed[g])
+            assert dists[g].tolist() == ograph.bfs_dist(nn[g], adj, seeds[g])
+    for directed in (False, True):
+        res = L.shortest_path_union_mask_by_pair_batch(gb, seeds, answers, directed=directed)
+        for g in range(sb.num_graphs):
+            ref = ograph.shortest_path_union_mask_by_pair(nn[g], es[g], ed[g], seeds[g], answers[g], directed=directed)
+            assert res[g][0].tolist() == ref[0]
+            assert tuple(res[g][1:]) == tuple(ref[1:]), (g, directed)
+
+
+def test_g_agent_selection_matches_reference_golden(dev):
+    from evi_rag_amd import labelling as L
+
+    z = _load("g_agent_select")
+    b = types.SimpleNamespace(**{k[2:]: z[k] for k in z.files if k.startswith("b_")})
+    scores = z["scores"]
+    params = z["start_params"].tolist()
+    for g in range(int(z["num_graphs"])):
+        lo, hi = int(b.edge_ptr[g]), int(b.edge_ptr[g + 1])
+        n0, n1 = int(b.ptr[g]), int(b.ptr[g + 1])
+        heads = torch.from_numpy(b.edge_index[0, lo:hi] - n0).to(dev)
+        tails = torch.from_numpy(b.edge_index[1, lo:hi] - n0).to(dev)
+        logit = L.node_softmax_logit(edge_scores=torch.from_numpy(scores[lo:hi]).to(dev), edge_head_locals=heads,
+                                     edge_tail_locals=tails, num_nodes=n1 - n0)
+        np.testing.assert_allclose(logit.cpu().numpy(), z[f"g{g}_logit"], rtol=0, atol=3e-5)
+        ref_logit = torch.from_numpy(z[f"g{g}_logit"]).to(dev)  # integer outputs checked on the reference's logits
+        for tk in (5, 500):
+            assert np.array_equal(L.select_topk_edges(edge_scores=ref_logit, edge_top_k=tk).cpu().numpy(), z[f"g{g}_topk{tk}"])
+        seeds = torch.from_numpy(b.q_local_indices[int(b.q_ptr[g]): int(b.q_ptr[g + 1])] - n0).to(dev)
+        for ri, (ratio, mn, mx) in enumerate(params):
+            got = L.select_start_edges(heads=heads, tails=tails, edge_scores=ref_logit, start_node_locals=seeds,
+                                       num_nodes=n1 - n0, start_keep_ratio=ratio, start_min_edges=int(mn),
+                                       start_max_edges=None if mx < 0 else int(mx))
+            assert np.array_equal(got.cpu().numpy(), z[f"g{g}_start{ri}"]), (g, ri)
+
+
+def test_seed_expansion_hub_matches_oracle(dev):
+    """A hub seed with thousands of incident edges, exact score ties and a self loop."""
+    from evi_rag_amd import labelling as L
+
+    rng = np.random.default_rng(0)
+    n, e = 500, 20000
+    heads = rng.integers(0, n, size=e)
+    tails = rng.integers(0, n, size=e)
+    heads[: e // 2] = 7  # hub as head
+    tails[e // 2: e // 2 + 3000] = 7  # and as tail
+    heads[5], tails[5] = 7, 7  # self loop
+    scores = np.round(rng.standard_normal(e), 1).astype(np.float32)  # many ties
+    labels = (rng.random(e) < 0.1).astype(np.float32)
+    seeds = np.array([7, 3, 7, 11])
+    for ratio, mn, mx in [(0.25, 1, None), (0.01, 1, 100), (1.0, 1, None), (0.5, 0, 2000)]:
+        ref = ograph.select_start_edges(heads, tails, scores, seeds, n, ratio, mn, mx)
+        got = L.select_start_edges(heads=torch.from_numpy(heads).to(dev), tails=torch.from_numpy(tails).to(dev),
+                                   edge_scores=torch.from_numpy(scores).to(dev), start_node_locals=torch.from_numpy(seeds),
+                                   num_nodes=n, start_keep_ratio=ratio, start_min_edges=mn, start_max_edges=mx)
+        assert np.array_equal(got.cpu().numpy(), ref), (ratio, mn, mx)
+    stats = L.seed_onehop_stats(torch.from_numpy(heads).to(dev), torch.from_numpy(tails).to(dev),
+                                torch.from_numpy(labels).to(dev), torch.tensor([7, 3, 7, 11, 9999, -1]), n)
+    assert stats == ograph.seed_onehop_stats(heads, tails, labels, np.array([7, 3, 7, 11, 9999, -1]), n)
+
+
+def test_masked_mean_pool_and_scatter_match_reference_golden(dev):
+    from evi_rag_amd import text_encode as T
+
+    z = _load("encode")
+    nb = int(z["num_batches"])
+    for fp16 in (False, True):
+        pooled = torch.cat([T.masked_mean_pool(torch.from_numpy(z[f"hidden_{i}"]).to(dev),
+                                               torch.from_numpy(z[f"mask_{i}"]).to(dev), fp16=fp16) for i in range(nb)])
+        np.testing.assert_allclose(pooled.cpu().numpy(), z[f"pooled_fp16_{int(fp16)}"], rtol=0, atol=2e-3 if fp16 else 1e-6)
+    # f16 / bf16 hidden states (a half-precision encoder) pool like their f32 upcast
+    h = torch.from_numpy(z["hidden_1"]).to(dev)
+    m = torch.from_numpy(z["mask_1"]).to(dev)
+    for dt in (torch.float16, torch.bfloat16):
+        got = T.masked_mean_pool(h.to(dt), m).cpu().numpy()
+        np.testing.assert_allclose(got, oenc.masked_mean_pool(h.to(dt).float().cpu().numpy(), z["mask_1"]), rtol=0, atol=1e-6)
+    table = torch.zeros((int(z["max_embedding_id"]) + 1, int(z["D"])), device=dev)
+    rows = torch.from_numpy(z["pooled_fp16_0"]).to(dev)
+    ids = torch.from_numpy(z["emb_ids"]).to(dev)
+    for s, e in oenc.iter_batches(10, 4):
+        T.scatter_rows(table, rows[s:e], ids[s:e])
+    assert np.array_equal(table.cpu().numpy(), z["memmap_table"])
+    # repeated id: the later row wins, like the reference's sequential loop
+    T.scatter_rows(table, rows[:3], torch.tensor([4, 4, 4], device=dev))
+    assert np.array_equal(table[4].cpu().numpy(), z["pooled_fp16_0"][2])
+
+
+def test_text_encoder_mirror_end_to_end(dev, tmp_path):
+    """TextEncoder.encode / encode_to_memmap with the same fake tokenizer + lookup model the golden
+    generator drove the reference with (tests/golden/make_golden.py:gen_encode)."""
+    from evi_rag_amd import text_encode as T
+
+    z = _load("encode")
+    table = torch.from_numpy(z["table"]).to(dev)
+
+    class Tok:
+        def __call__(self, texts, padding=True, truncation=True, return_tensors="pt"):
+            ids = [[(sum(map(ord, w)) % 97) + 1 for w in t.split()][:8] for t in texts]
+            L = max(1, max(len(i) for i in ids))
+            input_ids = torch.zeros((len(ids), L), dtype=torch.long)
+            mask = torch.zeros((len(ids), L), dtype=torch.long)
+            for r, row in enumerate(ids):
+                input_ids[r, : len(row)] = torch.tensor(row, dtype=torch.long)
+                mask[r, : len(row)] = 1
+            return {"input_ids": input_ids, "attention_mask": mask}
+
+    class Model(torch.nn.Module):
+        def forward(self, input_ids, attention_mask):
+            hid = table[input_ids] + 0.01 * torch.arange(input_ids.size(1), dtype=torch.float32, device=dev).view(1, -1, 1)
+            return types.SimpleNamespace(last_hidden_state=hid)
+
+    texts = ["alpha beta", "gamma", "delta epsilon zeta eta", "", "theta iota", "kappa lambda mu", "nu",
+             "xi omicron pi rho sigma tau upsilon phi chi psi omega", "alpha", "beta beta beta"]
+    enc = T.TextEncoder.from_components(Tok(), Model(), str(dev), fp16=False)
+    pooled = enc.encode(texts, batch_size=4)
+    assert pooled.device.type == "cpu" and pooled.dtype == torch.float32
+    np.testing.assert_allclose(pooled.numpy(), z["pooled_fp16_0"], rtol=0, atol=1e-6)
+    assert tuple(enc.encode([], 4).shape) == (0, 0)
+    out = tmp_path / "entity_embeddings.pt"
+    tensor = T.encode_to_memmap(enc, texts, z["emb_ids"].tolist(), 4, int(z["max_embedding_id"]), out, None, False)
+    np.testing.assert_allclose(tensor.numpy(), z["memmap_table"], rtol=0, atol=1e-6)
+    assert torch.equal(torch.load(out), tensor) and torch.all(tensor[0] == 0)
+    with pytest.raises(ValueError, match="same length"):
+        T.encode_to_memmap(enc, texts, [1], 4, 12, out, None, False)
