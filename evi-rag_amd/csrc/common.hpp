@@ -191,4 +191,39 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
     return 0;  // unreachable
 }
 
+// The k-th largest of `cnt` distinct keys (1 <= k <= cnt), by 8 MSB-first radix passes; no limit on
+// k or cnt.  All threads call; the result is uniform across the block.
+template <class Load>
+__device__ inline uint64_t block_kth_largest(SelectShared& sh, Load load, int64_t cnt, int64_t k) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    uint64_t prefix = 0, mask = 0;
+    int64_t need = k;  // rank of the wanted key inside the matching set
+    for (int pass = 7; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int i = tid; i < 256; i += nt) sh.hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < cnt; i += nt) {
+            const uint64_t key = load(i);
+            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFF], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int64_t acc = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + sh.hist[d] >= need) break;
+                acc += sh.hist[d];
+            }
+            sh.scalar[1] = (uint32_t)d;
+            sh.scalar[2] = (uint32_t)acc;
+        }
+        __syncthreads();
+        need -= sh.scalar[2];
+        prefix |= (uint64_t)sh.scalar[1] << shift;
+        mask |= 0xFFull << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
 }  // namespace evi

@@ -80,10 +80,6 @@ __global__ __launch_bounds__(kSelectThreads) void k_select_start_edges(
     if (max_edges >= 0) k = max_edges == 0 ? 0 : (k < max_edges ? k : max_edges);
     if (k > deg) k = deg;
     if (k <= 0) return;
-    if (k > EVI_TOPK_MAX_K && k < deg) {  // partial selection larger than the sort window
-        if (threadIdx.x == 0) atomicOr(status, 2);
-        return;
-    }
     if (k >= deg) {  // everything incident is kept: no ranking needed
         for (int i = threadIdx.x; i < deg; i += blockDim.x) mask[i < dout ? out_eid[ob + i] : in_eid[ib + i - dout]] = 1;
         return;
@@ -93,8 +89,12 @@ __global__ __launch_bounds__(kSelectThreads) void k_select_start_edges(
         const uint32_t e = (uint32_t)(tail_block ? in_eid[ib + (i - dout)] : out_eid[ob + i]);
         return make_key(scores[e], (tail_block ? 0x80000000u : 0u) | e);
     };
-    const int m = block_topk(sh, load, deg, (int)k);
-    for (int i = threadIdx.x; i < m; i += blockDim.x) mask[key_index(sh.keys[i]) & 0x7FFFFFFFu] = 1;
+    // only the SET of the k best entries is needed: find the k-th key, keep everything at or above it
+    const uint64_t kth = block_kth_largest(sh, load, deg, k);
+    for (int i = threadIdx.x; i < deg; i += blockDim.x) {
+        const uint64_t key = load(i);
+        if (key >= kth) mask[key_index(key) & 0x7FFFFFFFu] = 1;
+    }
 }
 
 // ---- G10 --------------------------------------------------------------------------------------------

@@ -260,8 +260,6 @@ def select_start_edges(*, heads: torch.Tensor, tails: torch.Tensor, edge_scores:
     st = int(status.item())
     if st & 1:
         raise IndexError("start_node_locals contains a node outside [0, num_nodes)")
-    if st & 2:
-        raise NotImplementedError("a seed keeps more than 2048 but not all of its incident edges")
     return torch.nonzero(mask, as_tuple=False).view(-1)
 
 

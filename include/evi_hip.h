@@ -238,8 +238,8 @@ int evi_node_softmax_logit(const float* edge_scores, const int64_t* edge_index, 
  * min(deg, min(max_edges, max(min_edges, ceil(float(deg) * ratio)))) best incident edges (the seed
  * as head OR tail; a self loop counts twice) by (score desc, head-incidence before tail-incidence,
  * edge id asc); out_mask[e] = 1 for the union (the sorted unique ids are its non-zeros).
- * start_max_edges < 0 = no cap.  status: 1 = a seed outside [0, N), 2 = a partial selection larger
- * than EVI_TOPK_MAX_K.  CSR from evi_graph_csr.
+ * start_max_edges < 0 = no cap; any degree and any k are supported (radix select of the k-th key).
+ * status: 1 = a seed outside [0, N).  CSR from evi_graph_csr.
  * Replaces GAgentBuilder._select_start_edges, src/data/components/g_agent_builder.py:655-724. */
 int evi_select_start_edges(const float* edge_scores, int64_t E, const int64_t* seed_nodes, int64_t num_seeds,
                            const int32_t* in_ptr, const int32_t* in_eid, const int32_t* out_ptr,
