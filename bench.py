@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph-eval", action="store_true")
     return ap.parse_args()
 
 
@@ -114,6 +115,70 @@ def cpu_baseline(shard, queries, k, n_total, cpu_rows, budget_s):
     return ob.time_cosine_topk(q, x, k, n_total=n_total, budget_s=budget_s)
 
 
+def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=4096, relations=4096):
+    """Secondary leg (not part of `value`): the per-question subgraph scoring stage of the same
+    evaluation — Retriever forward (DDE + edge scorer) and the fused ranking metrics on one
+    WebQSP-shaped batch (32 graphs, N_g ~ 1500, E_g ~ 4096, D = H)."""
+    import ctypes
+
+    from evi_rag_amd import _lib, metrics as M, synthetic
+    from evi_rag_amd.retriever import Retriever
+
+    lib = _lib.load()
+    sb = synthetic.make_batch(graphs, nodes_per_graph=nodes, edges_per_graph=edges, emb_dim=D, num_relations=relations,
+                              num_entities=1 << 17, seed=1)
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.answer_entity_ids_ptr = torch.from_numpy(sb.answer_ptr).to(dev)
+    batch.num_relations = relations
+    torch.manual_seed(0)
+    model = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
+    coll = M.RetrieverMetricCollection(K_WINDOW)
+    target = batch.labels > 0.5
+    E, N, H = sb.num_edges, sb.num_nodes, D
+    kp = 3 * D + 4
+    gemm_flops = 2.0 * D * D * (N + 1 + 3 * graphs + relations) + 2.0 * (2 * E) * H * (kp + H)
+
+    def one():
+        out = model(batch)
+        coll.update(preds=out.logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=graphs)
+        return out
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize(dev)
+    lib.evi_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = model(batch)
+    torch.cuda.synchronize(dev)
+    t_fwd = (time.perf_counter() - t0) / iters
+    lib.evi_timing_enable(0)
+    ms = (ctypes.c_double * 4)()
+    ln = (ctypes.c_int32 * 4)()
+    _lib.check(lib.evi_timing_read(ms, ln, 4))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        coll.update(preds=out.logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=graphs)
+    torch.cuda.synchronize(dev)
+    t_met = (time.perf_counter() - t0) / iters
+    gemm_ms = ms[2] / iters
+    tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    metrics = {k: float(v) for k, v in coll.compute().items()}
+    return {
+        "workload": f"{graphs} graphs, N={N}, E={E}, D=H={D}, DDE 2+2, bidirectional, k window {K_WINDOW[0]}..{K_WINDOW[-1]}",
+        "forward_ms_per_batch": t_fwd * 1e3,
+        "metrics_ms_per_batch": t_met * 1e3,
+        "queries_per_s": graphs / (t_fwd + t_met),
+        "edges_per_s": E / t_fwd,
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                     "kernel": "k_gemm_nt (f32 MFMA 32x32x2)", "gemm_ms_per_batch": gemm_ms,
+                     "gemm_launches_per_batch": ln[2] / iters, "algorithmic_flops_per_batch": gemm_flops,
+                     "edge_feature_ms_per_batch": ms[3] / iters},
+        "reachability@100": metrics.get("answer/reachability@100"),
+        "edge_recall@100": metrics.get("edge/recall@100"),
+    }
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,16 +205,13 @@ def main():
     n_batches = args.warmup + args.steps
     queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, args.seed, world)
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
-    gather_s = torch.empty((world, Q, k), dtype=torch.float32, device=dev) if world > 1 else None
-    gather_i = torch.empty((world, Q, k), dtype=torch.int64, device=dev) if world > 1 else None
+    from evi_rag_amd.dist import ShardedIndex
+
+    index = ShardedIndex(shard, N, local_topk=lambda q, x, kk, base: ops.cosine_topk(q, x, kk, row_id_base=base, workspace=ws))
 
     def step(b):
-        s, i = ops.cosine_topk(queries[b], shard, k, row_id_base=row_begin, workspace=ws)
-        if world > 1:
-            dist.all_gather_into_tensor(gather_s, s)
-            dist.all_gather_into_tensor(gather_i, i)
-            s, i = ops.topk_merge(gather_s, gather_i)
-        return s, i
+        # per-shard exact top-k; for world > 1 one all-gather of the packed [Q, k] lists + merge
+        return index.topk(queries[b], k)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -232,6 +294,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(shard, queries, k, N, args.cpu_rows, args.cpu_seconds)
+        if world == 1 and not args.no_graph_eval:
+            del shard, ws
+            torch.cuda.empty_cache()
+            result["graph_eval"] = bench_graph_eval(dev, D)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -29,7 +29,7 @@ constexpr int kHubListCap = 4096;
 //              4 = edge list not grouped by graph (edge_batch decreases).
 __global__ void k_edge_batch(const int64_t* __restrict__ edge_index, int64_t E,
                              const int64_t* __restrict__ node_ptr, int B, int64_t* __restrict__ edge_batch,
-                             int32_t* __restrict__ edge_count, int32_t* __restrict__ status) {
+                             int64_t* __restrict__ edge_ptr, int32_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     auto bucket = [&](int64_t v) -> int {  // bucketize(v, ptr[1:], right=True): #{j >= 1 : ptr[j] <= v}
@@ -51,17 +51,14 @@ __global__ void k_edge_batch(const int64_t* __restrict__ edge_index, int64_t E,
         if (gp > gh) st |= 4;
     }
     if (st) atomicOr(status, st);
-    if (gh >= 0 && gh < B) atomicAdd(&edge_count[gh], 1);
-}
-
-__global__ void k_edge_ptr_scan(const int32_t* __restrict__ edge_count, int B, int64_t* __restrict__ edge_ptr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {  // B is a batch size (tens): a serial scan is fine
-        int64_t acc = 0;
-        edge_ptr[0] = 0;
-        for (int g = 0; g < B; ++g) {
-            acc += edge_count[g];
-            edge_ptr[g + 1] = acc;
-        }
+    // edge_ptr without atomics: edge e opens every graph in (batch[e-1], batch[e]]; the last edge
+    // closes the rest.  (Equals the reference's scatter_add + cumsum whenever the list is grouped,
+    // i.e. whenever status stays 0.)
+    if (gh >= 0 && gh < B) {
+        const int gprev = e > 0 ? bucket(edge_index[e - 1]) : -1;
+        for (int gg = (gprev < -1 ? -1 : gprev) + 1; gg <= gh; ++gg) edge_ptr[gg] = e;
+        if (e == E - 1)
+            for (int gg = gh + 1; gg <= B; ++gg) edge_ptr[gg] = E;
     }
 }
 
@@ -250,18 +247,17 @@ extern "C" int evi_edge_batch(const int64_t* edge_index, int64_t E, const int64_
                               int64_t* edge_batch, int64_t* edge_ptr, int32_t* edge_count_ws,
                               int32_t* status, void* stream) {
     EVI_REQUIRE(E >= 0 && B >= 1, "evi_edge_batch: need E >= 0 and B >= 1, got E=%lld B=%d", (long long)E, B);
-    EVI_REQUIRE(node_ptr && edge_ptr && edge_count_ws && status, "evi_edge_batch: null pointer");
+    EVI_REQUIRE(node_ptr && edge_ptr && status, "evi_edge_batch: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    EVI_HIP_CHECK(hipMemsetAsync(edge_count_ws, 0, sizeof(int32_t) * B, st));
+    (void)edge_count_ws;
     EVI_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    EVI_HIP_CHECK(hipMemsetAsync(edge_ptr, 0, sizeof(int64_t) * (B + 1), st));  // E == 0: all zeros
     if (E > 0) {
         EVI_REQUIRE(edge_index && edge_batch, "evi_edge_batch: null pointer");
         hipLaunchKernelGGL(k_edge_batch, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, edge_index, E,
-                           node_ptr, B, edge_batch, edge_count_ws, status);
+                           node_ptr, B, edge_batch, edge_ptr, status);
         EVI_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_edge_ptr_scan, dim3(1), dim3(64), 0, st, edge_count_ws, B, edge_ptr);
-    EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
 

@@ -19,7 +19,7 @@
 namespace evi {
 
 constexpr int kMaxKValues = 16;
-constexpr int kUfLdsNodes = 12288;  // union-find parents kept in LDS up to this many nodes (48 KiB)
+constexpr int kUfLdsNodes = 8192;  // union-find parents + flags kept in LDS up to this many nodes (64 KiB)
 constexpr int kMaxAnswers = 2048;
 
 struct KWindow {
@@ -55,12 +55,14 @@ struct MetricsArgs {
     int32_t* topk_index;     // [B, k_max] local edge position, -1 padding (may be NULL)
     float* topk_score;       // [B, k_max] (may be NULL)
     int32_t* topk_count;     // [B] (may be NULL)
-    int32_t* uf_ws;          // [N] union-find parents for graphs too large for LDS
+    int32_t* uf_ws;          // [2 N] union-find parents + flags for graphs too large for LDS
 };
 
 struct MetricsShared {
     SelectShared sel;
     int parent[kUfLdsNodes];
+    int flag[kUfLdsNodes];
+    int eu[EVI_TOPK_MAX_K], ev[EVI_TOPK_MAX_K];
     int first_rank[kMaxAnswers];
     int misc[8];  // 0: positives, 1: reach rank
     unsigned int s_min_pos, s_max_neg;
@@ -150,54 +152,68 @@ __global__ __launch_bounds__(kSelectThreads) void k_retriever_metrics(MetricsArg
     // ---- answer reachability@k --------------------------------------------------------------------
     {
         const int64_t q0 = a.q_ptr[g], q1 = a.q_ptr[g + 1], a0 = a.a_ptr[g], a1 = a.a_ptr[g + 1];
-        int* parent = num_nodes <= kUfLdsNodes ? sh.parent : (a.uf_ws + n0);
-        for (int v = tid; v < num_nodes; v += nt) parent[v] = v;
+        const bool in_lds = num_nodes <= kUfLdsNodes;
+        int* parent = in_lds ? sh.parent : (a.uf_ws + 2 * n0);
+        int* flag = in_lds ? sh.flag : (a.uf_ws + 2 * n0 + num_nodes);  // bit 0: seed, bit 1: answer (valid at roots)
+        for (int v = tid; v < num_nodes; v += nt) {
+            parent[v] = v;
+            flag[v] = 0;
+        }
+        // endpoints of the ranked edges, as local node ids, staged in LDS by all threads
+        for (int i = tid; i < m; i += nt) {
+            const int64_t e = e0 + key_index(sh.sel.keys[i]);
+            sh.eu[i] = (int)(a.edge_index[e] - n0);
+            sh.ev[i] = (int)(a.edge_index[a.E + e] - n0);
+        }
+        if (tid == 0) sh.misc[2] = sh.misc[3] = 0;
+        __syncthreads();
+        for (int64_t i = q0 + tid; i < q1; i += nt) {
+            const int64_t v = a.q_idx[i];
+            if (v >= n0 && v < n1) {
+                atomicOr(&flag[v - n0], 1);
+                sh.misc[2] = 1;
+            }
+        }
+        for (int64_t i = a0 + tid; i < a1; i += nt) {
+            const int64_t v = a.a_idx[i];
+            if (v >= n0 && v < n1) {
+                atomicOr(&flag[v - n0], 2);
+                sh.misc[3] = 1;
+            }
+        }
+        __syncthreads();
+        // valid iff edges, nodes, and at least one in-range seed and answer (reachability.py:129-179)
+        const bool valid = cnt > 0 && num_nodes > 0 && sh.misc[2] && sh.misc[3];
+        if (valid) {  // a seed that is itself an answer is reachable with zero edges
+            for (int v = tid; v < num_nodes; v += nt)
+                if (flag[v] == 3) sh.misc[1] = 0;
+        }
         __syncthreads();
         if (tid == 0) {
-            // valid iff edges, nodes, and at least one in-range seed and answer (reachability.py:129-179)
-            int nq = 0, na = 0;
-            for (int64_t i = q0; i < q1; ++i) nq += (a.q_idx[i] >= n0 && a.q_idx[i] < n1) ? 1 : 0;
-            for (int64_t i = a0; i < a1; ++i) na += (a.a_idx[i] >= n0 && a.a_idx[i] < n1) ? 1 : 0;
-            const bool valid = cnt > 0 && num_nodes > 0 && nq > 0 && na > 0 && (q1 > q0) && (a1 > a0);
             a.reach_valid[g] = valid ? 1 : 0;
-            int reach_rank = 0x7FFFFFFF;  // smallest number of ranked edges after which seeds meet answers
-            if (valid) {
-                auto connected = [&]() -> bool {
-                    for (int64_t i = a0; i < a1; ++i) {
-                        const int64_t av = a.a_idx[i];
-                        if (av < n0 || av >= n1) continue;
-                        const int ra = uf_find(parent, (int)(av - n0));
-                        for (int64_t j = q0; j < q1; ++j) {
-                            const int64_t qv = a.q_idx[j];
-                            if (qv < n0 || qv >= n1) continue;
-                            if (uf_find(parent, (int)(qv - n0)) == ra) return true;
-                        }
-                    }
-                    return false;
-                };
-                if (connected()) {
-                    reach_rank = 0;  // a seed is itself an answer
-                } else {
-                    for (int i = 0; i < m; ++i) {
-                        const int64_t e = e0 + key_index(sh.sel.keys[i]);
-                        const int64_t u = a.edge_index[e] - n0, v = a.edge_index[a.E + e] - n0;
-                        if (u < 0 || v < 0 || u >= num_nodes || v >= num_nodes) continue;
-                        const int ru = uf_find(parent, (int)u), rv = uf_find(parent, (int)v);
-                        if (ru == rv) continue;
-                        parent[rv] = ru;  // connectivity only: union order / rank do not change the answer
-                        if (connected()) {
-                            reach_rank = i + 1;
-                            break;
-                        }
+            if (valid && sh.misc[1] != 0) {
+                // smallest number of ranked edges after which a seed's component holds an answer.
+                // Connectivity only: union order / rank do not change the answer.
+                int reach_rank = 0x7FFFFFFF;
+                for (int i = 0; i < m; ++i) {
+                    const int u = sh.eu[i], v = sh.ev[i];
+                    if (u < 0 || v < 0 || u >= num_nodes || v >= num_nodes) continue;
+                    const int ru = uf_find(parent, u), rv = uf_find(parent, v);
+                    if (ru == rv) continue;
+                    parent[rv] = ru;
+                    flag[ru] |= flag[rv];
+                    if (flag[ru] == 3) {
+                        reach_rank = i + 1;
+                        break;
                     }
                 }
+                sh.misc[1] = reach_rank;
             }
-            sh.misc[1] = reach_rank;
         }
         __syncthreads();
         if (tid < nk) {
             const int k_eff = a.kw.k[tid] < m ? a.kw.k[tid] : m;
-            a.reach[(int64_t)g * nk + tid] = (a.reach_valid[g] && sh.misc[1] <= k_eff && k_eff > 0) ? 1 : 0;
+            a.reach[(int64_t)g * nk + tid] = (valid && sh.misc[1] <= k_eff && k_eff > 0) ? 1 : 0;
         }
     }
 

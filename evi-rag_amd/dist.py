@@ -1,0 +1,92 @@
+"""Multi-GPU orchestration of the retrieval path: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+  ShardedIndex      row-sharded embedding index: per-shard exact top-k, ONE fixed-shape all-gather
+                    of the packed [Q, k] (score f32, id i64) lists, merge on every rank
+                    (SURVEY.md §8e).  Replaces the pickled `dist.all_gather_object` of per-sample
+                    lists at src/callbacks/retriever_topk_edge_writer.py:450-462.  The message is
+                    Q*k*12 bytes per rank (192 KB at Q = 32, k = 500): latency-bound, so it is a
+                    single all-gather, not a ring reduction.
+  shard_graphs      round-robin assignment of question graphs to ranks (graphs never span ranks, so
+                    the scorer needs no exchange); metric counters are summed with one small
+                    all-reduce (`RetrieverMetricCollection.sync`, the reference's dist_reduce_fx="sum").
+
+Because a row's score is one fixed-order f32 FMA chain and ties break on the global row id, the
+merged result is bit-identical for every number of shards.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_rows: int, world_size: int) -> List[int]:
+    """Row r of the global index lives on the rank whose [bounds[rank], bounds[rank+1]) contains it."""
+    return [num_rows * r // world_size for r in range(world_size + 1)]
+
+
+def shard_graphs(num_graphs: int, rank: int, world_size: int) -> List[int]:
+    """Graph ids evaluated by `rank` (round-robin, like a DistributedSampler without padding)."""
+    return list(range(rank, num_graphs, world_size))
+
+
+def _default_local_topk(queries, shard, k, row_id_base):
+    from . import ops
+
+    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base)
+
+
+def _default_merge(scores, ids):
+    from . import ops
+
+    return ops.topk_merge(scores, ids)
+
+
+class ShardedIndex:
+    """The local shard of a row-sharded, L2-normalised index plus the cross-rank top-k merge."""
+
+    def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
+                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None) -> None:
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bounds = shard_bounds(int(num_rows_total), self.world)
+        self.row_begin, self.row_end = self.bounds[self.rank], self.bounds[self.rank + 1]
+        if local_rows.size(0) != self.row_end - self.row_begin:
+            raise ValueError(f"rank {self.rank} must hold rows [{self.row_begin}, {self.row_end}): "
+                             f"{self.row_end - self.row_begin} rows, got {local_rows.size(0)}")
+        self.shard = local_rows
+        self._local_topk = local_topk or _default_local_topk
+        self._merge = merge or _default_merge
+        self._gather_s: Optional[torch.Tensor] = None
+        self._gather_i: Optional[torch.Tensor] = None
+
+    def topk(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Global top-k (scores [Q, k], global row ids [Q, k]) — identical on every rank."""
+        s, i = self._local_topk(queries, self.shard, k, self.row_begin)
+        if self.world == 1:
+            return s, i
+        Q = queries.size(0)
+        if self._gather_s is None or self._gather_s.shape != (self.world, Q, k) or self._gather_s.device != s.device:
+            self._gather_s = torch.empty((self.world, Q, k), dtype=torch.float32, device=s.device)
+            self._gather_i = torch.empty((self.world, Q, k), dtype=torch.int64, device=s.device)
+        # output = concatenation along dim 0 (the layout both RCCL and gloo accept)
+        dist.all_gather_into_tensor(self._gather_s.view(self.world * Q, k), s.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(self._gather_i.view(self.world * Q, k), i.contiguous(), group=self.group)
+        return self._merge(self._gather_s, self._gather_i)
+
+
+def all_reduce_sum_(values: Sequence[float], *, device: Optional[torch.device] = None, group=None) -> List[float]:
+    """One small all-reduce of f64 counters (metric states)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(values)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()
+
+
+__all__ = ["ShardedIndex", "shard_bounds", "shard_graphs", "all_reduce_sum_"]

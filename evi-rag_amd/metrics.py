@@ -137,7 +137,7 @@ def rank_batch(preds: torch.Tensor, target: Optional[torch.Tensor], batch: Any, 
         res.update(topk_index=torch.empty((B, k_max), dtype=torch.int32, device=dev),
                    topk_score=torch.empty((B, k_max), dtype=torch.float32, device=dev),
                    topk_count=torch.empty((B,), dtype=torch.int32, device=dev))
-    uf_ws = ops._workspace(dev, "metrics_uf", 4 * max(N, 1))
+    uf_ws = ops._workspace(dev, "metrics_uf", 8 * max(N, 1))
     karr = (ctypes.c_int32 * nk)(*ks)
     p = ops._ptr
     lib = _lib.load()

@@ -297,6 +297,7 @@ class Retriever(nn.Module):
             edge_batch, edge_ptr = compute_edge_batch(edge_index, node_ptr=node_ptr, num_graphs=B, device=dev)
             try:
                 batch.edge_batch = edge_batch  # the reference caches it on the batch too (:612)
+                batch.edge_ptr = edge_ptr      # (the loader attaches both: loader.py:98-99)
             except Exception:  # pragma: no cover - read-only batch objects
                 pass
         edge_batch, edge_ptr = i64(edge_batch).view(-1), i64(edge_ptr).view(-1)

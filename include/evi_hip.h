@@ -151,7 +151,7 @@ int evi_segment_topk(const float* scores, const int64_t* edge_ptr, int B, int k,
  *                              the ranked list itself (RetrieverTopKEdgeWriter._select_topk_edges,
  *                              src/callbacks/retriever_topk_edge_writer.py:294-320); each may be NULL
  * target [E] u8 = labels > 0.5 (NULL skips recall and margin); q_idx / a_idx are the batch-global
- * q_local_indices / a_local_indices with their [B+1] pointers; uf_workspace: [num_nodes] i32. */
+ * q_local_indices / a_local_indices with their [B+1] pointers; uf_workspace: [2 * num_nodes] i32. */
 int evi_retriever_metrics(
     const float* scores, const uint8_t* target, const int64_t* edge_index, int64_t E,
     const int64_t* edge_ptr, const int64_t* node_ptr, int B, const int64_t* q_idx, const int64_t* q_ptr,
@@ -169,7 +169,7 @@ int evi_retriever_metrics(
  * 1 = graph id out of range, 2 = head and tail in different graphs ("edge_index crosses graph
  * boundaries"), 4 = edge list not grouped by graph ("edge_batch is not non-decreasing").
  *   edge_index [2, E] i64; node_ptr [B+1] i64; edge_batch [E] i64; edge_ptr [B+1] i64;
- *   edge_count_ws [B] i32 scratch.
+ *   edge_count_ws: unused (kept for ABI stability; may be NULL).
  * Replaces compute_edge_batch, src/utils/graph_utils.py:50-104. */
 int evi_edge_batch(const int64_t* edge_index, int64_t E, const int64_t* node_ptr, int B,
                    int64_t* edge_batch, int64_t* edge_ptr, int32_t* edge_count_ws, int32_t* status,
