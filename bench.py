@@ -115,6 +115,26 @@ def cpu_baseline(shard, queries, k, n_total, cpu_rows, budget_s):
     return ob.time_cosine_topk(q, x, k, n_total=n_total, budget_s=budget_s)
 
 
+def pmc_traffic_gbs(N, D, Q, k, world, kernel_ms_per_step):
+    """HBM traffic of the scan kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), as GB/s at this run's kernel time;
+    null when no profile exists for this configuration (counters cannot be read inside the bench)."""
+    if world != 1 or kernel_ms_per_step <= 0:
+        return None
+    best = None
+    prof_dir = os.path.join(REPO_ROOT, "profiles")
+    for name in sorted(os.listdir(prof_dir)) if os.path.isdir(prof_dir) else []:
+        if name.endswith("_pmc_traffic.json"):
+            with open(os.path.join(prof_dir, name)) as fh:
+                p = json.load(fh)
+            c = p.get("config", {})
+            if (c.get("index_rows"), c.get("dim"), c.get("queries_per_step"), c.get("k")) == (N, D, Q, k):
+                best = p  # the latest round's file wins
+    if best is None:
+        return None
+    return best["hbm_bytes_per_step"] / (kernel_ms_per_step * 1e-3) / 1e9
+
+
 def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=4096, relations=4096):
     """Secondary leg (not part of `value`): the per-question subgraph scoring stage of the same
     evaluation — Retriever forward (DDE + edge scorer) and the fused ranking metrics on one
@@ -282,7 +302,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step),
                 "kernel": "k_cosine_score",
                 "algorithmic_bytes_per_step": bytes_per_step,
                 "launches_per_step": launches[0] / steps,
