@@ -121,18 +121,95 @@ __device__ inline void block_bitonic_sort_desc(SelectShared& sh, int n_pow2) {
     __syncthreads();
 }
 
+// Picks, on wave 0, the digit d (255..0) whose bucket holds the need-th largest matching key:
+// scalar[1] = d, scalar[2] = number of matching keys in buckets above d.  Call with all threads;
+// a barrier must precede (hist complete) and follow (scalars visible).
+__device__ inline void radix_pick_digit(SelectShared& sh, uint32_t need) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        // lane l owns digits 255-4l .. 252-4l (descending), 4 per lane
+        uint32_t c[4];
+        uint32_t local = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c[j] = sh.hist[255 - (4 * tid + j)];
+            local += c[j];
+        }
+        uint32_t incl = local;  // inclusive scan over lanes = keys in this lane's digits and above
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += up;
+        }
+        uint32_t before = incl - local;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (before < need && need <= before + c[j]) {
+                sh.scalar[1] = 255u - (uint32_t)(4 * tid + j);
+                sh.scalar[2] = before;
+            }
+            before += c[j];
+        }
+    }
+}
+
+// Sorts 1024 keys, one per thread of a 1024-thread block, descending; returns this thread's key of
+// the sorted sequence (position tid).  Strides below 64 exchange through wave shuffles, strides
+// >= 64 through `xchg` (2 x 1024 keys of LDS, double-buffered: one barrier per LDS stage).
+__device__ inline uint64_t block_sort1024_desc(uint64_t key, uint64_t* xchg) {
+    const int tid = threadIdx.x;
+    int buf = 0;
+    for (int size = 2; size <= 1024; size <<= 1) {
+        const bool desc = (tid & size) == 0;
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            uint64_t other;
+            if (stride < 64) {
+                const uint32_t lo = __shfl_xor((uint32_t)key, stride, 64);
+                const uint32_t hi = __shfl_xor((uint32_t)(key >> 32), stride, 64);
+                other = ((uint64_t)hi << 32) | lo;
+            } else {
+                uint64_t* b = xchg + buf * 1024;
+                b[tid] = key;
+                __syncthreads();
+                other = b[tid ^ stride];
+                buf ^= 1;
+            }
+            const bool lower = (tid & stride) == 0;  // this thread holds the lower position of the pair
+            const bool want_max = lower == desc;
+            const bool take = want_max ? (other > key) : (other < key);
+            if (take) key = other;
+        }
+    }
+    return key;
+}
+
 // Exact top-k of `cnt` distinct keys produced by load(i), i in [0, cnt).  On return
 // sh.keys[0..m) holds the m = min(cnt, k) largest keys in descending order (visible to all
 // threads).  k <= EVI_TOPK_MAX_K <= kSortCap.  Keys equal to 0 are padding and sort last.
+// Requires blockDim.x == kSelectThreads (1024).
 //
-// cnt <= kSortCap: one bitonic sort in LDS.  Otherwise an MSB-first 8-bit radix select narrows
-// the keys to the k-th largest key's bucket until the survivors fit in LDS, then sorts those.
+// An MSB-first 8-bit radix select first narrows the list to the k-th key's bucket plus everything
+// above it, until the survivors fit the sorter: 1024 keys (one per thread, shuffle/LDS hybrid
+// bitonic, ~10 barriers) when k <= 1024, else 8192 keys (LDS bitonic).
 template <class Load>
 __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    constexpr int kFast = 1024;
     if (cnt <= 0) return 0;
-    if (cnt <= kSortCap) {
-        int p2 = next_pow2((int)cnt);
+    int got;
+    if (cnt <= kFast) {
+        got = (int)cnt;
+        const uint64_t key = tid < cnt ? load(tid) : 0ull;
+        __syncthreads();  // callers may still be reading sh.keys from a previous use
+        const uint64_t sorted = block_sort1024_desc(key, sh.keys);
+        __syncthreads();
+        sh.keys[tid] = sorted;
+        __syncthreads();
+        return got < k ? got : k;
+    }
+    const uint32_t limit = k <= kFast ? kFast : kSortCap;
+    if (cnt <= (int64_t)limit) {  // only reachable with limit == kSortCap
+        const int p2 = next_pow2((int)cnt);
         for (int i = tid; i < p2; i += nt) sh.keys[i] = (i < cnt) ? load(i) : 0ull;
         block_bitonic_sort_desc(sh, p2);
         return (int)(cnt < k ? cnt : k);
@@ -141,26 +218,17 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
     // and the k-th largest key matches (prefix, mask).
     uint64_t prefix = 0, mask = 0;
     uint32_t above = 0;
+    got = 0;
     for (int pass = 7; pass >= 0; --pass) {
         const int shift = pass * 8;
         for (int i = tid; i < 256; i += nt) sh.hist[i] = 0;
         __syncthreads();
         for (int64_t i = tid; i < cnt; i += nt) {
-            uint64_t key = load(i);
+            const uint64_t key = load(i);
             if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFF], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t need = (uint32_t)k - above;  // rank of the k-th key inside the matching set
-            uint32_t acc = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (acc + sh.hist[d] >= need) break;
-                acc += sh.hist[d];
-            }
-            sh.scalar[1] = (uint32_t)d;
-            sh.scalar[2] = acc;
-        }
+        radix_pick_digit(sh, (uint32_t)k - above);
         __syncthreads();
         const uint32_t d = sh.scalar[1];
         const uint32_t in_bucket = sh.hist[d];
@@ -169,26 +237,35 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
         mask |= 0xFFull << shift;
         __syncthreads();
         // Survivors = keys above the bucket + keys in the bucket. If they fit, sort them.
-        if (above + in_bucket <= (uint32_t)kSortCap || pass == 0) {
+        if (above + in_bucket <= limit || pass == 0) {
             if (tid == 0) sh.scalar[0] = 0;
             __syncthreads();
             for (int64_t i = tid; i < cnt; i += nt) {
-                uint64_t key = load(i);
+                const uint64_t key = load(i);
                 if ((key & mask) >= prefix) {
-                    uint32_t pos = atomicAdd(&sh.scalar[0], 1u);
+                    const uint32_t pos = atomicAdd(&sh.scalar[0], 1u);
                     if (pos < (uint32_t)kSortCap) sh.keys[pos] = key;
                 }
             }
             __syncthreads();
-            int got = (int)sh.scalar[0];
+            got = (int)sh.scalar[0];
             if (got > kSortCap) got = kSortCap;  // unreachable for distinct keys
-            int p2 = next_pow2(got);
-            for (int i = got + tid; i < p2; i += nt) sh.keys[i] = 0ull;
-            block_bitonic_sort_desc(sh, p2);
-            return got < k ? got : k;
+            break;
         }
     }
-    return 0;  // unreachable
+    if (got <= kFast) {
+        const uint64_t key = tid < got ? sh.keys[tid] : 0ull;
+        __syncthreads();
+        const uint64_t sorted = block_sort1024_desc(key, sh.keys + kFast);  // exchange area beyond the survivors
+        __syncthreads();
+        sh.keys[tid] = sorted;
+        __syncthreads();
+    } else {
+        const int p2 = next_pow2(got);
+        for (int i = got + tid; i < p2; i += nt) sh.keys[i] = 0ull;
+        block_bitonic_sort_desc(sh, p2);
+    }
+    return got < k ? got : k;
 }
 
 // The k-th largest of `cnt` distinct keys (1 <= k <= cnt), by 8 MSB-first radix passes; no limit on

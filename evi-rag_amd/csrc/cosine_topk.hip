@@ -107,40 +107,69 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
         return *p;
     };
 
-    for (int64_t t = (int64_t)blockIdx.x * WAVES + wave; t < tiles; t += (int64_t)gridDim.x * WAVES) {
-        const int64_t row = seg_begin + t * 16 + n;
-        const int64_t rowc = row < seg_end ? row : seg_end - 1;
-        const f32x4* xp = reinterpret_cast<const f32x4*>(idx + rowc * (int64_t)D) + g;
+    // The wave's work is ONE stream of load groups (U float4 per lane each) that runs across tile
+    // boundaries: while group i is multiplied, group i+1 — possibly the first group of the wave's
+    // next tile — is already in flight, in a second register set (ping-pong, no copies).  Every
+    // iteration therefore has the same number of loads outstanding, so the compiler's counted
+    // vmcnt waits release exactly the group that is needed and never drain the prefetch.
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    auto tile_ptr = [&](int64_t t) -> const f32x4* {
+        const int64_t r = seg_begin + t * 16 + n;
+        const int64_t rc = r < seg_end ? r : seg_end - 1;
+        return reinterpret_cast<const f32x4*>(idx + rc * (int64_t)D) + g;
+    };
+    auto load_group = [&](f32x4 (&x)[U], const f32x4* xp, int gi) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = ldx(xp + (gi * U + u) * 4);
+    };
+    f32x4 acc[NQB];
+    auto mul_group = [&](const f32x4 (&x)[U], int gi) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = gi * U + u;
+            float4 a[NQB];
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) a[b] = lq[(j * 4) * NQ + b * 16];
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) {
+                const float ab[4] = {a[b].x, a[b].y, a[b].z, a[b].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[e], x[u][e], acc[b], 0, 0, 0);
+            }
+        }
+    };
 
-        f32x4 acc[NQB];
+    int64_t t = (int64_t)blockIdx.x * WAVES + wave;
+    const f32x4* xp = tile_ptr(t < tiles ? t : 0);
+    f32x4 xa[U], xb[U];
+    if (t < tiles) load_group(xa, xp, 0);
+    for (; t < tiles; t += stride) {
+        const int64_t tn = t + stride;
+        const f32x4* xpn = tile_ptr(tn < tiles ? tn : t);  // past the end: a harmless re-read
+        const int64_t row = seg_begin + t * 16 + n;
 #pragma unroll
         for (int b = 0; b < NQB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        f32x4 xcur[U], xnext[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) xcur[u] = ldx(xp + u * 4);
-        for (int gi = 0; gi < groups; ++gi) {
-            if (gi + 1 < groups) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) xnext[u] = ldx(xp + ((gi + 1) * U + u) * 4);
+        if ((groups & 1) == 0) {
+            for (int gi = 0; gi < groups; gi += 2) {
+                load_group(xb, xp, gi + 1);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs it overlaps
+                mul_group(xa, gi);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gi + 2 < groups) load_group(xa, xp, gi + 2); else load_group(xa, xpn, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mul_group(xb, gi + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {  // odd group count: same stream, with a register copy per group
+            for (int gi = 0; gi < groups; ++gi) {
+                if (gi + 1 < groups) load_group(xb, xp, gi + 1); else load_group(xb, xpn, 0);
+                mul_group(xa, gi);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = gi * U + u;
-                float4 a[NQB];
-#pragma unroll
-                for (int b = 0; b < NQB; ++b) a[b] = lq[(j * 4) * NQ + b * 16];
-#pragma unroll
-                for (int b = 0; b < NQB; ++b) {
-                    const float ab[4] = {a[b].x, a[b].y, a[b].z, a[b].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[e], xcur[u][e], acc[b], 0, 0, 0);
-                }
+                for (int u = 0; u < U; ++u) xa[u] = xb[u];
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) xcur[u] = xnext[u];
         }
+        xp = xpn;
 
         if (row < seg_end) {
             const float scale = row_scale ? row_scale[row] : 1.0f;
@@ -383,8 +412,14 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
 
     const int chunks = D / 16;
     const ScanVariant variant = scan_variant();
-    int U = (chunks % 8 == 0) ? 8 : (chunks % 4 == 0) ? 4 : (chunks % 2 == 0) ? 2 : 1;
-    while (U > variant.u_cap && U > 1) U >>= 1;
+    // loads in flight per lane per group: the largest U <= cap that leaves an EVEN number of groups
+    // (copy-free ping-pong), else the largest U that divides the row.
+    int U = 1;
+    for (int cand = 8; cand >= 1; cand >>= 1)
+        if (cand <= variant.u_cap && chunks % (2 * cand) == 0) { U = cand; break; }
+    if (U == 1 && chunks % 2 != 0)
+        for (int cand = 8; cand >= 1; cand >>= 1)
+            if (cand <= variant.u_cap && chunks % cand == 0) { U = cand; break; }
     const int cus = device_cu_count();
     const int waves_per_block = variant.threads == 1024 ? 16 : 8;
 
