@@ -199,6 +199,58 @@ def shortest_path_union_mask_by_pair(num_nodes: int, edge_src: Sequence[int], ed
     return mask.tolist(), ps, pa, pe, pc, pl
 
 
+# ---- C2-C4: canonical edge selection --------------------------------------------------------------------
+
+def canonicalize_positive_edges(edge_src: Sequence[int], edge_dst: Sequence[int], edge_relation_ids: Sequence[int],
+                                positive_mask: Sequence[bool], pair_edge_local_ids: Sequence[int],
+                                pair_edge_counts: Sequence[int], question_embedding_norm: torch.Tensor,
+                                relation_embeddings_norm: torch.Tensor):
+    """Among parallel positive edges of the same unordered node pair keep the one whose relation is
+    most cosine-similar to the question (first maximum in (relation_id, idx) order); returns
+    (keep_mask, new_pair_edge_local_ids, new_pair_edge_counts).
+    reference: _group_positive_edges_by_pair / _select_canonical_edge_indices / _filter_pair_edges /
+    _canonicalize_graph_edges, scripts/build_retrieval_pipeline.py:840-932.  The relation scores are
+    one device GEMV over the normalised relation table (`torch.mv` at :871 for every group at once);
+    the grouping is the reference's own host logic."""
+    n = len(edge_src)
+    if n == 0 or not any(positive_mask):
+        return list(positive_mask), list(pair_edge_local_ids), list(pair_edge_counts)
+    if question_embedding_norm.numel() == 0:
+        raise ValueError("question_embedding is empty")
+    if relation_embeddings_norm.numel() == 0:
+        raise ValueError("relation_embeddings are empty; cannot canonicalize positives.")
+    if relation_embeddings_norm.dim() != 2 or question_embedding_norm.dim() != 1:
+        raise ValueError("Embeddings must be 2D (relations) and 1D (question) for canonicalization.")
+    if int(relation_embeddings_norm.size(1)) != int(question_embedding_norm.numel()):
+        raise ValueError("Question embedding dim does not match relation embedding dim.")
+    groups = {}
+    for idx, keep in enumerate(positive_mask):
+        if not keep:
+            continue
+        u, v = int(edge_src[idx]), int(edge_dst[idx])
+        groups.setdefault((u, v) if u <= v else (v, u), []).append(idx)
+    rel_scores = ops.linear_act(relation_embeddings_norm, question_embedding_norm.view(1, -1), None).view(-1).cpu()
+    keep_mask = [False] * n
+    for members in groups.values():
+        if len(members) == 1:
+            keep_mask[members[0]] = True
+            continue
+        ordered = sorted(members, key=lambda i: (int(edge_relation_ids[i]), i))
+        s = rel_scores[torch.tensor([int(edge_relation_ids[i]) for i in ordered], dtype=torch.long)]
+        keep_mask[ordered[int(torch.argmax(s).item())]] = True
+    if not pair_edge_local_ids or not pair_edge_counts:
+        return keep_mask, list(pair_edge_local_ids), list(pair_edge_counts)
+    new_ids, new_counts, off = [], [], 0
+    for c in pair_edge_counts:
+        kept = [i for i in pair_edge_local_ids[off: off + c] if keep_mask[int(i)]]
+        new_ids.extend(kept)
+        new_counts.append(len(kept))
+        off += c
+    if off != len(pair_edge_local_ids):
+        raise ValueError("pair_edge_counts do not sum to len(pair_edge_local_ids)")
+    return keep_mask, new_ids, new_counts
+
+
 # ---- GAgentBuilder statics ---------------------------------------------------------------------------
 
 def node_softmax_logit(*, edge_scores: torch.Tensor, edge_head_locals: torch.Tensor, edge_tail_locals: torch.Tensor,
@@ -288,6 +340,6 @@ def seed_onehop_stats(heads: torch.Tensor, tails: torch.Tensor, labels: torch.Te
     return [(int(s), int(d), int(p)) for s, d, p in zip(uniq.tolist(), deg.tolist(), pdeg.tolist()) if d >= 0]
 
 
-__all__ = ["GraphBatch", "bfs_dist", "bfs_dist_batch", "shortest_path_union_mask_by_pair",
+__all__ = ["GraphBatch", "canonicalize_positive_edges", "bfs_dist", "bfs_dist_batch", "shortest_path_union_mask_by_pair",
            "shortest_path_union_mask_by_pair_batch", "node_softmax_logit", "select_topk_edges", "select_start_edges",
            "seed_onehop_stats"]

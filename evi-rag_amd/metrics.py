@@ -304,11 +304,149 @@ class ScoreMargin(_SumMetric):
         return {"edge/score_margin": torch.tensor(self._states["margin_sum"] / denom, dtype=torch.float32)}
 
 
+def _bridge_sublists(preds, target, batch, num_graphs, indexes):
+    """Scores / labels / edge_ptr restricted to bridge edges (touching neither a seed nor an answer),
+    per graph, in the original order.  reference: _compute_bridge_mask,
+    src/metrics/retriever_metrics.py:66-80."""
+    scores = preds.detach().reshape(-1)
+    dev = ops._require_gpu(scores)
+    edge_index = torch.as_tensor(_attr(batch, "edge_index")).to(device=dev, dtype=torch.long).contiguous()
+    num_nodes = _attr(batch, "num_nodes")
+    if num_nodes is None:
+        raise ValueError("Batch missing num_nodes required for bridge metrics.")
+    q, a = _attr(batch, "q_local_indices"), _attr(batch, "a_local_indices")
+    if q is None or a is None:
+        raise ValueError("Batch missing q_local_indices/a_local_indices required for bridge metrics.")
+    near = ops.qa_edge_mask(edge_index, int(num_nodes), torch.as_tensor(q), torch.as_tensor(a))
+    bridge = ~near
+    if bridge.numel() != scores.numel():
+        raise ValueError(f"bridge_mask length mismatch: {bridge.numel()} vs scores {scores.numel()}")
+    node_ptr = torch.as_tensor(_attr(batch, "ptr")).to(device=dev, dtype=torch.long)
+    B = int(num_graphs) if num_graphs is not None else int(node_ptr.numel() - 1)
+    ids = indexes if indexes is not None else _attr(batch, "edge_batch")
+    if ids is None:
+        ids, _, _ = ops.edge_batch(edge_index, node_ptr)
+    ids = torch.as_tensor(ids).to(device=dev, dtype=torch.long).view(-1)
+    tgt = target.detach().reshape(-1).to(dev)
+    tgt = (tgt > 0.5) if tgt.dtype != torch.bool else tgt
+    counts = torch.bincount(ids[bridge], minlength=B)
+    edge_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+    full_counts = torch.bincount(ids, minlength=B)
+    full_ptr = torch.cat([full_counts.new_zeros(1), full_counts.cumsum(0)])
+    return scores[bridge].contiguous(), tgt[bridge].contiguous(), edge_ptr, bridge, tgt, full_ptr, B
+
+
+def _class_stats(scores, target_u8, edge_ptr, B):
+    dev = scores.device
+    out = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    if B > 0:
+        lib = _lib.load()
+        _lib.check(lib.evi_graph_class_stats(ops._ptr(scores), ops._ptr(target_u8), ops._ptr(edge_ptr.contiguous()), B,
+                                             ops._ptr(out), ops._stream(dev)))
+    return out
+
+
+class BridgeEdgeRecallAtK(_SumMetric):
+    """Edge recall@k over bridge edges only, averaged over graphs with a bridge positive.
+    reference: BridgeEdgeRecallAtK, src/metrics/retriever_metrics.py:169-267."""
+
+    def __init__(self, k_values: Optional[Sequence[int]] = None, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.k_values = normalize_k_values(k_values)
+        for k in self.k_values:
+            self._add_state(f"recall_sum_at_{k}")
+        self._add_state("graph_count")
+
+    def update(self, preds, target, indexes, batch, num_graphs: Optional[int] = None, **_: Any) -> None:
+        if not self.k_values or preds.numel() == 0:
+            return
+        s, t, eptr, _, _, _, B = _bridge_sublists(preds, target, batch, num_graphs, indexes)
+        if s.numel() == 0:
+            return
+        # rank the bridge sub-lists; reachability / answer inputs are irrelevant here
+        dev = s.device
+        zero_ptr = torch.zeros(B + 1, dtype=torch.long, device=dev)
+        fake = dict(edge_index=torch.zeros((2, s.numel()), dtype=torch.long, device=dev), ptr=_attr(batch, "ptr"), edge_ptr=eptr,
+                    q_local_indices=torch.zeros(0, dtype=torch.long, device=dev), q_local_indices_ptr=zero_ptr,
+                    a_local_indices=torch.zeros(0, dtype=torch.long, device=dev), a_local_indices_ptr=zero_ptr)
+        rb = rank_batch(s, t, fake, self.k_values, num_graphs=B)
+        stats = _class_stats(s, t.to(torch.uint8), eptr, B)
+        valid = (stats[:, 0] > 0) & rb.recall_valid.bool()  # graphs without a bridge positive are skipped (:239-241)
+        self._states["graph_count"] += float(valid.sum().item())
+        sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0).tolist()
+        for k in self.k_values:
+            self._states[f"recall_sum_at_{k}"] += sums[self._col(rb, k)]
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        denom = max(self._states["graph_count"], 1.0)
+        return {f"bridge/recall@{k}": torch.tensor(self._states[f"recall_sum_at_{k}"] / denom, dtype=torch.float32)
+                for k in self.k_values}
+
+
+class BridgePositiveCoverage(_SumMetric):
+    """reference: BridgePositiveCoverage, src/metrics/retriever_metrics.py:270-327."""
+
+    def __init__(self, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        for n in ("bridge_pos_edges", "total_pos_edges", "graphs_with_pos", "graphs_with_bridge_pos"):
+            self._add_state(n)
+
+    def update(self, preds, target, indexes, batch, num_graphs: Optional[int] = None, **_: Any) -> None:
+        if preds.numel() == 0:
+            return
+        s, t, eptr, bridge, tgt_all, full_ptr, B = _bridge_sublists(preds, target, batch, num_graphs, indexes)
+        all_stats = _class_stats(preds.detach().reshape(-1).float().contiguous(), tgt_all.to(torch.uint8).contiguous(), full_ptr, B)
+        br_stats = _class_stats(s, t.to(torch.uint8), eptr, B) if s.numel() else torch.zeros((B, 4), dtype=torch.float64, device=s.device)
+        self._states["total_pos_edges"] += float(all_stats[:, 0].sum().item())
+        self._states["bridge_pos_edges"] += float(br_stats[:, 0].sum().item())
+        has_pos = all_stats[:, 0] > 0
+        self._states["graphs_with_pos"] += float(has_pos.sum().item())
+        self._states["graphs_with_bridge_pos"] += float((has_pos & (br_stats[:, 0] > 0)).sum().item())
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        e = max(self._states["total_pos_edges"], 1.0)
+        g = max(self._states["graphs_with_pos"], 1.0)
+        return {"bridge/pos_edge_frac": torch.tensor(self._states["bridge_pos_edges"] / e, dtype=torch.float32),
+                "bridge/pos_graph_frac": torch.tensor(self._states["graphs_with_bridge_pos"] / g, dtype=torch.float32)}
+
+
+class BridgeProbQuality(_SumMetric):
+    """Mean sigmoid(score) of positive / negative bridge edges per graph having both.
+    reference: BridgeProbQuality, src/metrics/retriever_metrics.py:400-476."""
+
+    def __init__(self, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        for n in ("pos_prob_sum", "neg_prob_sum", "sep_sum", "graph_count"):
+            self._add_state(n)
+
+    def update(self, preds, target, indexes, batch, num_graphs: Optional[int] = None, **_: Any) -> None:
+        if preds.numel() == 0:
+            return
+        s, t, eptr, _, _, _, B = _bridge_sublists(preds, target, batch, num_graphs, indexes)
+        if s.numel() == 0:
+            return
+        st = _class_stats(s, t.to(torch.uint8), eptr, B)
+        valid = (st[:, 0] > 0) & (st[:, 1] > 0)
+        pos_mean = (st[:, 2] / st[:, 0].clamp(min=1.0)).float().double()  # per-graph means are f32 in the reference
+        neg_mean = (st[:, 3] / st[:, 1].clamp(min=1.0)).float().double()
+        self._states["pos_prob_sum"] += float((pos_mean * valid).sum().item())
+        self._states["neg_prob_sum"] += float((neg_mean * valid).sum().item())
+        self._states["sep_sum"] += float(((pos_mean - neg_mean) * valid).sum().item())
+        self._states["graph_count"] += float(valid.sum().item())
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        d = max(self._states["graph_count"], 1.0)
+        return {"bridge/pos_prob": torch.tensor(self._states["pos_prob_sum"] / d, dtype=torch.float32),
+                "bridge/neg_prob": torch.tensor(self._states["neg_prob_sum"] / d, dtype=torch.float32),
+                "bridge/separation": torch.tensor(self._states["sep_sum"] / d, dtype=torch.float32)}
+
+
 class RetrieverMetricCollection:
     """The metric set RetrieverModule builds (src/models/retriever_module.py:100-131), sharing one
     ranking pass per batch.  `update` takes the module's keyword set; `compute` merges the dicts."""
 
-    def __init__(self, k_values: Sequence[int], *, answer_hit: bool = True, prefix: str = "") -> None:
+    def __init__(self, k_values: Sequence[int], *, answer_hit: bool = True, bridge_metrics: bool = False,
+                 prefix: str = "") -> None:
         self.k_values = normalize_k_values(k_values)
         self.prefix = prefix
         self.metrics: Dict[str, _SumMetric] = {
@@ -318,6 +456,10 @@ class RetrieverMetricCollection:
         }
         if answer_hit:
             self.metrics["answer_hit"] = AnswerHitAtK(self.k_values)
+        if bridge_metrics:  # evaluation_cfg.bridge_metrics (configs/model/retriever_module.yaml:52-53)
+            self.metrics["bridge_recall"] = BridgeEdgeRecallAtK(self.k_values)
+            self.metrics["bridge_coverage"] = BridgePositiveCoverage()
+            self.metrics["bridge_quality"] = BridgeProbQuality()
 
     def update(self, *, preds, target, indexes, batch, query_ids=None, num_graphs=None, features=None, **_: Any) -> None:
         if preds.numel() == 0:
@@ -326,7 +468,7 @@ class RetrieverMetricCollection:
         for name, m in self.metrics.items():
             if name == "answer_hit" and not shared.have_answers:
                 continue
-            m._shared = shared
+            m._shared = None if name.startswith("bridge") else shared
             try:
                 m.update(preds=preds, target=target, indexes=indexes, batch=batch, query_ids=query_ids,
                          num_graphs=num_graphs)
@@ -349,4 +491,5 @@ class RetrieverMetricCollection:
 
 
 __all__ = ["normalize_k_values", "rank_batch", "RankedBatch", "EdgeRecallAtK", "AnswerReachability", "AnswerHitAtK",
-           "ScoreMargin", "RetrieverMetricCollection"]
+           "ScoreMargin", "BridgeEdgeRecallAtK", "BridgePositiveCoverage", "BridgeProbQuality",
+           "RetrieverMetricCollection"]

@@ -55,7 +55,7 @@ size_t evi_last_error(char* buf, size_t buf_bytes);
 
 /* Optional per-kernel timing for the bench's roofline leg.  While enabled, each call brackets its
  * dominant kernels with hipEvents on the call's stream (class 0: the cosine scan kernel,
- * class 1: top-k selection kernels).  evi_timing_read synchronises those events, writes the summed
+ * class 1: top-k selection kernels, class 2: scorer GEMMs, class 3: edge-feature kernel).  evi_timing_read synchronises those events, writes the summed
  * milliseconds and launch counts per class into HOST arrays of n_classes entries, and clears the
  * log.  Calls made while timing is enabled must not be captured into a hipGraph. */
 int evi_timing_enable(int on);
@@ -160,6 +160,22 @@ int evi_retriever_metrics(
     uint8_t* recall_valid, uint8_t* reach, uint8_t* reach_valid, uint8_t* answer_hit, float* answer_recall,
     uint8_t* answer_valid, float* score_margin, uint8_t* margin_valid, int32_t* topk_index,
     float* topk_score, int32_t* topk_count, int32_t* uf_workspace, void* stream);
+
+/* per graph: out[g, 0..3] = {positives, negatives, sum sigmoid(score) over positives, over negatives}
+ * (f64, deterministic).  Building block of BridgeProbQuality / BridgePositiveCoverage,
+ * src/metrics/retriever_metrics.py:270-327, 400-476 (applied to the bridge-edge sub-lists).
+ *   scores [E] f32, target [E] u8, edge_ptr [B+1] i64, out [B, 4] f64. */
+int evi_graph_class_stats(const float* scores, const uint8_t* target, const int64_t* edge_ptr, int B,
+                          double* out, void* stream);
+
+/* ---- D1: embedding feed ---------------------------------------------------------------------- */
+
+/* out[i, :] = table[ids[i], :] from an HBM-resident table (status bit 1 = an id outside
+ * [0, num_rows); that row is zero-filled).  Replaces the CPU index_select + pinned-buffer H2D copy of
+ * GlobalEmbeddingStore.get_entity_embeddings / get_relation_embeddings,
+ * src/data/components/embedding_store.py:101-150. */
+int evi_gather_rows(const float* table, int64_t num_rows, int D, const int64_t* ids, int64_t n,
+                    float* out, int32_t* status, void* stream);
 
 /* ---- G11: edge -> graph assignment and the Q/A "near" mask --------------------------------- */
 

@@ -179,3 +179,37 @@ def test_text_encoder_mirror_end_to_end(dev, tmp_path):
     assert torch.equal(torch.load(out), tensor) and torch.all(tensor[0] == 0)
     with pytest.raises(ValueError, match="same length"):
         T.encode_to_memmap(enc, texts, [1], 4, 12, out, None, False)
+
+
+def test_canonical_edge_selection_matches_reference_golden(dev):
+    """C2-C4: keep indices / filtered pair lists produced by the reference's own functions."""
+    from evi_rag_amd import labelling as L
+    from evi_rag_amd import ops
+
+    z = _load("cosine")
+    reln = ops.normalize_embeddings(torch.from_numpy(z["rel"]).to(dev), 1e-6)
+    qn = ops.normalize_embeddings(torch.from_numpy(z["q"]).to(dev), 1e-6)
+    mask, ids, counts = L.canonicalize_positive_edges(z["edge_src"], z["edge_dst"], z["edge_rel"], z["positive"].tolist(),
+                                                      z["pair_ids"].tolist(), z["pair_counts"].tolist(), qn, reln)
+    assert sorted(np.nonzero(mask)[0].tolist()) == sorted(z["keep_indices"].tolist())
+    assert ids == z["new_pair_ids"].tolist() and counts == z["new_pair_counts"].tolist()
+
+
+def test_embedding_store_gather(dev):
+    """D1: device gather == index_select; out-of-range ids raise like index_select."""
+    from evi_rag_amd.embedding_store import GlobalEmbeddingStore
+
+    g = torch.Generator().manual_seed(0)
+    ent, rel = torch.randn((1000, 96), generator=g), torch.randn((37, 96), generator=g)
+    store = GlobalEmbeddingStore.from_tensors(ent, rel, device=dev)
+    ids = torch.randint(0, 1000, (5000,), generator=g)
+    assert torch.equal(store.get_entity_embeddings(ids).cpu(), ent.index_select(0, ids))
+    rids = torch.randint(0, 37, (77,), generator=g)
+    assert torch.equal(store.get_relation_embeddings(rids.to(dev)).cpu(), rel.index_select(0, rids))
+    assert store.get_entity_embeddings(torch.empty(0, dtype=torch.long)).shape == (0, 96)
+    assert (store.entity_dim, store.relation_dim) == (96, 96)
+    with pytest.raises(IndexError):
+        store.get_relation_embeddings(torch.tensor([0, 37]))
+    b = types.SimpleNamespace(node_embedding_ids=ids[:10], edge_attr=rids[:20])
+    store.attach(b)
+    assert b.node_embeddings.shape == (10, 96) and b.edge_embeddings.shape == (20, 96) and b.num_relations == 37

@@ -133,3 +133,23 @@ def test_metrics_edge_cases(dev):
         import ctypes
         _lib.check(_lib.load().evi_retriever_metrics(*([None] * 3), 0, None, None, 1, *([None] * 7),
                                                      (ctypes.c_int32 * 2)(5, 5), 2, *([None] * 14)))
+
+
+@pytest.mark.parametrize("tag", ["toy", "mid"])
+def test_bridge_metrics_match_reference_golden(dev, tag):
+    """T5: BridgeEdgeRecallAtK / BridgePositiveCoverage / BridgeProbQuality values from the reference."""
+    from evi_rag_amd import metrics as M
+
+    z = np.load(os.path.join(GOLD, f"metrics_{tag}.npz"), allow_pickle=False)
+    ref = dict(zip(z["keys"].tolist(), z["values"].tolist()))
+    b = _batch_from(z, dev)
+    scores = torch.from_numpy(z["scores"]).to(dev)
+    target = b.labels > 0.5
+    coll = M.RetrieverMetricCollection(K_VALUES, bridge_metrics=True)
+    coll.update(preds=scores, target=target, indexes=None, batch=b, num_graphs=b.num_graphs)
+    got = {k: float(v) for k, v in coll.compute().items()}
+    bridge_keys = [k for k in ref if k.startswith("bridge/")]
+    assert len(bridge_keys) == len(K_VALUES) + 5
+    for k in bridge_keys:
+        assert got[k] == pytest.approx(ref[k], abs=2e-6), k
+    assert set(got) == set(ref)
