@@ -51,6 +51,11 @@ void timing_end(int token, hipStream_t st);
 int launch_gemm_nt(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                    const float* bias, int act, float* C, int64_t ldc, hipStream_t st);
 
+// Split-bf16 variant (gemm_bf16x3.hip); wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes.
+size_t gemm_bf16x3_workspace_bytes(int N, int K);
+int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st);
+
 // ---- ordered keys ---------------------------------------------------------------------------
 // A 64-bit key whose unsigned order is the ranking order used everywhere in this library:
 // larger score first, then smaller index first.  -0.0 ranks with +0.0; NaN ranks above +inf

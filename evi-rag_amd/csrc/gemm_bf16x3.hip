@@ -1,0 +1,229 @@
+// Split-bf16 ("bf16x3") GEMM for the scorer:  C[M,N] = act(A[M,K] * W[N,K]^T + bias), f32 in / f32 out.
+//
+// gfx950 has no TF32: an f32-input MFMA runs at 1/16 of the bf16 rate.  Each f32 operand is split
+// into two bf16 values, x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and the product is formed
+// as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation: three bf16 MFMAs
+// instead of sixteen f32-MFMA-equivalents.  The dropped lo*lo term and the rounding of lo are both
+// <= 2^-18 relative per product, so a length-K dot product is accurate to ~1e-5 of sum|a w| —
+// two decades inside the 1e-3 the scorer is allowed (and comparable to the TF32 the reference runs
+// with on CUDA, configs/extras/default.yaml:11).  evi_gemm_nt_f32 stays available as the exact path.
+//
+// 256 x 256 x 32 block tile, 8 waves (2 x 4), each wave 128 x 64 = eight 32x32 accumulators.
+// W is pre-split once per call into bf16 hi / lo planes (it is reused by every block); A is split
+// while it is staged global -> VGPR -> LDS.  LDS rows are 64 B (32 bf16); the four 16-byte chunks of
+// a row are XOR-swizzled with (row >> 2) & 3 so every ds_read_b128 lane group is conflict-free.
+#include "common.hpp"
+
+#include <hip/hip_bf16.h>
+
+namespace evi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XM = 256, XN = 256, XK = 32;
+constexpr int kXThreads = 512;
+
+__device__ inline float act3(float v, int act) {
+    if (act == 1) return tanhf(v);
+    if (act == 2) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+// 16-byte slot of chunk c (0..3) of row r in a [rows][32 bf16] tile
+__device__ inline int slot3(int r, int c) { return r * 4 + (c ^ ((r >> 2) & 3)); }
+
+// W [N, K] f32 (row stride ldw) -> hi / lo bf16 planes [N, Kp], zero padded to Kp
+__global__ void k_split_weight(const float* __restrict__ W, int N, int K, int64_t ldw, int Kp,
+                               __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    const float x = k < K ? W[(int64_t)n * ldw + k] : 0.f;
+    const __bf16 h = (__bf16)x;
+    hi[i] = h;
+    lo[i] = (__bf16)(x - (float)h);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
+    const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
+    const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
+    int64_t ldc) {
+    __shared__ uint4 sAhi[XM * 4], sAlo[XM * 4], sWhi[XN * 4], sWlo[XN * 4];  // 4 x 16 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nblocks_n = (N + XN - 1) / XN;
+    const int64_t m0 = (int64_t)(blockIdx.x / nblocks_n) * XM;
+    const int n0 = (int)(blockIdx.x % nblocks_n) * XN;
+
+    f32x4 ra[4];
+    uint4 rwh[2], rwl[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const uint4 zero16 = make_uint4(0u, 0u, 0u, 0u);
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // A: 2048 float4 chunks, 8 per row (128 B contiguous)
+            const int s = tid + kXThreads * i;
+            const int r = s >> 3, c4 = s & 7;
+            const int k = k0 + c4 * 4;
+            const int64_t am = m0 + r;
+            ra[i] = (am < M && k < K) ? *reinterpret_cast<const f32x4*>(A + am * lda + k) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // W planes: 1024 16-byte chunks each, 4 per row
+            const int s = tid + kXThreads * i;
+            const int r = s >> 2, c = s & 3;
+            const int wr = n0 + r;
+            if (wr < N) {
+                const int64_t off = (int64_t)wr * Kp + k0 + c * 8;
+                rwh[i] = *reinterpret_cast<const uint4*>(Whi + off);
+                rwl[i] = *reinterpret_cast<const uint4*>(Wlo + off);
+            } else {
+                rwh[i] = rwl[i] = zero16;
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = tid + kXThreads * i;
+            const int r = s >> 3, c4 = s & 7;
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (__bf16)ra[i][e];
+                l[e] = (__bf16)(ra[i][e] - (float)h[e]);
+            }
+            // 8-byte halves of the 16-byte chunk c = c4 >> 1
+            uint2* dh = reinterpret_cast<uint2*>(&sAhi[slot3(r, c4 >> 1)]) + (c4 & 1);
+            uint2* dl = reinterpret_cast<uint2*>(&sAlo[slot3(r, c4 >> 1)]) + (c4 & 1);
+            *dh = *reinterpret_cast<uint2*>(&h);
+            *dl = *reinterpret_cast<uint2*>(&l);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tid + kXThreads * i;
+            const int r = s >> 2, c = s & 3;
+            sWhi[slot3(r, c)] = rwh[i];
+            sWlo[slot3(r, c)] = rwl[i];
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += XK) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + XK < K) load_tiles(k0 + XK);
+#pragma unroll
+        for (int kk = 0; kk < XK; kk += 16) {
+            const int c = (kk >> 3) + fh;  // chunk holding k = kk + 8 h .. + 7
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + fr;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&sWhi[slot3(row, c)]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&sWlo[slot3(row, c)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 128 + i * 32 + fr;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAhi[slot3(row, c)]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAlo[slot3(row, c)]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m < M) C[m * ldc + n] = act3(acc[i][j][r] + bv, ACT);
+            }
+        }
+    }
+}
+
+size_t gemm_bf16x3_workspace_bytes(int N, int K) {
+    const int Kp = (K + XK - 1) / XK * XK;
+    return align_up((size_t)N * Kp * 2, 256) * 2;
+}
+
+// wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes of scratch for the split weight planes.
+int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
+    if (M == 0 || N == 0) return EVI_OK;
+    const int Kp = (K + XK - 1) / XK * XK;
+    __bf16* hi = static_cast<__bf16*>(wsplit);
+    __bf16* lo = reinterpret_cast<__bf16*>(static_cast<char*>(wsplit) + align_up((size_t)N * Kp * 2, 256));
+    const int64_t total = (int64_t)N * Kp;
+    hipLaunchKernelGGL(k_split_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, ldw, Kp, hi, lo);
+    EVI_LAUNCH_CHECK();
+    const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
+    const int tok = timing_begin(kTimeGemm, st);
+    switch (act) {
+        case 1:
+            hipLaunchKernelGGL(k_gemm_nt_bf16x3<1>, grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
+            break;
+        case 2:
+            hipLaunchKernelGGL(k_gemm_nt_bf16x3<2>, grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
+            break;
+        default:
+            hipLaunchKernelGGL(k_gemm_nt_bf16x3<0>, grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
+    }
+    timing_end(tok, st);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+}  // namespace evi
+
+using namespace evi;
+
+extern "C" size_t evi_gemm_nt_bf16x3_workspace_bytes(int N, int K) {
+    if (N <= 0 || K <= 0) return 0;
+    return gemm_bf16x3_workspace_bytes(N, K);
+}
+
+extern "C" int evi_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                                  const float* bias, int act, float* C, int64_t ldc, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    EVI_REQUIRE(M >= 0 && N >= 0 && K >= 1, "evi_gemm_nt_bf16x3: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    EVI_REQUIRE(K % 4 == 0 && lda % 4 == 0, "evi_gemm_nt_bf16x3: K and lda must be multiples of 4, got K=%d lda=%lld", K,
+                (long long)lda);
+    EVI_REQUIRE(lda >= K && ldw >= K && ldc >= N, "evi_gemm_nt_bf16x3: leading dimension smaller than the row");
+    EVI_REQUIRE(act >= 0 && act <= 2, "evi_gemm_nt_bf16x3: act must be 0 (none), 1 (tanh) or 2 (sigmoid)");
+    if (M == 0 || N == 0) return EVI_OK;
+    EVI_REQUIRE(A && W && C && workspace, "evi_gemm_nt_bf16x3: null pointer");
+    if (workspace_bytes < gemm_bf16x3_workspace_bytes(N, K))
+        return fail(EVI_ERR_NOMEM, "evi_gemm_nt_bf16x3: workspace %zu B < %zu B", workspace_bytes,
+                    gemm_bf16x3_workspace_bytes(N, K));
+    return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, workspace,
+                                 reinterpret_cast<hipStream_t>(stream));
+}

@@ -14,6 +14,8 @@
 // Bound: MFMA f32 (steps 1 and 4: 2*(2(3D+1)H + 2H^2) flops per edge); steps 2-3 are gathers.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace evi {
 
 constexpr int kEdgeChunk = 65536;
@@ -100,7 +102,7 @@ struct EdgeFeatArgs {
 };
 
 template <int DPL>
-__global__ __launch_bounds__(256) void k_edge_features(EdgeFeatArgs a) {
+__global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
     extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
     for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds_wt[i] = a.struct_wt[i];
@@ -295,6 +297,18 @@ __global__ __launch_bounds__(256) void k_score_combine(
     }
 }
 
+static bool use_f32_gemm() {
+    const char* v = getenv("EVI_SCORER_GEMM");
+    return v && v[0] == 'f';
+}
+
+// act(A W^T + b) on the split-bf16 GEMM (default) or the exact f32 GEMM (EVI_SCORER_GEMM=f32)
+static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                       const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
+    if (use_f32_gemm()) return launch_gemm_nt(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
+    return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st);
+}
+
 static int dpl_for(int d) {
     const int need = (d + 63) / 64;
     const int opts[] = {1, 2, 4, 8, 12, 16, 20};
@@ -316,7 +330,7 @@ static int dpl_for(int d) {
 
 struct FwdLayout {
     size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
-        in_eid, out_ptr, out_nbr, out_eid, csr_ws, w1p, wt, X, h1, feats, total;
+        in_eid, out_ptr, out_nbr, out_eid, csr_ws, w1p, wt, wsplit, X, h1, feats, total;
     int64_t ec;
     int Kp;
     int dedupe;
@@ -353,6 +367,7 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.csr_ws = take((size_t)(N > 0 ? N : 1) * 8);
     L.w1p = take((size_t)H * L.Kp * f);
     L.wt = take((size_t)F * D * f);
+    L.wsplit = take(gemm_bf16x3_workspace_bytes(H > D ? H : D, L.Kp > H ? L.Kp : H));
     L.X = take((size_t)dirs * L.ec * L.Kp * f);
     L.h1 = take((size_t)dirs * L.ec * H * f);
     L.feats = take((size_t)dirs * L.ec * H * f);
@@ -423,17 +438,18 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     float* bias_q = F32(L.bias_q);
     float* rel_repr = F32(L.rel_repr);
     float* ns = out->node_struct ? out->node_struct : F32(L.ns);
+    void* wsplit = base + L.wsplit;
     int rc;
 
     // 1. projections
-    if ((rc = launch_gemm_nt(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, st))) return rc;
-    if ((rc = launch_gemm_nt(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, st))) return rc;
+    if ((rc = scorer_gemm(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, wsplit, st))) return rc;
+    if ((rc = scorer_gemm(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, wsplit, st))) return rc;
     hipLaunchKernelGGL(k_overwrite_non_text, dim3((unsigned)N), dim3(256), 0, st, node_repr, b->node_embedding_ids,
                        non_text, N, D);
     EVI_LAUNCH_CHECK();
-    if ((rc = launch_gemm_nt(b->question_emb, B, D, D, w->query_w, D, D, w->query_b, 1, q_proj, D, st))) return rc;
-    if ((rc = launch_gemm_nt(q_proj, B, D, D, w->q_gate_w, D, D, w->q_gate_b, 2, gate_q, D, st))) return rc;
-    if ((rc = launch_gemm_nt(q_proj, B, D, D, w->q_bias_w, D, D, w->q_bias_b, 1, bias_q, D, st))) return rc;
+    if ((rc = scorer_gemm(b->question_emb, B, D, D, w->query_w, D, D, w->query_b, 1, q_proj, D, wsplit, st))) return rc;
+    if ((rc = scorer_gemm(q_proj, B, D, D, w->q_gate_w, D, D, w->q_gate_b, 2, gate_q, D, wsplit, st))) return rc;
+    if ((rc = scorer_gemm(q_proj, B, D, D, w->q_bias_w, D, D, w->q_bias_b, 1, bias_q, D, wsplit, st))) return rc;
     if (L.dedupe) {
         const int64_t R = b->num_relations;
         int32_t* first = I32(L.rel_first);
@@ -445,9 +461,9 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         hipLaunchKernelGGL(k_gather_relation_rows, dim3((unsigned)R), dim3(256), 0, st, b->edge_embeddings, first, D,
                            F32(L.rel_rows));
         EVI_LAUNCH_CHECK();
-        if ((rc = launch_gemm_nt(F32(L.rel_rows), R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.rel_rows), R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st))) return rc;
     } else {
-        if ((rc = launch_gemm_nt(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, st))) return rc;
+        if ((rc = scorer_gemm(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st))) return rc;
     }
 
     // 2. structure features
@@ -493,8 +509,8 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         a.dir_fwd = dir_fwd;
         a.dir_bwd = dir_bwd;
         a.X = F32(L.X);
-        int64_t blocks = (ec + 3) / 4;
-        if (blocks > 2048) blocks = 2048;
+        int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
+        if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS: 32 waves per CU hide the gather latency
         const int tok = timing_begin(kTimeEdge, st);
         EVI_DPL_DISPATCH(dpl_d, {
             static thread_local bool attr = false;
@@ -503,16 +519,16 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr = true;
             }
-            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(256), feat_lds, st, a);
+            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
         const int64_t M = (int64_t)dirs * ec;
-        if ((rc = launch_gemm_nt(F32(L.X), M, L.Kp, L.Kp, F32(L.w1p), H, L.Kp, w->state0_b, 0, F32(L.h1), H, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.X), M, L.Kp, L.Kp, F32(L.w1p), H, L.Kp, w->state0_b, 0, F32(L.h1), H, wsplit, st))) return rc;
         EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_layernorm_gelu<DPL>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st,
                                                    F32(L.h1), M, H, w->state_ln_w, w->state_ln_b));
         EVI_LAUNCH_CHECK();
-        if ((rc = launch_gemm_nt(F32(L.h1), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.h1), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st))) return rc;
         EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_score_combine<DPL>, dim3((unsigned)((ec + 3) / 4)), dim3(256), 0, st,
                                                    F32(L.feats), e0, ec, H, dir_fwd, dir_bwd, w->score_w, w->score_b,
                                                    out->logits, out->logits_fwd, out->logits_bwd, out->edge_features));

@@ -308,6 +308,18 @@ int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_to
 int evi_gemm_nt_f32(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                     const float* bias, int act, float* C, int64_t ldc, void* stream);
 
+/* Same contract as evi_gemm_nt_f32 at ~5x the speed: every f32 operand is split into two bf16
+ * values (x = hi + lo) and the product formed as hi*hi + hi*lo + lo*hi on bf16 MFMA with f32
+ * accumulation (gfx950 has no TF32; an f32-input MFMA runs at 1/16 of the bf16 rate).  Per-product
+ * relative error <= ~2^-17, i.e. results agree with the exact f32 path to ~1e-5 of sum|a*w| — the
+ * precision class of the TF32 matmuls the reference runs with on CUDA
+ * (torch.set_float32_matmul_precision("high"), configs/extras/default.yaml:11).
+ * workspace: evi_gemm_nt_bf16x3_workspace_bytes(N, K) for the split weight planes. */
+size_t evi_gemm_nt_bf16x3_workspace_bytes(int N, int K);
+int evi_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                       const float* bias, int act, float* C, int64_t ldc, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* Parameters of src.models.components.retriever.Retriever as device pointers, in state_dict
  * order (every tensor f32, row-major, exactly the checkpoint's shapes). */
 typedef struct EviRetrieverWeights {
@@ -375,7 +387,9 @@ typedef struct EviRetrieverOutput {
 
 /* Eval-mode Retriever._forward_impl (src/models/components/retriever.py:195-289): dropout is the
  * identity, the hide-and-seek bias is off (apply_in_eval: false,
- * configs/model/retriever_module.yaml:25).  direction_mode: 0 bidirectional, 1 forward, 2 backward. */
+ * configs/model/retriever_module.yaml:25).  direction_mode: 0 bidirectional, 1 forward, 2 backward.
+ * Dense contractions run on the split-bf16 GEMM (evi_gemm_nt_bf16x3) unless the environment
+ * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM. */
 size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                              int dde_reverse_rounds, int64_t num_relations);
 int evi_retriever_forward(const EviRetrieverWeights* weights, const EviRetrieverBatch* batch,

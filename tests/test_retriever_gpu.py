@@ -59,6 +59,35 @@ def test_gemm_matches_torch_fp32(dev, M, K, N, act):
     torch.testing.assert_close(got, ref, rtol=0, atol=3e-6 * max(1.0, K / 256))
 
 
+@pytest.mark.parametrize("M,K,N,act", [(1, 32, 32, "tanh"), (300, 768, 768, "sigmoid"), (1000, 2308, 768, None),
+                                        (257, 48, 300, "tanh"), (513, 36, 16, None)])
+def test_gemm_bf16x3_matches_fp32_reference(dev, M, K, N, act):
+    """Split-bf16 GEMM vs an fp64-accumulated fp32 reference: error ~1e-5 of sum|a w|, far inside 1e-3."""
+    from evi_rag_amd import ops
+
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((N, K), generator=g) / K ** 0.5
+    b = torch.randn((N,), generator=g)
+    got = ops.linear_act(x.to(dev), w.to(dev), b.to(dev), act, mode="bf16x3").cpu()
+    ref = (x.double() @ w.double().T + b.double())
+    ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda v: v}[act](ref).float()
+    torch.testing.assert_close(got, ref, rtol=0, atol=4e-5)
+    exact = ops.linear_act(x.to(dev), w.to(dev), b.to(dev), act, mode="f32").cpu()
+    assert float((got - exact).abs().max()) < 4e-5
+
+
+def test_retriever_forward_exact_f32_gemm_mode(dev, monkeypatch):
+    """EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM; both modes meet the reference golden."""
+    monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
+    z = _load("retriever_mid")
+    model = _model_from(z, dev)
+    with torch.no_grad():
+        out = model(_batch_from(z, dev))
+    np.testing.assert_allclose(out.logits.cpu().numpy(), z["logits"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), z["edge_embeddings"], rtol=0, atol=5e-5)
+
+
 def test_gemm_rejects_unaligned(dev):
     from evi_rag_amd import _lib
 
