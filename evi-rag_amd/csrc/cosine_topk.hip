@@ -31,9 +31,9 @@ namespace evi {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kQueryBlock = 32;               // queries per pass over the index
-constexpr int64_t kFirstSegment = 8192;       // dense segment (fits one LDS sort)
+constexpr int64_t kFirstSegment = 65536;      // dense segment: every score is written, no filter yet
 constexpr int kCntStride = 64;                // one append cursor per 256 B: no false sharing between queries
-constexpr int64_t kSegmentGrowth = 8;
+constexpr int64_t kSegmentGrowth = 16;
 constexpr int64_t kMaxSegmentDefault = 1 << 24;  // recommended workspace: 8 B x 32 x (min(N, 2^24) + k)
 
 // q [Q, D] -> qfrag[((j*4 + g) * (NQB*16) + i) * 4 + t] = q[i][16 j + 4 g + t], zero for i >= Q.

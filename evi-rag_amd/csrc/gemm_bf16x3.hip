@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
     int64_t ldc) {
-    __shared__ uint4 sAhi[XM * 4], sAlo[XM * 4], sWhi[XN * 4], sWlo[XN * 4];  // 4 x 16 KiB
+    __shared__ uint4 sAhi[2][XM * 4], sAlo[2][XM * 4], sWhi[2][XN * 4], sWlo[2][XN * 4];  // 2 stages x 4 x 16 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int s = tid + kXThreads * i;
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
                 l[e] = (__bf16)(ra[i][e] - (float)h[e]);
             }
             // 8-byte halves of the 16-byte chunk c = c4 >> 1
-            uint2* dh = reinterpret_cast<uint2*>(&sAhi[slot3(r, c4 >> 1)]) + (c4 & 1);
-            uint2* dl = reinterpret_cast<uint2*>(&sAlo[slot3(r, c4 >> 1)]) + (c4 & 1);
+            uint2* dh = reinterpret_cast<uint2*>(&sAhi[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
+            uint2* dl = reinterpret_cast<uint2*>(&sAlo[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
             *dh = *reinterpret_cast<uint2*>(&h);
             *dl = *reinterpret_cast<uint2*>(&l);
         }
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         for (int i = 0; i < 2; ++i) {
             const int s = tid + kXThreads * i;
             const int r = s >> 2, c = s & 3;
-            sWhi[slot3(r, c)] = rwh[i];
-            sWlo[slot3(r, c)] = rwl[i];
+            sWhi[buf][slot3(r, c)] = rwh[i];
+            sWlo[buf][slot3(r, c)] = rwl[i];
         }
     };
 
@@ -123,12 +123,16 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
+    // Two LDS stages: while stage `cur` is multiplied, the next tile (already in registers) is split
+    // and written to the other stage and the tile after it is fetched; one barrier per k-tile.
     load_tiles(0);
-    for (int k0 = 0; k0 < K; k0 += XK) {
-        __syncthreads();
-        store_tiles();
-        __syncthreads();
-        if (k0 + XK < K) load_tiles(k0 + XK);
+    store_tiles(0);
+    __syncthreads();
+    if (XK < K) load_tiles(XK);
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += XK, cur ^= 1) {
+        if (k0 + XK < K) store_tiles(cur ^ 1);
+        if (k0 + 2 * XK < K) load_tiles(k0 + 2 * XK);
 #pragma unroll
         for (int kk = 0; kk < XK; kk += 16) {
             const int c = (kk >> 3) + fh;  // chunk holding k = kk + 8 h .. + 7
@@ -136,14 +140,14 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + fr;
-                bh[j] = *reinterpret_cast<const bf16x8*>(&sWhi[slot3(row, c)]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&sWlo[slot3(row, c)]);
+                bh[j] = *reinterpret_cast<const bf16x8*>(&sWhi[cur][slot3(row, c)]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&sWlo[cur][slot3(row, c)]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 128 + i * 32 + fr;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAhi[slot3(row, c)]);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAlo[slot3(row, c)]);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAlo[cur][slot3(row, c)]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
                 }
             }
         }
+        __syncthreads();
     }
 
 #pragma unroll

@@ -56,9 +56,9 @@ def test_row_normalize_empty_passthrough(dev):
         (3, 7, 16, 10),          # N < k: padding
         (16, 300, 64, 500),      # one query block, k > N
         (17, 5000, 128, 50),     # two query blocks, ragged
-        (33, 9000, 768, 500),    # > 32 queries: two passes; > first dense segment
-        (32, 70000, 768, 500),   # several filtered segments
-        (8, 20000, 1024, 2048),  # max k, radix-select path in later segments
+        (33, 70000, 768, 500),   # > 32 queries: two passes; > first dense segment
+        (32, 300000, 768, 500),  # dense first segment + filtered segments
+        (8, 150000, 1024, 2048), # max k, radix-select path in later segments
         (5, 12345, 1280, 7),     # max D, N not a multiple of 16
         (4, 10000, 48, 64),      # D/16 odd (U = 1 path)
     ],
@@ -100,7 +100,7 @@ def test_cosine_topk_sorted_index_worst_case(dev):
     """Adversarial order: every later row beats every earlier one, so every row passes the filter."""
     from evi_rag_amd import ops
 
-    N, D, k = 50000, 64, 100
+    N, D, k = 200000, 64, 100
     base = np.zeros((N, D), dtype=np.float32)
     base[:, 0] = 1.0
     base[:, 1] = np.linspace(-1.0, 1.0, N, dtype=np.float32)  # cosine with e1 increases with row id
@@ -119,7 +119,7 @@ def test_cosine_topk_small_workspace_same_result(dev):
     """A minimum-size workspace only changes the segment schedule, never the result."""
     from evi_rag_amd import _lib, ops
 
-    N, D, Q, k = 40000, 384, 32, 300
+    N, D, Q, k = 250000, 384, 32, 300
     x = _make_index(N, D, seed=11)
     q = np.random.default_rng(12).standard_normal((Q, D), dtype=np.float32)
     xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
@@ -152,7 +152,7 @@ def test_sharded_topk_merge_equals_single_shard(dev):
     """Row-sharding invariance: per-shard top-k + merge == one-shard top-k, bit-exact."""
     from evi_rag_amd import ops
 
-    N, D, Q, k, P = 36000, 768, 32, 500, 4
+    N, D, Q, k, P = 300000, 768, 32, 500, 4
     x = _make_index(N, D, seed=21)
     q = np.random.default_rng(22).standard_normal((Q, D), dtype=np.float32)
     xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
