@@ -72,6 +72,12 @@ def _worker(rank, world, port, out_dir):
         m.sync()
         assert m._states["graph_count"] == 7.0 and m._states["recall_sum_at_1"] == float(sum(range(7)))
         assert edist.all_reduce_sum_([1.0, rank]) == [float(world), float(sum(range(world)))]
+        # ragged gather used by the top-k artifact writer: rank r contributes r + 2 rows
+        from evi_rag_amd.topk_writer import gather_padded
+
+        parts = gather_padded(torch.full((rank + 2, 3), float(rank)))
+        assert [tuple(p.shape) for p in parts] == [(r + 2, 3) for r in range(world)]
+        assert all(bool((p == r).all()) for r, p in enumerate(parts))
     finally:
         dist.destroy_process_group()
 
