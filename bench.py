@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--index-dtype", choices=["f32", "f16"], default="f32",
+                    help="storage dtype of the resident index (f16: BASELINE config 4 variant; the headline is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-eval", action="store_true")
     return ap.parse_args()
@@ -93,7 +95,7 @@ def build_queries(dev, shard, row_begin, row_end, n_total, n_batches, Q, D, seed
     mine = (gold >= row_begin) & (gold < row_end)
     if bool(mine.any()):
         local = (gold[mine] - row_begin).to(dev)
-        base[mine.to(dev)] = shard.index_select(0, local)
+        base[mine.to(dev)] = shard.index_select(0, local).float()
     if world > 1:
         dist.all_reduce(base, op=dist.ReduceOp.SUM)
     gen = torch.Generator(device=dev)
@@ -110,7 +112,7 @@ def cpu_baseline(shard, queries, k, n_total, cpu_rows, budget_s):
     from oracle import cpu_baseline as ob
 
     rows = int(min(cpu_rows, shard.shape[0]))
-    x = shard[:rows].cpu()
+    x = shard[:rows].float().cpu()
     q = queries[0].cpu()
     return ob.time_cosine_topk(q, x, k, n_total=n_total, budget_s=budget_s)
 
@@ -226,6 +228,11 @@ def main():
     row_begin = N * rank // world
     row_end = N * (rank + 1) // world
     shard = build_shard(dev, row_begin, row_end, D, args.seed)
+    elem_bytes = 4
+    if args.index_dtype == "f16":
+        shard = shard.to(torch.float16)
+        elem_bytes = 2
+        torch.cuda.empty_cache()
     n_batches = args.warmup + args.steps
     queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, args.seed, world)
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
@@ -275,7 +282,7 @@ def main():
     if rank == 0:
         steps = args.steps
         shard_rows = row_end - row_begin
-        bytes_per_step = shard_rows * D * 4 + Q * D * 4 + Q * k * 12
+        bytes_per_step = shard_rows * D * elem_bytes + Q * D * 4 + Q * k * 12
         score_ms_per_step = ms[0] / steps
         achieved = bytes_per_step / (score_ms_per_step * 1e-3) / 1e9 if score_ms_per_step > 0 else 0.0
         result = {
@@ -289,7 +296,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.index_dtype == "f32" else "f16 index x f32 queries (f16 MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k",
@@ -297,7 +304,7 @@ def main():
                 "dim": D,
                 "queries_per_step": Q,
                 "k": k,
-                "index_dtype": "f32",
+                "index_dtype": args.index_dtype,
                 "sharding": f"rows/{world}" if world > 1 else "none",
             },
             "roofline": {
@@ -306,7 +313,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step),
+                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step) if args.index_dtype == "f32" else None,
                 "kernel": "k_cosine_score",
                 "algorithmic_bytes_per_step": bytes_per_step,
                 "launches_per_step": launches[0] / steps,

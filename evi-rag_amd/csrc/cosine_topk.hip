@@ -49,6 +49,31 @@ __global__ void k_query_fragments(const float* __restrict__ q, int Q, int D, int
     }
 }
 
+// f16-index variant: per K-step J of 32 and lane group g, the A fragment of query i is 8 halves
+// q[i][32 J + 8 g .. + 7], stored twice: hi = f16(q) and lo = f16((q - hi) * 2048) (the scale keeps lo
+// out of the f16 subnormal range; the lo accumulator is rescaled by 2^-11 at the end).
+//   qfrag16[((J*4 + g)*2 + part) * nq_pad + i]  (16 bytes each), zero for i >= Q.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kLoScale = 2048.0f;
+__global__ void k_query_fragments_f16(const float* __restrict__ q, int Q, int D, int nq_pad,
+                                      f16x8* __restrict__ qfrag) {
+    const int total = (D / 32) * 4 * nq_pad;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        const int i = s % nq_pad;
+        const int jg = s / nq_pad;  // J*4 + g
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = i < Q ? q[(int64_t)i * D + jg * 8 + e] : 0.f;
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)((v - (float)h) * kLoScale);
+        }
+        qfrag[(jg * 2 + 0) * nq_pad + i] = hi;
+        qfrag[(jg * 2 + 1) * nq_pad + i] = lo;
+    }
+}
+
 __global__ void k_init_state(float* tau, int32_t* cnt, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -64,9 +89,11 @@ __global__ void k_init_state(float* tau, int32_t* cnt, int n) {
 // Appends are staged per workgroup in LDS (capq entries per query) and flushed once at the end
 // with one global atomic per query, so the per-query cursors see ~256 atomics per launch instead
 // of one per candidate; entries that do not fit go straight to the global list.
-template <int NQB, int U, int THREADS, int NT>
+//   F16: the index is stored as f16 (half the HBM bytes); queries are split hi + lo in f16 and
+//   multiplied on v_mfma_f32_16x16x32_f16 with f32 accumulation.
+template <int NQB, int U, int THREADS, int NT, int F16>
 __global__ __launch_bounds__(THREADS) void k_cosine_score(
-    const float* __restrict__ qfrag, const float* __restrict__ idx, int64_t seg_begin,
+    const float* __restrict__ qfrag, const void* __restrict__ idx, int64_t seg_begin,
     int64_t seg_end, int D, int Q, const float* __restrict__ row_scale,
     const float* __restrict__ tau, float* __restrict__ cand_score, int32_t* __restrict__ cand_id,
     int32_t* __restrict__ cand_cnt, int64_t cap, int dense, int capq) {
@@ -74,8 +101,8 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     constexpr int NQ = NQB * 16;
     constexpr int WAVES = THREADS / 64;
     const int tid = threadIdx.x;
-    const int chunks = D / 16;
-    const int qslots = chunks * 4 * NQ;
+    const int chunks = F16 ? D / 32 : D / 16;  // 64-byte pieces of a row
+    const int qslots = (D / 16) * 4 * NQ;      // same LDS footprint for both layouts: D * NQ * 4 bytes
     int* lds_cnt = reinterpret_cast<int*>(lds_q + qslots);          // [32]
     float* lds_sc = reinterpret_cast<float*>(lds_cnt + kQueryBlock);  // [32][capq]
     int* lds_id = reinterpret_cast<int*>(lds_sc + kQueryBlock * capq);  // [32][capq]
@@ -113,20 +140,32 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     // iteration therefore has the same number of loads outstanding, so the compiler's counted
     // vmcnt waits release exactly the group that is needed and never drain the prefetch.
     const int64_t stride = (int64_t)gridDim.x * WAVES;
+    const int64_t row_bytes = (int64_t)D * (F16 ? 2 : 4);
     auto tile_ptr = [&](int64_t t) -> const f32x4* {
         const int64_t r = seg_begin + t * 16 + n;
         const int64_t rc = r < seg_end ? r : seg_end - 1;
-        return reinterpret_cast<const f32x4*>(idx + rc * (int64_t)D) + g;
+        return reinterpret_cast<const f32x4*>(static_cast<const char*>(idx) + rc * row_bytes) + g;
     };
     auto load_group = [&](f32x4 (&x)[U], const f32x4* xp, int gi) {
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = ldx(xp + (gi * U + u) * 4);
     };
-    f32x4 acc[NQB];
+    f32x4 acc[NQB], acc_lo[NQB];
     auto mul_group = [&](const f32x4 (&x)[U], int gi) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = gi * U + u;
+            if (F16) {
+                const f16x8 xb = __builtin_bit_cast(f16x8, x[u]);
+                const f16x8* lq16 = reinterpret_cast<const f16x8*>(lds_q) + ((j * 4 + g) * 2) * NQ + n;
+#pragma unroll
+                for (int b = 0; b < NQB; ++b) {
+                    const f16x8 ah = lq16[b * 16], al = lq16[NQ + b * 16];
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xb, acc[b], 0, 0, 0);
+                    acc_lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xb, acc_lo[b], 0, 0, 0);
+                }
+                continue;
+            }
             float4 a[NQB];
 #pragma unroll
             for (int b = 0; b < NQB; ++b) a[b] = lq[(j * 4) * NQ + b * 16];
@@ -149,7 +188,7 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
         const f32x4* xpn = tile_ptr(tn < tiles ? tn : t);  // past the end: a harmless re-read
         const int64_t row = seg_begin + t * 16 + n;
 #pragma unroll
-        for (int b = 0; b < NQB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NQB; ++b) acc[b] = acc_lo[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if ((groups & 1) == 0) {
             for (int gi = 0; gi < groups; gi += 2) {
                 load_group(xb, xp, gi + 1);
@@ -179,7 +218,8 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
                 for (int r = 0; r < 4; ++r) {
                     const int qi = b * 16 + 4 * g + r;
                     if (qi >= Q) continue;
-                    const float s = row_scale ? acc[b][r] * scale : acc[b][r];
+                    const float dot = F16 ? fmaf(acc_lo[b][r], 1.0f / kLoScale, acc[b][r]) : acc[b][r];
+                    const float s = row_scale ? dot * scale : dot;
                     if (dense) {
                         const int64_t pos = row - seg_begin;
                         cand_score[qi * cap + pos] = s;
@@ -305,7 +345,7 @@ struct ScoreArgs {
     size_t lds;
     hipStream_t st;
     const float* qfrag;
-    const float* idx;
+    const void* idx;
     int64_t b, e;
     int D, Q;
     const float* row_scale;
@@ -317,15 +357,15 @@ struct ScoreArgs {
     int dense, capq;
 };
 
-template <int NQB, int U, int THREADS, int NT>
+template <int NQB, int U, int THREADS, int NT, int F16 = 0>
 static int launch_score(const ScoreArgs& a) {
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cosine_score<NQB, U, THREADS, NT>),
+        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cosine_score<NQB, U, THREADS, NT, F16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT>), dim3(a.grid), dim3(THREADS), a.lds, a.st,
+    hipLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT, F16>), dim3(a.grid), dim3(THREADS), a.lds, a.st,
                        a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci, a.cc, a.cap,
                        a.dense, a.capq);
     EVI_LAUNCH_CHECK();
@@ -339,6 +379,17 @@ static int launch_score_u(int U, const ScoreArgs& a) {
         case 4: return launch_score<NQB, 4, THREADS, NT>(a);
         case 2: return launch_score<NQB, 2, THREADS, NT>(a);
         default: return launch_score<NQB, 1, THREADS, NT>(a);
+    }
+}
+
+// f16 index: 1024-thread workgroups, plain loads (the tuned f32 configuration)
+template <int NQB>
+static int launch_score_f16(int U, const ScoreArgs& a) {
+    switch (U) {
+        case 8: return launch_score<NQB, 8, 1024, 0, 1>(a);
+        case 4: return launch_score<NQB, 4, 1024, 0, 1>(a);
+        case 2: return launch_score<NQB, 2, 1024, 0, 1>(a);
+        default: return launch_score<NQB, 1, 1024, 0, 1>(a);
     }
 }
 
@@ -376,10 +427,9 @@ extern "C" size_t evi_cosine_topk_min_workspace_bytes(int Q, int64_t N, int D, i
     return ws_layout(D, k, clamp_seg(N, kFirstSegment)).total;
 }
 
-extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t N, int D,
-                               const float* row_scale, int k, int64_t row_id_base, float* out_score,
-                               int64_t* out_index, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int64_t N, int D,
+                            const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                            int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream) {
     EVI_REQUIRE(Q >= 1, "evi_cosine_topk: Q must be >= 1, got %d", Q);
     EVI_REQUIRE(N >= 0, "evi_cosine_topk: N must be >= 0, got %lld", (long long)N);
     EVI_REQUIRE(N < (int64_t)0x7FFFFFFF, "evi_cosine_topk: a shard holds at most 2^31-1 rows, got %lld",
@@ -391,6 +441,8 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
     if (D < 16 || D % 16 != 0 || D > 1280)
         return fail(EVI_ERR_UNSUPPORTED,
                     "evi_cosine_topk: D must be a multiple of 16 in [16, 1280], got %d", D);
+    if (f16 && D % 32 != 0)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_f16: D must be a multiple of 32, got %d", D);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     const size_t min_ws = evi_cosine_topk_min_workspace_bytes(Q, N, D, k);
@@ -410,8 +462,9 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
     float* cs = reinterpret_cast<float*>(base + w.score_off);
     int32_t* ci = reinterpret_cast<int32_t*>(base + w.id_off);
 
-    const int chunks = D / 16;
-    const ScanVariant variant = scan_variant();
+    const int chunks = f16 ? D / 32 : D / 16;
+    ScanVariant variant = scan_variant();
+    if (f16) variant.threads = 1024;
     // loads in flight per lane per group: the largest U <= cap that leaves an EVEN number of groups
     // (copy-free ping-pong), else the largest U that divides the row.
     int U = 1;
@@ -432,8 +485,12 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
 
         hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, st, tau, cnt, kQueryBlock);
         EVI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_query_fragments, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D,
-                           nq_pad, qfrag);
+        if (f16)
+            hipLaunchKernelGGL(k_query_fragments_f16, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
+                               reinterpret_cast<f16x8*>(qfrag));
+        else
+            hipLaunchKernelGGL(k_query_fragments, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D,
+                               nq_pad, qfrag);
         EVI_LAUNCH_CHECK();
 
         if (N == 0) {
@@ -442,7 +499,7 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
             EVI_LAUNCH_CHECK();
             continue;
         }
-        const size_t lds_q_bytes = (size_t)chunks * 4 * nq_pad * sizeof(float4);
+        const size_t lds_q_bytes = (size_t)(D / 16) * 4 * nq_pad * sizeof(float4);
         // staging entries per query: whatever LDS is left, at most 64
         int capq = (int)((160 * 1024 - lds_q_bytes - kQueryBlock * sizeof(int)) / (kQueryBlock * 8));
         capq = capq > 64 ? 64 : (capq < 0 ? 0 : capq);
@@ -459,7 +516,8 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
             const ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
                                cs, ci, cnt, w.cap, first ? 1 : 0, capq};
             const int tok = timing_begin(kTimeCosineScore, st);
-            const int rc = nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa);
+            const int rc = f16 ? (nqb == 1 ? launch_score_f16<1>(U, sa) : launch_score_f16<2>(U, sa))
+                               : (nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa));
             timing_end(tok, st);
             if (rc != EVI_OK) return rc;
             const int final_pass = end >= N ? 1 : 0;
@@ -477,4 +535,20 @@ extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t 
         }
     }
     return EVI_OK;
+}
+
+extern "C" int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t N, int D,
+                               const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                               int64_t* out_index, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    return cosine_topk_impl(q, Q, idx, 0, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
+                            workspace_bytes, stream);
+}
+
+extern "C" int evi_cosine_topk_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D,
+                                   const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                                   int64_t* out_index, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    return cosine_topk_impl(q, Q, idx_f16, 1, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
+                            workspace_bytes, stream);
 }

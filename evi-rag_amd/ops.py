@@ -125,7 +125,10 @@ def cosine_topk(
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
     q = _f32c(queries, "queries")
-    x = _f32c(index, "index")
+    if index.dtype == torch.float16:
+        x = index.contiguous()  # f16-storage index: evi_cosine_topk_f16
+    else:
+        x = _f32c(index, "index")
     Q, D = q.shape
     N, D2 = x.shape
     if D != D2:
@@ -142,8 +145,9 @@ def cosine_topk(
         workspace = _workspace(dev, "cosine_topk", need)
     out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
     out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    fn = lib.evi_cosine_topk_f16 if x.dtype == torch.float16 else lib.evi_cosine_topk
     _lib.check(
-        lib.evi_cosine_topk(
+        fn(
             _ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base),
             _ptr(out_score), _ptr(out_index), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
             _stream(dev),

@@ -105,6 +105,15 @@ int evi_cosine_topk(const float* q, int Q, const float* idx, int64_t N, int D,
                     float* out_score, int64_t* out_index,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same contract with the index stored as IEEE f16 ([N, D] halves, D % 32 == 0): half the HBM bytes
+ * per pass.  Queries stay f32: each is split q = hi + lo into two f16 values and multiplied on
+ * v_mfma_f32_16x16x32_f16 with f32 accumulation, so scores equal the f32 dot product with the
+ * (f16-rounded) stored rows to ~1e-6.  For the 100 M-row index of BASELINE config 4. */
+int evi_cosine_topk_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D,
+                        const float* row_scale, int k, int64_t row_id_base,
+                        float* out_score, int64_t* out_index,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.
  *   scores [P, Q, k] f32, ids [P, Q, k] i64  ->  out_score [Q, k], out_index [Q, k].

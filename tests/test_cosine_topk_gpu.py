@@ -82,6 +82,26 @@ def test_cosine_topk_matches_oracle(dev, Q, N, D, k):
         assert np.array_equal(ids[1, :m].cpu().numpy(), np.arange(m) + 1000)
 
 
+@pytest.mark.parametrize("Q,N,D,k", [(32, 200000, 768, 500), (5, 1000, 64, 50), (17, 70001, 1024, 100)])
+def test_cosine_topk_f16_index_matches_oracle(dev, Q, N, D, k):
+    """f16-storage index (BASELINE config 4): scores == f32 queries . f16-rounded rows, to ~1e-6."""
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N + D)
+    q = np.random.default_rng(Q).standard_normal((Q, D), dtype=np.float32)
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    x16 = xn.to(torch.float16)
+    sc, ids = ops.cosine_topk(qn, x16, k, row_id_base=7)
+    ref_full = (qn.cpu().numpy().astype(np.float64) @ x16.cpu().numpy().astype(np.float64).T).astype(np.float32)
+    check_topk_against_scores(sc.cpu().numpy(), ids.cpu().numpy(), ref_full, k, id_base=7, score_tol=2e-6)
+    # and the f16 result stays within the f16 rounding of the f32-index result
+    s32, i32 = ops.cosine_topk(qn, xn, k, row_id_base=7)
+    assert float((sc[:, 0] - s32[:, 0]).abs().max()) < 1e-3
+    with pytest.raises(NotImplementedError):
+        ops.cosine_topk(qn[:, :48].contiguous(), x16[:, :48].contiguous(), 5)  # D % 32 != 0
+
+
 def test_cosine_topk_row_scale_equals_prenormalised(dev):
     """raw index + row_scale (fused normalisation) returns the same ids as a normalised index."""
     from evi_rag_amd import ops

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--threads", default="512,1024")
     ap.add_argument("--nt", default="0,1")
     ap.add_argument("--u", default="8,4")
+    ap.add_argument("--f16", action="store_true", help="store the index as f16")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -33,13 +34,15 @@ def main():
     for r0 in range(0, args.rows, step):
         x[r0:r0 + step] = torch.randn((min(step, args.rows - r0), args.dim), generator=g, device=dev)
     ops.normalize_embeddings(x, 1e-6, out=x)
+    if args.f16:
+        x = x.to(torch.float16)
     q = ops.normalize_embeddings(torch.randn((args.queries, args.dim), generator=g, device=dev), 1e-6)
     variants = list(itertools.product([int(v) for v in args.threads.split(",")],
                                       [int(v) for v in args.nt.split(",")],
                                       [int(v) for v in args.u.split(",")]))
     res = {v: [] for v in variants}
     ref = None
-    nbytes = args.rows * args.dim * 4
+    nbytes = args.rows * args.dim * (2 if args.f16 else 4)
     for rnd in range(args.rounds + 1):
         for v in variants:
             os.environ["EVI_SCAN_THREADS"], os.environ["EVI_SCAN_NT"], os.environ["EVI_SCAN_U"] = map(str, v)
