@@ -238,10 +238,11 @@ def main():
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
     from evi_rag_amd.dist import ShardedIndex
 
-    index = ShardedIndex(shard, N, local_topk=lambda q, x, kk, base: ops.cosine_topk(q, x, kk, row_id_base=base, workspace=ws))
+    index = ShardedIndex(shard, N)
+    index.workspace = ws
 
     def step(b):
-        # per-shard exact top-k; for world > 1 one all-gather of the packed [Q, k] lists + merge
+        # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge
         return index.topk(queries[b], k)
 
     def fence():

@@ -15,28 +15,33 @@ namespace evi {
 // scores/ids [P, Q, k]; block = query.  Slot order (shard asc, rank asc) equals id order among
 // equal scores when shards are passed in ascending row-id order, so the slot number is the
 // tie-break and ids may be full 64-bit.
+// shard p's scores start at scores + p * score_stride (floats), its ids at ids + p * id_stride (i64):
+// contiguous [P, Q, k] arrays have strides Q*k; the packed all-gather layout ([scores | ids] per
+// rank) has the per-rank record size.
 __global__ __launch_bounds__(kSelectThreads) void k_topk_merge(
-    const float* __restrict__ scores, const int64_t* __restrict__ ids, int P, int Q, int k,
-    float* __restrict__ out_score, int64_t* __restrict__ out_index) {
+    const float* __restrict__ scores, const int64_t* __restrict__ ids, int64_t score_stride, int64_t id_stride,
+    int P, int Q, int k, float* __restrict__ out_score, int64_t* __restrict__ out_index) {
     __shared__ SelectShared sh;
     const int qi = blockIdx.x;
     const int64_t cnt = (int64_t)P * k;
-    auto slot_of = [&](int64_t i) -> int64_t {
-        const int p = (int)(i / k), j = (int)(i % k);
-        return ((int64_t)p * Q + qi) * k + j;
+    auto slot_of = [&](int64_t i, int& p) -> int64_t {
+        p = (int)(i / k);
+        return (int64_t)qi * k + (i % k);
     };
     auto load = [&](int64_t i) -> uint64_t {
-        const int64_t s = slot_of(i);
-        if (ids[s] < 0) return 0ull;
-        return make_key(scores[s], (uint32_t)i);
+        int p;
+        const int64_t s = slot_of(i, p);
+        if (ids[p * id_stride + s] < 0) return 0ull;
+        return make_key(scores[p * score_stride + s], (uint32_t)i);
     };
     const int m = block_topk(sh, load, cnt, k);
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const uint64_t key = i < m ? sh.keys[i] : 0ull;
         if (key != 0ull) {
-            const int64_t s = slot_of((int64_t)key_index(key));
-            out_score[(int64_t)qi * k + i] = scores[s];
-            out_index[(int64_t)qi * k + i] = ids[s];
+            int p;
+            const int64_t s = slot_of((int64_t)key_index(key), p);
+            out_score[(int64_t)qi * k + i] = scores[p * score_stride + s];
+            out_index[(int64_t)qi * k + i] = ids[p * id_stride + s];
         } else {
             out_score[(int64_t)qi * k + i] = -INFINITY;
             out_index[(int64_t)qi * k + i] = -1;
@@ -80,8 +85,30 @@ extern "C" int evi_topk_merge(const float* scores, const int64_t* ids, int P, in
                 (long long)P * k, kSortCap);
     if (Q == 0) return EVI_OK;
     EVI_REQUIRE(scores && ids && out_score && out_index, "evi_topk_merge: null pointer");
-    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(kSelectThreads), 0,
-                       reinterpret_cast<hipStream_t>(stream), scores, ids, P, Q, k, out_score, out_index);
+    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(kSelectThreads), 0, reinterpret_cast<hipStream_t>(stream), scores,
+                       ids, (int64_t)Q * k, (int64_t)Q * k, P, Q, k, out_score, out_index);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" size_t evi_topk_packed_bytes(int Q, int k) {
+    if (Q <= 0 || k <= 0) return 0;
+    return align_up((size_t)Q * k * sizeof(float), 8) + (size_t)Q * k * sizeof(int64_t);
+}
+
+extern "C" int evi_topk_merge_packed(const void* packed, int P, int Q, int k, float* out_score, int64_t* out_index,
+                                     void* stream) {
+    EVI_REQUIRE(P >= 1 && Q >= 0, "evi_topk_merge_packed: need P >= 1 and Q >= 0, got P=%d Q=%d", P, Q);
+    EVI_REQUIRE(k >= 1 && k <= EVI_TOPK_MAX_K, "evi_topk_merge_packed: k must be in [1, %d], got %d", EVI_TOPK_MAX_K, k);
+    EVI_REQUIRE((int64_t)P * k <= kSortCap, "evi_topk_merge_packed: P*k = %lld exceeds %d", (long long)P * k, kSortCap);
+    if (Q == 0) return EVI_OK;
+    EVI_REQUIRE(packed && out_score && out_index, "evi_topk_merge_packed: null pointer");
+    const size_t rec = evi_topk_packed_bytes(Q, k);
+    const size_t ids_off = align_up((size_t)Q * k * sizeof(float), 8);
+    const char* base = static_cast<const char*>(packed);
+    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(kSelectThreads), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + ids_off),
+                       (int64_t)(rec / sizeof(float)), (int64_t)(rec / sizeof(int64_t)), P, Q, k, out_score, out_index);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -117,6 +117,7 @@ def cosine_topk(
     row_scale: Optional[torch.Tensor] = None,
     row_id_base: int = 0,
     workspace: Optional[torch.Tensor] = None,
+    out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Top-k rows of `index` per query by dot product (cosine when both are L2-normalised, or when
     `index` is raw and row_scale = row_inv_norm(index)).  Returns (scores [Q,k] f32, ids [Q,k] i64),
@@ -143,8 +144,14 @@ def cosine_topk(
     need = int(lib.evi_cosine_topk_workspace_bytes(Q, N, D, int(k)))
     if workspace is None:
         workspace = _workspace(dev, "cosine_topk", need)
-    out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
-    out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    if out is not None:
+        out_score, out_index = out
+        if (out_score.shape != (Q, k) or out_index.shape != (Q, k) or out_score.dtype != torch.float32
+                or out_index.dtype != torch.int64 or not out_score.is_contiguous() or not out_index.is_contiguous()):
+            raise ValueError("out must be contiguous (float32 [Q, k], int64 [Q, k]) tensors")
+    else:
+        out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     fn = lib.evi_cosine_topk_f16 if x.dtype == torch.float16 else lib.evi_cosine_topk
     _lib.check(
         fn(
@@ -172,6 +179,27 @@ def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, t
         return out_score, out_index
     lib = _lib.load()
     _lib.check(lib.evi_topk_merge(_ptr(s), _ptr(ids), P, Q, k, _ptr(out_score), _ptr(out_index), _stream(dev)))
+    return out_score, out_index
+
+
+def topk_packed_views(packed: torch.Tensor, Q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(scores [Q, k] f32, ids [Q, k] i64) views into one rank's packed exchange record."""
+    n = Q * k
+    ids_off = (n * 4 + 7) // 8 * 8
+    rec = packed.view(torch.uint8).view(-1)
+    return rec[: n * 4].view(torch.float32).view(Q, k), rec[ids_off: ids_off + n * 8].view(torch.int64).view(Q, k)
+
+
+def topk_merge_packed(packed: torch.Tensor, P: int, Q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge P packed per-shard records (the output of ONE all-gather) into the global top-k."""
+    dev = _require_gpu(packed)
+    lib = _lib.load()
+    rec = int(lib.evi_topk_packed_bytes(Q, k))
+    if packed.numel() * packed.element_size() < P * rec:
+        raise ValueError(f"packed buffer holds {packed.numel() * packed.element_size()} B, need {P * rec} B")
+    out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    _lib.check(lib.evi_topk_merge_packed(packed.data_ptr(), P, Q, k, _ptr(out_score), _ptr(out_index), _stream(dev)))
     return out_score, out_index
 
 

@@ -122,6 +122,14 @@ int evi_cosine_topk_f16(const float* q, int Q, const void* idx_f16, int64_t N, i
 int evi_topk_merge(const float* scores, const int64_t* ids, int P, int Q, int k,
                    float* out_score, int64_t* out_index, void* stream);
 
+/* The same merge on the PACKED exchange layout, so that one all-gather moves scores and ids
+ * together: each rank's record is [Q*k f32 scores | pad to 8 B | Q*k i64 ids]
+ * (evi_topk_packed_bytes(Q, k) bytes; evi_cosine_topk can write straight into it), and `packed`
+ * holds the P records back to back in ascending shard order. */
+size_t evi_topk_packed_bytes(int Q, int k);
+int evi_topk_merge_packed(const void* packed, int P, int Q, int k, float* out_score, int64_t* out_index,
+                          void* stream);
+
 /* ---- T1-T3 / G9: per-graph (segmented) top-k over edge scores ---------------------------- */
 
 /* For each graph g (edges edge_ptr[g] .. edge_ptr[g+1]) write the min(k, E_g) edges with the

@@ -185,6 +185,16 @@ def test_sharded_topk_merge_equals_single_shard(dev):
     s_m, i_m = ops.topk_merge(ss, ii)
     assert torch.equal(i_m, i_all)
     assert torch.equal(s_m, s_all)
+    # the packed exchange layout (one all-gather per step): kernels write straight into the records
+    from evi_rag_amd import _lib
+
+    rec = int(_lib.load().evi_topk_packed_bytes(Q, k))
+    packed = torch.empty(P * rec, dtype=torch.uint8, device=dev)
+    for r in range(P):
+        views = ops.topk_packed_views(packed[r * rec:(r + 1) * rec], Q, k)
+        ops.cosine_topk(qn, xn[bounds[r]:bounds[r + 1]], k, row_id_base=bounds[r], out=views)
+    s_p, i_p = ops.topk_merge_packed(packed, P, Q, k)
+    assert torch.equal(i_p, i_all) and torch.equal(s_p, s_all)
     # and the merge kernel itself against the oracle merge
     rs, ri = orank.merge_topk(ss.cpu().numpy(), ii.cpu().numpy(), k)
     assert np.array_equal(ri, i_m.cpu().numpy())
