@@ -201,6 +201,22 @@ def test_retriever_forward_matches_oracle_webqsp_shape(dev, dedupe):
     assert np.array_equal(out.query_ids.cpu().numpy(), ref["query_ids"])
 
 
+@pytest.mark.parametrize("D,H", [(1024, 1024), (384, 256), (1280, 64)])
+def test_retriever_forward_other_dims(dev, D, H):
+    """The reference default (emb_dim = hidden_dim = 1024, configs/model/retriever_module.yaml:10-11),
+    a MiniLM-sized D and the largest supported D, against the numpy oracle."""
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(2, nodes_per_graph=120, edges_per_graph=300, emb_dim=D, num_relations=20, seed=D)
+    torch.manual_seed(D)
+    model = Retriever(emb_dim=D, hidden_dim=H, dde_cfg={"num_rounds": 1, "num_reverse_rounds": 2}).eval()
+    w = {k: v.numpy() for k, v in model.state_dict().items()}
+    ref = oscorer.retriever_forward(w, sb, num_rounds=1, num_reverse_rounds=2)
+    out = model.to(dev)(synthetic.as_namespace(sb, device=dev))
+    np.testing.assert_allclose(out.logits.cpu().numpy(), ref["logits"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=3e-4)
+
+
 def test_retriever_error_contract(dev):
     from evi_rag_amd.retriever import Retriever
 
