@@ -244,12 +244,10 @@ __global__ __launch_bounds__(kGraphThreads) void k_dde(
 using namespace evi;
 
 extern "C" int evi_edge_batch(const int64_t* edge_index, int64_t E, const int64_t* node_ptr, int B,
-                              int64_t* edge_batch, int64_t* edge_ptr, int32_t* edge_count_ws,
-                              int32_t* status, void* stream) {
+                              int64_t* edge_batch, int64_t* edge_ptr, int32_t* status, void* stream) {
     EVI_REQUIRE(E >= 0 && B >= 1, "evi_edge_batch: need E >= 0 and B >= 1, got E=%lld B=%d", (long long)E, B);
     EVI_REQUIRE(node_ptr && edge_ptr && status, "evi_edge_batch: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    (void)edge_count_ws;
     EVI_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
     EVI_HIP_CHECK(hipMemsetAsync(edge_ptr, 0, sizeof(int64_t) * (B + 1), st));  // E == 0: all zeros
     if (E > 0) {

@@ -247,11 +247,10 @@ def edge_batch(edge_index: torch.Tensor, node_ptr: torch.Tensor):
     E, B = ei.size(1), ptr.numel() - 1
     eb = torch.empty(E, dtype=torch.int64, device=dev)
     eptr = torch.empty(B + 1, dtype=torch.int64, device=dev)
-    scratch = torch.empty(B + 1, dtype=torch.int32, device=dev)  # [B] counts + [1] status
+    status = torch.empty(1, dtype=torch.int32, device=dev)
     lib = _lib.load()
-    _lib.check(lib.evi_edge_batch(_ptr(ei), E, _ptr(ptr), B, _ptr(eb), _ptr(eptr), scratch.data_ptr(),
-                                  scratch.data_ptr() + 4 * B, _stream(dev)))
-    return eb, eptr, scratch[B:]
+    _lib.check(lib.evi_edge_batch(_ptr(ei), E, _ptr(ptr), B, _ptr(eb), _ptr(eptr), status.data_ptr(), _stream(dev)))
+    return eb, eptr, status
 
 
 def qa_edge_mask(edge_index: torch.Tensor, num_nodes: int, q_local_indices: torch.Tensor,

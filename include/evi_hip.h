@@ -201,12 +201,10 @@ int evi_gather_rows(const float* table, int64_t num_rows, int D, const int64_t* 
  * on the device) receives a bit mask the host shim turns into the reference's ValueErrors:
  * 1 = graph id out of range, 2 = head and tail in different graphs ("edge_index crosses graph
  * boundaries"), 4 = edge list not grouped by graph ("edge_batch is not non-decreasing").
- *   edge_index [2, E] i64; node_ptr [B+1] i64; edge_batch [E] i64; edge_ptr [B+1] i64;
- *   edge_count_ws: unused (kept for ABI stability; may be NULL).
+ *   edge_index [2, E] i64; node_ptr [B+1] i64; edge_batch [E] i64; edge_ptr [B+1] i64.
  * Replaces compute_edge_batch, src/utils/graph_utils.py:50-104. */
 int evi_edge_batch(const int64_t* edge_index, int64_t E, const int64_t* node_ptr, int B,
-                   int64_t* edge_batch, int64_t* edge_ptr, int32_t* edge_count_ws, int32_t* status,
-                   void* stream);
+                   int64_t* edge_batch, int64_t* edge_ptr, int32_t* status, void* stream);
 
 /* out_mask[e] = head in (Q u A) or tail in (Q u A); status bit 1 = a q/a index outside
  * [0, num_nodes).  node_mask_ws: [num_nodes] bytes of scratch.
