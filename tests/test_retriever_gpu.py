@@ -217,6 +217,25 @@ def test_retriever_forward_other_dims(dev, D, H):
     np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=3e-4)
 
 
+def test_retriever_forward_multi_chunk_batch(dev):
+    """More than 65 536 edges: the scorer processes the batch in edge chunks; one big graph with a
+    hub node (DDE hub path) and a small one."""
+    from evi_rag_amd.retriever import Retriever
+
+    D = H = 32
+    sb = synthetic.make_batch(2, nodes_per_graph=6000, edges_per_graph=70000, emb_dim=D, num_relations=2000, seed=77,
+                              alpha=1.6, size_jitter=0.1)
+    assert sb.num_edges > 70000
+    torch.manual_seed(5)
+    model = Retriever(emb_dim=D, hidden_dim=H).eval()
+    w = {k: v.numpy() for k, v in model.state_dict().items()}
+    ref = oscorer.retriever_forward(w, sb, num_rounds=2, num_reverse_rounds=2)
+    out = model.to(dev)(synthetic.as_namespace(sb, device=dev))
+    np.testing.assert_allclose(out.logits.cpu().numpy(), ref["logits"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out.logits_bwd.cpu().numpy(), ref["logits_bwd"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=2e-4)
+
+
 def test_retriever_error_contract(dev):
     from evi_rag_amd.retriever import Retriever
 
