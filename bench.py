@@ -44,8 +44,9 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--index-dtype", choices=["f32", "f16"], default="f32",
-                    help="storage dtype of the resident index (f16: BASELINE config 4 variant; the headline is f32)")
+    ap.add_argument("--index-dtype", choices=["f32", "f16", "fp8"], default="f32",
+                    help="storage dtype of the resident index (f16 / fp8 e4m3 + per-row scale: BASELINE configs 4 / 5; "
+                         "the headline is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-eval", action="store_true")
     return ap.parse_args()
@@ -235,10 +236,17 @@ def main():
         torch.cuda.empty_cache()
     n_batches = args.warmup + args.steps
     queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, args.seed, world)
+    row_scale = None
+    shard_f32_sample = None
+    if args.index_dtype == "fp8":
+        shard_f32_sample = shard[: args.cpu_rows].clone()
+        shard, row_scale = ops.quantize_rows_fp8(shard)
+        elem_bytes = 1
+        torch.cuda.empty_cache()
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
     from evi_rag_amd.dist import ShardedIndex
 
-    index = ShardedIndex(shard, N)
+    index = ShardedIndex(shard, N, row_scale=row_scale)
     index.workspace = ws
 
     def step(b):
@@ -283,7 +291,7 @@ def main():
     if rank == 0:
         steps = args.steps
         shard_rows = row_end - row_begin
-        bytes_per_step = shard_rows * D * elem_bytes + Q * D * 4 + Q * k * 12
+        bytes_per_step = shard_rows * D * elem_bytes + Q * D * 4 + Q * k * 12 + (shard_rows * 4 if row_scale is not None else 0)
         score_ms_per_step = ms[0] / steps
         achieved = bytes_per_step / (score_ms_per_step * 1e-3) / 1e9 if score_ms_per_step > 0 else 0.0
         result = {
@@ -297,7 +305,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.index_dtype == "f32" else "f16 index x f32 queries (f16 MFMA, f32 accumulate)",
+            "dtype": {"f32": "f32", "f16": "f16 index x f32 queries (f16 MFMA, f32 accumulate)",
+                      "fp8": "e4m3 index + f32 row scale x f32 queries (f16 MFMA, f32 accumulate)"}[args.index_dtype],
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k",
@@ -325,7 +334,8 @@ def main():
             "sorted_ok": sorted_ok,
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(shard, queries, k, N, args.cpu_rows, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(shard if shard_f32_sample is None else shard_f32_sample, queries, k, N,
+                                                  args.cpu_rows, args.cpu_seconds)
         if world == 1 and not args.no_graph_eval:
             del shard, ws
             torch.cuda.empty_cache()

@@ -74,6 +74,36 @@ __global__ void k_query_fragments_f16(const float* __restrict__ q, int Q, int D,
     }
 }
 
+// fp8-index variant: a 64-byte piece J of a row holds 64 e4m3 values; lane group g owns bytes
+// 16 g .. 16 g + 15 and feeds them to two f16 MFMA K-steps (m = 0: bytes 0-7, m = 1: bytes 8-15).
+//   qfrag8[(((J*2 + m)*4 + g)*2 + part) * nq_pad + i] = 8 halves of q[i][64 J + 16 g + 8 m .. + 7]
+__global__ void k_query_fragments_fp8(const float* __restrict__ q, int Q, int D, int nq_pad,
+                                      f16x8* __restrict__ qfrag) {
+    const int total = (D / 64) * 8 * nq_pad;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        const int i = s % nq_pad;
+        const int jmg = s / nq_pad;            // (J*2 + m)*4 + g
+        const int g = jmg & 3, m = (jmg >> 2) & 1, J = jmg >> 3;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = i < Q ? q[(int64_t)i * D + 64 * J + 16 * g + 8 * m + e] : 0.f;
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)((v - (float)h) * kLoScale);
+        }
+        qfrag[(jmg * 2 + 0) * nq_pad + i] = hi;
+        qfrag[(jmg * 2 + 1) * nq_pad + i] = lo;
+    }
+}
+
+// two e4m3 bytes of w (selected by `sel`) -> two f16 whose value is the fp8 value / 256:
+// f16 bits = sign << 15 | (low 7 bits) << 7 (exact for every finite e4m3 code, subnormals included)
+__device__ inline uint32_t fp8x2_to_f16x2_scaled(uint32_t w, uint32_t sel) {
+    const uint32_t p = __builtin_amdgcn_perm(0u, w, sel);  // bytes -> [b_hi, 0, b_lo, 0]
+    return (p & 0x80008000u) | ((p >> 1) & 0x3F803F80u);
+}
+
 __global__ void k_init_state(float* tau, int32_t* cnt, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -91,6 +121,7 @@ __global__ void k_init_state(float* tau, int32_t* cnt, int n) {
 // of one per candidate; entries that do not fit go straight to the global list.
 //   F16: the index is stored as f16 (half the HBM bytes); queries are split hi + lo in f16 and
 //   multiplied on v_mfma_f32_16x16x32_f16 with f32 accumulation.
+//   (F16 == 2: the index is OCP e4m3 with a per-row scale; bytes are widened to f16 in registers.)
 template <int NQB, int U, int THREADS, int NT, int F16>
 __global__ __launch_bounds__(THREADS) void k_cosine_score(
     const float* __restrict__ qfrag, const void* __restrict__ idx, int64_t seg_begin,
@@ -101,7 +132,7 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     constexpr int NQ = NQB * 16;
     constexpr int WAVES = THREADS / 64;
     const int tid = threadIdx.x;
-    const int chunks = F16 ? D / 32 : D / 16;  // 64-byte pieces of a row
+    const int chunks = F16 == 2 ? D / 64 : (F16 ? D / 32 : D / 16);  // 64-byte pieces of a row
     const int qslots = (D / 16) * 4 * NQ;      // same LDS footprint for both layouts: D * NQ * 4 bytes
     int* lds_cnt = reinterpret_cast<int*>(lds_q + qslots);          // [32]
     float* lds_sc = reinterpret_cast<float*>(lds_cnt + kQueryBlock);  // [32][capq]
@@ -140,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     // iteration therefore has the same number of loads outstanding, so the compiler's counted
     // vmcnt waits release exactly the group that is needed and never drain the prefetch.
     const int64_t stride = (int64_t)gridDim.x * WAVES;
-    const int64_t row_bytes = (int64_t)D * (F16 ? 2 : 4);
+    const int64_t row_bytes = (int64_t)D * (F16 == 2 ? 1 : (F16 ? 2 : 4));
     auto tile_ptr = [&](int64_t t) -> const f32x4* {
         const int64_t r = seg_begin + t * 16 + n;
         const int64_t rc = r < seg_end ? r : seg_end - 1;
@@ -155,6 +186,27 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = gi * U + u;
+            if (F16 == 2) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 w = __builtin_bit_cast(u32x4, x[u]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    u32x4 h;
+                    h[0] = fp8x2_to_f16x2_scaled(w[2 * m], 0x010C000Cu);
+                    h[1] = fp8x2_to_f16x2_scaled(w[2 * m], 0x030C020Cu);
+                    h[2] = fp8x2_to_f16x2_scaled(w[2 * m + 1], 0x010C000Cu);
+                    h[3] = fp8x2_to_f16x2_scaled(w[2 * m + 1], 0x030C020Cu);
+                    const f16x8 xb = __builtin_bit_cast(f16x8, h);
+                    const f16x8* lq16 = reinterpret_cast<const f16x8*>(lds_q) + ((((j * 2 + m) * 4 + g) * 2) * NQ) + n;
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b) {
+                        const f16x8 ah = lq16[b * 16], al = lq16[NQ + b * 16];
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xb, acc[b], 0, 0, 0);
+                        acc_lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xb, acc_lo[b], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
             if (F16) {
                 const f16x8 xb = __builtin_bit_cast(f16x8, x[u]);
                 const f16x8* lq16 = reinterpret_cast<const f16x8*>(lds_q) + ((j * 4 + g) * 2) * NQ + n;
@@ -218,7 +270,8 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
                 for (int r = 0; r < 4; ++r) {
                     const int qi = b * 16 + 4 * g + r;
                     if (qi >= Q) continue;
-                    const float dot = F16 ? fmaf(acc_lo[b][r], 1.0f / kLoScale, acc[b][r]) : acc[b][r];
+                    float dot = F16 ? fmaf(acc_lo[b][r], 1.0f / kLoScale, acc[b][r]) : acc[b][r];
+                    if (F16 == 2) dot *= 256.0f;  // the widened bytes carry value / 256
                     const float s = row_scale ? dot * scale : dot;
                     if (dense) {
                         const int64_t pos = row - seg_begin;
@@ -382,14 +435,14 @@ static int launch_score_u(int U, const ScoreArgs& a) {
     }
 }
 
-// f16 index: 1024-thread workgroups, plain loads (the tuned f32 configuration)
-template <int NQB>
-static int launch_score_f16(int U, const ScoreArgs& a) {
+// f16 / fp8 index: 1024-thread workgroups, plain loads (the tuned f32 configuration)
+template <int NQB, int KIND>
+static int launch_score_lowp(int U, const ScoreArgs& a) {
     switch (U) {
-        case 8: return launch_score<NQB, 8, 1024, 0, 1>(a);
-        case 4: return launch_score<NQB, 4, 1024, 0, 1>(a);
-        case 2: return launch_score<NQB, 2, 1024, 0, 1>(a);
-        default: return launch_score<NQB, 1, 1024, 0, 1>(a);
+        case 8: return launch_score<NQB, 8, 1024, 0, KIND>(a);
+        case 4: return launch_score<NQB, 4, 1024, 0, KIND>(a);
+        case 2: return launch_score<NQB, 2, 1024, 0, KIND>(a);
+        default: return launch_score<NQB, 1, 1024, 0, KIND>(a);
     }
 }
 
@@ -441,8 +494,11 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
     if (D < 16 || D % 16 != 0 || D > 1280)
         return fail(EVI_ERR_UNSUPPORTED,
                     "evi_cosine_topk: D must be a multiple of 16 in [16, 1280], got %d", D);
-    if (f16 && D % 32 != 0)
+    if (f16 == 1 && D % 32 != 0)
         return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_f16: D must be a multiple of 32, got %d", D);
+    if (f16 == 2 && D % 64 != 0)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_fp8: D must be a multiple of 64, got %d", D);
+    EVI_REQUIRE(f16 != 2 || row_scale || N == 0, "evi_cosine_topk_fp8: row_scale (the per-row dequantisation scale) is required");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     const size_t min_ws = evi_cosine_topk_min_workspace_bytes(Q, N, D, k);
@@ -462,7 +518,7 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
     float* cs = reinterpret_cast<float*>(base + w.score_off);
     int32_t* ci = reinterpret_cast<int32_t*>(base + w.id_off);
 
-    const int chunks = f16 ? D / 32 : D / 16;
+    const int chunks = f16 == 2 ? D / 64 : (f16 ? D / 32 : D / 16);
     ScanVariant variant = scan_variant();
     if (f16) variant.threads = 1024;
     // loads in flight per lane per group: the largest U <= cap that leaves an EVEN number of groups
@@ -485,7 +541,10 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
 
         hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, st, tau, cnt, kQueryBlock);
         EVI_LAUNCH_CHECK();
-        if (f16)
+        if (f16 == 2)
+            hipLaunchKernelGGL(k_query_fragments_fp8, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
+                               reinterpret_cast<f16x8*>(qfrag));
+        else if (f16)
             hipLaunchKernelGGL(k_query_fragments_f16, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
                                reinterpret_cast<f16x8*>(qfrag));
         else
@@ -516,8 +575,9 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
             const ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
                                cs, ci, cnt, w.cap, first ? 1 : 0, capq};
             const int tok = timing_begin(kTimeCosineScore, st);
-            const int rc = f16 ? (nqb == 1 ? launch_score_f16<1>(U, sa) : launch_score_f16<2>(U, sa))
-                               : (nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa));
+            const int rc = f16 == 2 ? (nqb == 1 ? launch_score_lowp<1, 2>(U, sa) : launch_score_lowp<2, 2>(U, sa))
+                           : f16  ? (nqb == 1 ? launch_score_lowp<1, 1>(U, sa) : launch_score_lowp<2, 1>(U, sa))
+                                  : (nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa));
             timing_end(tok, st);
             if (rc != EVI_OK) return rc;
             const int final_pass = end >= N ? 1 : 0;
@@ -550,5 +610,13 @@ extern "C" int evi_cosine_topk_f16(const float* q, int Q, const void* idx_f16, i
                                    int64_t* out_index, void* workspace, size_t workspace_bytes,
                                    void* stream) {
     return cosine_topk_impl(q, Q, idx_f16, 1, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
+                            workspace_bytes, stream);
+}
+
+extern "C" int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, int64_t N, int D,
+                                   const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                                   int64_t* out_index, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    return cosine_topk_impl(q, Q, idx_fp8, 2, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
                             workspace_bytes, stream);
 }

@@ -3,6 +3,8 @@
 // One wave per row, 16-byte loads when D % 4 == 0, f32 accumulation, butterfly reduce.
 #include "common.hpp"
 
+#include <hip/hip_fp8.h>
+
 namespace evi {
 
 __device__ inline float wave_sum(float v) {
@@ -61,6 +63,26 @@ __global__ __launch_bounds__(256) void k_row_norm(const float* __restrict__ x, i
     }
 }
 
+// Per-row symmetric quantisation to OCP e4m3: scale = max|x| / 448 (1 for an all-zero row),
+// out = e4m3(x / scale) with round-to-nearest-even and saturation; x ~ out * scale.
+__global__ __launch_bounds__(256) void k_quantize_rows_fp8(const float* __restrict__ x, int64_t n, int D,
+                                                           uint8_t* __restrict__ out, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nwaves) {
+        const float* row = x + r * (int64_t)D;
+        float mx = 0.f;
+        for (int d = lane; d < D; d += 64) mx = fmaxf(mx, fabsf(row[d]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
+        if (lane == 0) scale[r] = sc;
+        uint8_t* o = out + r * (int64_t)D;
+        for (int d = lane; d < D; d += 64)
+            o[d] = (uint8_t)__hip_cvt_float_to_fp8(row[d] / sc, __HIP_SATFINITE, __HIP_E4M3);
+    }
+}
+
 static int norm_grid(int64_t n) {
     int64_t blocks = (n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
@@ -91,6 +113,17 @@ extern "C" int evi_row_normalize(const float* x, int64_t n, int D, float eps, fl
     EVI_REQUIRE(x && out, "evi_row_normalize: null pointer");
     hipLaunchKernelGGL(k_row_norm<1>, dim3(norm_grid(n)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), x, n, D, eps, out);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_quantize_rows_fp8(const float* x, int64_t n, int D, uint8_t* out_fp8, float* out_scale,
+                                     void* stream) {
+    EVI_REQUIRE(n >= 0 && D >= 1, "evi_quantize_rows_fp8: need n >= 0 and D >= 1, got n=%lld D=%d", (long long)n, D);
+    if (n == 0) return EVI_OK;
+    EVI_REQUIRE(x && out_fp8 && out_scale, "evi_quantize_rows_fp8: null pointer");
+    hipLaunchKernelGGL(k_quantize_rows_fp8, dim3(norm_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n,
+                       D, out_fp8, out_scale);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

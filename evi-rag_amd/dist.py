@@ -32,10 +32,10 @@ def shard_graphs(num_graphs: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_graphs, world_size))
 
 
-def _default_local_topk(queries, shard, k, row_id_base):
+def _default_local_topk(queries, shard, k, row_id_base, row_scale=None):
     from . import ops
 
-    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base)
+    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale)
 
 
 def _default_merge(scores, ids):
@@ -48,7 +48,8 @@ class ShardedIndex:
     """The local shard of a row-sharded, L2-normalised index plus the cross-rank top-k merge."""
 
     def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
-                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None) -> None:
+                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
+                 row_scale: Optional[torch.Tensor] = None) -> None:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -58,6 +59,11 @@ class ShardedIndex:
             raise ValueError(f"rank {self.rank} must hold rows [{self.row_begin}, {self.row_end}): "
                              f"{self.row_end - self.row_begin} rows, got {local_rows.size(0)}")
         self.shard = local_rows
+        # per-row scale of the local shard: the fused normalisation of a raw index, or the
+        # dequantisation scale of an fp8 index (ops.quantize_rows_fp8)
+        self.row_scale = row_scale
+        if row_scale is not None and row_scale.numel() != local_rows.size(0):
+            raise ValueError(f"row_scale must have one entry per local row ({local_rows.size(0)}), got {row_scale.numel()}")
         self._local_topk = local_topk or _default_local_topk
         self._merge = merge or _default_merge
         self._gather_s: Optional[torch.Tensor] = None
@@ -73,7 +79,10 @@ class ShardedIndex:
         """Global top-k (scores [Q, k], global row ids [Q, k]) — identical on every rank."""
         if self.world > 1 and self._packed_ok and queries.is_cuda:
             return self._topk_packed(queries, k)
-        s, i = self._local_topk(queries, self.shard, k, self.row_begin)
+        if self.row_scale is not None:
+            s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale)
+        else:
+            s, i = self._local_topk(queries, self.shard, k, self.row_begin)
         if self.world == 1:
             return s, i
         Q = queries.size(0)
@@ -95,7 +104,8 @@ def _topk_packed(self: "ShardedIndex", queries: torch.Tensor, k: int):
         self._packed_local = torch.empty(rec, dtype=torch.uint8, device=queries.device)
         self._packed_all = torch.empty(self.world * rec, dtype=torch.uint8, device=queries.device)
     s, i = ops.topk_packed_views(self._packed_local, Q, k)
-    ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, workspace=self.workspace, out=(s, i))
+    ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
+                    workspace=self.workspace, out=(s, i))
     dist.all_gather_into_tensor(self._packed_all, self._packed_local, group=self.group)
     return ops.topk_merge_packed(self._packed_all, self.world, Q, k)
 

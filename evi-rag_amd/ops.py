@@ -103,6 +103,21 @@ def normalize_embeddings(embeddings: torch.Tensor, eps: float = 1e-6, out: Optio
     return out
 
 
+def quantize_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(e4m3 bytes [n, D] uint8, scale [n] f32): x ~ e4m3 * scale, scale = max|x| / 448 per row."""
+    dev = _require_gpu(x)
+    if x.dim() != 2:
+        raise ValueError(f"x must be 2D [n, D], got shape {tuple(x.shape)}")
+    x = _f32c(x, "x")
+    n, D = x.shape
+    out = torch.empty((n, D), dtype=torch.uint8, device=dev)
+    scale = torch.empty(n, dtype=torch.float32, device=dev)
+    if n:
+        lib = _lib.load()
+        _lib.check(lib.evi_quantize_rows_fp8(_ptr(x), n, D, _ptr(out), _ptr(scale), _stream(dev)))
+    return out, scale
+
+
 # ---- cosine top-k -------------------------------------------------------------------------------
 
 def cosine_topk_workspace_bytes(Q: int, N: int, D: int, k: int) -> int:
@@ -128,6 +143,10 @@ def cosine_topk(
     q = _f32c(queries, "queries")
     if index.dtype == torch.float16:
         x = index.contiguous()  # f16-storage index: evi_cosine_topk_f16
+    elif index.dtype == torch.uint8:
+        x = index.contiguous()  # e4m3 bytes from quantize_rows_fp8: evi_cosine_topk_fp8 (row_scale required)
+        if row_scale is None:
+            raise ValueError("an fp8 index needs row_scale (the per-row scale returned by quantize_rows_fp8)")
     else:
         x = _f32c(index, "index")
     Q, D = q.shape
@@ -152,7 +171,7 @@ def cosine_topk(
     else:
         out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
-    fn = lib.evi_cosine_topk_f16 if x.dtype == torch.float16 else lib.evi_cosine_topk
+    fn = {torch.float16: lib.evi_cosine_topk_f16, torch.uint8: lib.evi_cosine_topk_fp8}.get(x.dtype, lib.evi_cosine_topk)
     _lib.check(
         fn(
             _ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base),

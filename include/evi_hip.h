@@ -114,6 +114,20 @@ int evi_cosine_topk_f16(const float* q, int Q, const void* idx_f16, int64_t N, i
                         float* out_score, int64_t* out_index,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* fp8 storage (BASELINE config 5): rows quantised to OCP e4m3 with one f32 scale per row,
+ *   scale = max|x| / 448 (1 for an all-zero row), out = e4m3(x / scale), round-to-nearest-even. */
+int evi_quantize_rows_fp8(const float* x, int64_t n, int D, uint8_t* out_fp8, float* out_scale, void* stream);
+
+/* Same contract as evi_cosine_topk over an e4m3 index ([N, D] bytes, D % 64 == 0) with its per-row
+ * scale in row_scale (required): score = (sum_d q[i,d] * e4m3(idx[r,d])) * row_scale[r].  A quarter
+ * of the f32 HBM bytes.  The bytes are widened to f16 in registers (exactly) and multiplied with the
+ * hi + lo split f32 queries on f16 MFMA, so the only error is the index quantisation itself: results
+ * are exact w.r.t. the dequantised rows and are compared with the f32 index by overlap@k. */
+int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, int64_t N, int D,
+                        const float* row_scale, int k, int64_t row_id_base,
+                        float* out_score, int64_t* out_index,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.
  *   scores [P, Q, k] f32, ids [P, Q, k] i64  ->  out_score [Q, k], out_index [Q, k].

@@ -29,6 +29,35 @@ def row_inv_norm(embeddings: np.ndarray, eps: float) -> np.ndarray:
     return (np.float32(1.0) / np.maximum(norm, np.float32(eps))).astype(np.float32)
 
 
+def e4m3_decode_table() -> np.ndarray:
+    """All 256 OCP e4m3 ("e4m3fn") codes as f32: 1 sign, 4 exponent (bias 7), 3 mantissa bits;
+    exponent 0 is subnormal (m / 8 * 2^-6); 0x7F / 0xFF are NaN; no infinities; max finite 448.
+    (The fp8-storage index is this framework's own extension — BASELINE config 5 — so the codec is
+    restated from the OCP 8-bit floating point specification, not from the reference.)"""
+    c = np.arange(256)
+    e, m = (c >> 3) & 15, c & 7
+    mag = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7))
+    mag = np.where((c & 0x7F) == 0x7F, np.nan, mag)
+    return np.where(c & 0x80, -mag, mag).astype(np.float32)
+
+
+def quantize_rows_e4m3(x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-row symmetric e4m3 quantisation: scale = max|x| / 448 (1 for a zero row), code =
+    nearest e4m3 value of x / scale, ties to the even code, saturating at +-448."""
+    x = np.asarray(x, dtype=np.float32)
+    mx = np.max(np.abs(x), axis=1) if x.shape[1] else np.zeros(x.shape[0], np.float32)
+    scale = np.where(mx > 0, mx / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    v = (x / scale[:, None]).astype(np.float32)
+    pos = e4m3_decode_table()[:127].astype(np.float64)  # codes 0..126 ascend in value
+    a = np.minimum(np.abs(v).astype(np.float64), 448.0)
+    hi = np.clip(np.searchsorted(pos, a, side="left"), 1, 126)
+    lo = hi - 1
+    dl, dh = a - pos[lo], pos[hi] - a
+    code = np.where(dl < dh, lo, np.where(dh < dl, hi, np.where(lo % 2 == 0, lo, hi)))
+    code = np.where(a == 0, 0, code).astype(np.uint8)
+    return (code | np.where(np.signbit(v), 0x80, 0).astype(np.uint8)), scale
+
+
 def cosine_scores(queries: np.ndarray, index: np.ndarray, eps: float) -> np.ndarray:
     """[Q, N] f32 cosine of every query against every index row: normalise, then matmul — the
     generalisation of `torch.mv(rel_vecs, question_vec)` (build_retrieval_pipeline.py:871)."""

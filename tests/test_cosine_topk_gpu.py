@@ -102,6 +102,49 @@ def test_cosine_topk_f16_index_matches_oracle(dev, Q, N, D, k):
         ops.cosine_topk(qn[:, :48].contiguous(), x16[:, :48].contiguous(), 5)  # D % 32 != 0
 
 
+def test_quantize_rows_fp8_matches_oracle(dev):
+    from evi_rag_amd import ops
+
+    x = _make_index(3000, 192, seed=21)
+    x[5, :8] = [1e-9, -1e-9, 3.0, -3.0, 0.0, 1e-3, -1e-3, 2.9999]  # subnormal codes, signed zeros
+    codes, scale = ops.quantize_rows_fp8(torch.from_numpy(x).to(dev))
+    ref_c, ref_s = ocos.quantize_rows_e4m3(x)
+    np.testing.assert_array_equal(scale.cpu().numpy(), ref_s)
+    got = codes.cpu().numpy()
+    # -0 and +0 are the same value: compare the decoded values, then the codes away from zero
+    tab = ocos.e4m3_decode_table()
+    np.testing.assert_array_equal(tab[got], tab[ref_c])
+    assert not np.isnan(tab[got]).any()
+    assert np.abs(tab[got]).max() == 448.0 and scale[0].item() == 1.0
+
+
+@pytest.mark.parametrize("Q,N,D,k", [(32, 200000, 768, 500), (5, 1000, 64, 50), (17, 70001, 1024, 100)])
+def test_cosine_topk_fp8_index_matches_oracle(dev, Q, N, D, k):
+    """e4m3-storage index (BASELINE config 5): exact w.r.t. the dequantised rows; overlap@k vs f32."""
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N + D + 1)
+    q = np.random.default_rng(Q + 2).standard_normal((Q, D), dtype=np.float32)
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    codes, scale = ops.quantize_rows_fp8(xn)
+    sc, ids = ops.cosine_topk(qn, codes, k, row_scale=scale, row_id_base=7)
+    deq = ocos.e4m3_decode_table()[codes.cpu().numpy()].astype(np.float64)
+    ref_full = ((qn.cpu().numpy().astype(np.float64) @ deq.T) * scale.cpu().numpy().astype(np.float64)).astype(np.float32)
+    check_topk_against_scores(sc.cpu().numpy(), ids.cpu().numpy(), ref_full, k, id_base=7, score_tol=2e-6)
+    # quantisation quality against the f32 index: the retrieved sets mostly agree
+    s32, i32 = ops.cosine_topk(qn, xn, k, row_id_base=7)
+    m = min(k, N)
+    a, b = ids[:, :m].cpu().numpy(), i32[:, :m].cpu().numpy()
+    overlap = np.mean([len(np.intersect1d(a[r], b[r])) / m for r in range(Q)])
+    assert overlap > 0.8, overlap
+    assert float((sc[:, 0] - s32[:, 0]).abs().max()) < 2e-2
+    with pytest.raises(NotImplementedError):
+        ops.cosine_topk(qn[:, :32].contiguous(), codes[:, :32].contiguous(), 5, row_scale=scale)  # D % 64 != 0
+    with pytest.raises(ValueError):
+        ops.cosine_topk(qn, codes, 5)  # no scale
+
+
 def test_cosine_topk_row_scale_equals_prenormalised(dev):
     """raw index + row_scale (fused normalisation) returns the same ids as a normalised index."""
     from evi_rag_amd import ops
