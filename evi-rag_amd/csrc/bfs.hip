@@ -3,6 +3,7 @@
 //   evi_bfs_levels          _bfs_dist, scripts/build_retrieval_pipeline.py:610-631 (multi-source BFS
 //                           levels, unreachable = -1), over the undirected adjacency (:570-586) or
 //                           one directed half (:589-603)
+//   evi_shortest_path_single _shortest_path_single, :453-530 (deterministic single path, G4)
 //   evi_shortest_path_pairs _shortest_path_union_mask_by_pair / ..._directed + the edge predicates
 //                           _select_shortest_edges_undirected/_directed, :650-815: for every
 //                           (seed, answer) pair with a path, the edges u->v with
@@ -18,26 +19,15 @@ namespace evi {
 
 constexpr int kBfsThreads = 1024;
 
-// mode 0: undirected (out- and in-rows), 1: follow edges (out-rows), 2: against edges (in-rows)
-__global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
-    const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
-    const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ in_ptr,
-    const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
-    int mode, int32_t* __restrict__ dist_out) {
-    __shared__ int changed;
-    const int j = blockIdx.x, tid = threadIdx.x;
-    const int g = job_graph[j];
-    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
-    const int ng = (int)(n1 - n0);
-    int32_t* dist = dist_out + dist_off[j];  // local node id -> level
-    for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
-    __syncthreads();
-    for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
-        const int64_t s = src_idx[i];
-        if (s >= n0 && s < n1) dist[s - n0] = 0;  // out-of-range sources are ignored (:619)
-    }
+// Level-synchronous expansion of the sources already marked 0 in dist[0..ng) (everything else -1).
+// mode 0: undirected (out- and in-rows), 1: follow edges (out-rows), 2: against edges (in-rows).
+// Every thread of the workgroup calls; returns after the first empty frontier.
+__device__ inline void bfs_block(int32_t* __restrict__ dist, int ng, int64_t n0, const int32_t* __restrict__ in_ptr,
+                                 const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr,
+                                 const int32_t* __restrict__ out_nbr, int mode, int* changed) {
+    const int tid = threadIdx.x;
     for (int level = 0;; ++level) {
-        if (tid == 0) changed = 0;
+        if (tid == 0) *changed = 0;
         __syncthreads();
         bool any = false;
         for (int v = tid; v < ng; v += kBfsThreads) {
@@ -60,11 +50,117 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
                     }
                 }
         }
-        if (any) changed = 1;
+        if (any) *changed = 1;
         __syncthreads();
-        if (!changed) break;  // every wave reaches this: the frontier is empty
+        if (!*changed) break;  // every wave reaches this: the frontier is empty
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
+    const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
+    const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ in_ptr,
+    const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
+    int mode, int32_t* __restrict__ dist_out) {
+    __shared__ int changed;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int g = job_graph[j];
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    int32_t* dist = dist_out + dist_off[j];  // local node id -> level
+    for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
+    __syncthreads();
+    for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
+        const int64_t s = src_idx[i];
+        if (s >= n0 && s < n1) dist[s - n0] = 0;  // out-of-range sources are ignored (:619)
+    }
+    bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &changed);
+}
+
+// One workgroup per job (graph, source set, target set): the reference's deterministic single shortest
+// path (_shortest_path_single, :453-530).  Its FIFO BFS over (neighbour id, edge id)-sorted adjacency
+// visits each level in the lexicographic order of the tree paths, so the path it returns is the
+// lexicographically smallest node sequence among ALL shortest source->target paths, towards the
+// nearest target (ties: smallest id), and each hop uses the smallest edge id between its two nodes.
+// That characterisation needs no queue: BFS from the sources (ds), pick the target, BFS from it (dt),
+// then walk from the smallest source with dt == D, each hop taking the smallest neighbour with
+// dt == D - i (min over the CSR row of (neighbour, edge id)).
+__global__ __launch_bounds__(kBfsThreads) void k_shortest_path_single(
+    const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
+    const int64_t* __restrict__ tgt_ptr, const int64_t* __restrict__ tgt_idx, const int64_t* __restrict__ dist_off,
+    const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr, const int32_t* __restrict__ in_ptr,
+    const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ in_eid, const int32_t* __restrict__ out_ptr,
+    const int32_t* __restrict__ out_nbr, const int32_t* __restrict__ out_eid, int32_t* __restrict__ dist_ws, int path_cap,
+    int32_t* __restrict__ out_len, int64_t* __restrict__ out_nodes, int64_t* __restrict__ out_edges) {
+    __shared__ int changed;
+    __shared__ unsigned long long best;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int g = job_graph[j];
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1], e0 = edge_ptr[g];
+    const int ng = (int)(n1 - n0);
+    int32_t* ds = dist_ws + dist_off[j];
+    int32_t* dt = ds + ng;
+    int64_t* nodes = out_nodes + (int64_t)j * (path_cap + 1);
+    int64_t* edges = out_edges + (int64_t)j * path_cap;
+    constexpr unsigned long long kNone = ~0ull;
+    for (int v = tid; v < ng; v += kBfsThreads) ds[v] = dt[v] = -1;
+    if (tid == 0) best = kNone;
+    __syncthreads();
+    for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
+        const int64_t s = src_idx[i];
+        if (s >= n0 && s < n1) ds[s - n0] = 0;
+    }
+    bfs_block(ds, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, 0, &changed);
+    // nearest reachable target, smallest id on ties (:501-508)
+    for (int64_t i = tgt_ptr[j] + tid; i < tgt_ptr[j + 1]; i += kBfsThreads) {
+        const int64_t t = tgt_idx[i];
+        if (t < n0 || t >= n1) continue;
+        const int d = ds[t - n0];
+        if (d >= 0) atomicMin(&best, ((unsigned long long)d << 32) | (unsigned long long)(t - n0));
+    }
+    __syncthreads();
+    const unsigned long long tb = best;
+    __syncthreads();
+    if (tb == kNone) {  // no sources, no targets, or no path (uniform across the workgroup)
+        if (tid == 0) out_len[j] = -1;
+        return;
+    }
+    const int D = (int)(tb >> 32), target = (int)(tb & 0xffffffffu);
+    if (tid == 0) {
+        dt[target] = 0;
+        best = kNone;
+    }
+    bfs_block(dt, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, 0, &changed);
+    for (int v = tid; v < ng; v += kBfsThreads)
+        if (ds[v] == 0 && dt[v] == D) atomicMin(&best, (unsigned long long)v);
+    __syncthreads();
+    int cur = (int)best;
+    __syncthreads();
+    if (tid == 0) nodes[0] = cur;
+    for (int i = 1; i <= D; ++i) {
+        if (tid == 0) best = kNone;
+        __syncthreads();
+        const int64_t gv = n0 + cur;
+        for (int p = out_ptr[gv] + tid; p < out_ptr[gv + 1]; p += kBfsThreads) {
+            const int w = out_nbr[p] - (int)n0;
+            if (dt[w] == D - i && ds[w] == i)
+                atomicMin(&best, ((unsigned long long)w << 32) | (unsigned long long)(out_eid[p] - e0));
+        }
+        for (int p = in_ptr[gv] + tid; p < in_ptr[gv + 1]; p += kBfsThreads) {
+            const int w = in_nbr[p] - (int)n0;
+            if (dt[w] == D - i && ds[w] == i)
+                atomicMin(&best, ((unsigned long long)w << 32) | (unsigned long long)(in_eid[p] - e0));
+        }
+        __syncthreads();
+        const unsigned long long nb = best;
+        __syncthreads();
+        cur = (int)(nb >> 32);
+        if (tid == 0 && i <= path_cap) {
+            nodes[i] = cur;
+            edges[i - 1] = (int64_t)(nb & 0xffffffffu);
+        }
+    }
+    if (tid == 0) out_len[j] = D;
 }
 
 // One workgroup per dense pair slot p = (graph g, i-th seed job of g, j-th answer job of g).
@@ -152,6 +248,25 @@ extern "C" int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, 
     EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels: null pointer");
     hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), 0, reinterpret_cast<hipStream_t>(stream),
                        job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, mode, dist_out);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_shortest_path_single(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
+                                        const int64_t* tgt_ptr, const int64_t* tgt_idx, const int64_t* dist_off,
+                                        int num_jobs, const int64_t* node_ptr, const int64_t* edge_ptr,
+                                        const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* in_eid,
+                                        const int32_t* out_ptr, const int32_t* out_nbr, const int32_t* out_eid,
+                                        int32_t* dist_ws, int path_cap, int32_t* out_len, int64_t* out_nodes,
+                                        int64_t* out_edges, void* stream) {
+    EVI_REQUIRE(num_jobs >= 0 && path_cap >= 1, "evi_shortest_path_single: need num_jobs >= 0 and path_cap >= 1");
+    if (num_jobs == 0) return EVI_OK;
+    EVI_REQUIRE(job_graph && src_ptr && tgt_ptr && dist_off && node_ptr && edge_ptr && in_ptr && out_ptr && dist_ws &&
+                    out_len && out_nodes && out_edges,
+                "evi_shortest_path_single: null pointer");
+    hipLaunchKernelGGL(k_shortest_path_single, dim3(num_jobs), dim3(kBfsThreads), 0, reinterpret_cast<hipStream_t>(stream),
+                       job_graph, src_ptr, src_idx, tgt_ptr, tgt_idx, dist_off, node_ptr, edge_ptr, in_ptr, in_nbr, in_eid,
+                       out_ptr, out_nbr, out_eid, dist_ws, path_cap, out_len, out_nodes, out_edges);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -452,6 +452,26 @@ static int launch_score_v(const ScanVariant& v, int U, const ScoreArgs& a) {
     return v.nt ? launch_score_u<NQB, 512, 1>(U, a) : launch_score_u<NQB, 512, 0>(U, a);
 }
 
+// Segment schedule knobs (tuning only; results do not depend on them):
+//   EVI_SCAN_FIRST   rows of the dense first segment, [4096, 65536] (default 65536)
+//   EVI_SCAN_GROWTH  next segment = growth x rows scanned so far, [2, 256] (default 16)
+struct SegmentSchedule {
+    int64_t first, growth;
+};
+static SegmentSchedule segment_schedule() {
+    static SegmentSchedule s{0, 0};
+    if (s.first == 0) {
+        int64_t first = kFirstSegment, growth = kSegmentGrowth;
+        if (const char* e = getenv("EVI_SCAN_FIRST")) first = atoll(e);
+        if (const char* e = getenv("EVI_SCAN_GROWTH")) growth = atoll(e);
+        first = first < 4096 ? 4096 : (first > kFirstSegment ? kFirstSegment : first);
+        first = (first + 15) / 16 * 16;
+        growth = growth < 2 ? 2 : (growth > 256 ? 256 : growth);
+        s = SegmentSchedule{first, growth};
+    }
+    return s;
+}
+
 static int device_cu_count() {
     static int cus = 0;
     if (cus == 0) {
@@ -564,7 +584,8 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
         capq = capq > 64 ? 64 : (capq < 0 ? 0 : capq);
         const size_t lds = lds_q_bytes + kQueryBlock * sizeof(int) + (size_t)kQueryBlock * capq * 8;
         int64_t begin = 0;
-        int64_t seg = clamp_seg(N, kFirstSegment);
+        const SegmentSchedule sched = segment_schedule();
+        int64_t seg = clamp_seg(N, sched.first);
         bool first = true;
         while (begin < N) {
             int64_t end = begin + seg;
@@ -589,7 +610,7 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
             EVI_LAUNCH_CHECK();
             begin = end;
             first = false;
-            int64_t next = begin * kSegmentGrowth;
+            int64_t next = begin * sched.growth;
             seg = next < seg_max ? next : seg_max;
             if (seg < 1) seg = 1;
         }

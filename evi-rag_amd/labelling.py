@@ -1,6 +1,7 @@
 """Host-side mirrors of the graph labelling and edge-selection helpers, backed by the CSR kernels.
 
   bfs_dist / shortest_path_union_mask_by_pair     scripts/build_retrieval_pipeline.py:610-631, 691-830
+  shortest_path_single / has_connectivity         scripts/build_retrieval_pipeline.py:453-530, 946-979
   node_softmax_logit / select_topk_edges / select_start_edges
                                                    GAgentBuilder statics, src/data/components/g_agent_builder.py:595-724
   seed_onehop_stats                                scripts/seed_onehop_stats.py:96-117
@@ -199,6 +200,95 @@ def shortest_path_union_mask_by_pair(num_nodes: int, edge_src: Sequence[int], ed
     return mask.tolist(), ps, pa, pe, pc, pl
 
 
+# ---- G4: deterministic single shortest path, connectivity ----------------------------------------------
+
+def shortest_path_single_batch(gb: GraphBatch, sources: Sequence[Sequence[int]], targets: Sequence[Sequence[int]],
+                               *, path_cap: int = 32) -> List[Tuple[List[int], List[int]]]:
+    """Per graph (edge ids, node ids) of the reference's single shortest path; sources / targets are
+    LOCAL node ids.  ([], []) when there is no path; ([], [node]) when a target is itself a source."""
+    dev = gb.device
+    B = gb.B
+    if B == 0:
+        return []
+
+    def flat(lists):
+        ptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        idx = np.concatenate(lists).astype(np.int64) if ptr[-1] > 0 else np.empty(0, np.int64)
+        return ptr, idx
+
+    def to_global(lists):
+        out = []
+        for g in range(B):
+            v = np.asarray(list(lists[g]), np.int64).reshape(-1)
+            n = gb.node_ptr_h[g + 1] - gb.node_ptr_h[g]
+            out.append(v[(v >= 0) & (v < n)] + gb.node_ptr_h[g])
+        return out
+
+    sp, si = flat(to_global(sources))
+    tp, ti = flat(to_global(targets))
+    sizes = gb.node_ptr_h[1:] - gb.node_ptr_h[:-1]
+    dist_off = np.concatenate([[0], np.cumsum(2 * sizes)]).astype(np.int64)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)  # noqa: E731
+    jg = torch.arange(B, dtype=torch.int32, device=dev)
+    sp_t, si_t, tp_t, ti_t, do_t = t(sp, torch.int64), t(si, torch.int64), t(tp, torch.int64), t(ti, torch.int64), t(dist_off[:-1], torch.int64)
+    ws = torch.empty(max(int(dist_off[-1]), 1), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    c = gb.csr
+    while True:
+        out_len = torch.empty(B, dtype=torch.int32, device=dev)
+        out_nodes = torch.empty((B, path_cap + 1), dtype=torch.int64, device=dev)
+        out_edges = torch.empty((B, path_cap), dtype=torch.int64, device=dev)
+        _lib.check(lib.evi_shortest_path_single(
+            ops._ptr(jg), ops._ptr(sp_t), ops._ptr(si_t), ops._ptr(tp_t), ops._ptr(ti_t), ops._ptr(do_t), B,
+            ops._ptr(gb.node_ptr), ops._ptr(gb.edge_ptr), c.in_ptr.data_ptr(), c.in_nbr.data_ptr(), c.in_eid.data_ptr(),
+            c.out_ptr.data_ptr(), c.out_nbr.data_ptr(), c.out_eid.data_ptr(), ws.data_ptr(), int(path_cap),
+            out_len.data_ptr(), out_nodes.data_ptr(), out_edges.data_ptr(), ops._stream(dev)))
+        lens = out_len.cpu().numpy()
+        if lens.size == 0 or int(lens.max()) <= path_cap:
+            break
+        path_cap = int(lens.max())  # a longer path than the buffer: rerun once with room for it
+    nodes_h, edges_h = out_nodes.cpu().numpy(), out_edges.cpu().numpy()
+    results = []
+    for g in range(B):
+        L = int(lens[g])
+        if L < 0:
+            results.append(([], []))
+            continue
+        edges = gb.valid_ids[g][edges_h[g, :L]].tolist()  # back to positions in the caller's edge list
+        results.append((edges, nodes_h[g, : L + 1].tolist()))
+    return results
+
+
+def shortest_path_single(num_nodes: int, edge_src: Sequence[int], edge_dst: Sequence[int], sources: Sequence[int],
+                         targets: Sequence[int]) -> Tuple[List[int], List[int]]:
+    """reference: _shortest_path_single, scripts/build_retrieval_pipeline.py:453-530."""
+    if not len(sources) or not len(targets) or num_nodes <= 0:
+        return [], []
+    gb = GraphBatch([num_nodes], [np.asarray(edge_src)], [np.asarray(edge_dst)])
+    return shortest_path_single_batch(gb, [sources], [targets])[0]
+
+
+def has_connectivity(graph: Sequence[Tuple[str, str, str]], seeds: Sequence[str], answers: Sequence[str], *,
+                     path_mode: str = "undirected") -> bool:
+    """Whether any answer is reachable from the seeds (local indexing in first-seen order).
+    reference: has_connectivity, scripts/build_retrieval_pipeline.py:946-979."""
+    if not graph or not seeds or not answers:
+        return False
+    if path_mode not in ("undirected", "qa_directed"):
+        raise ValueError(f"Unsupported path_mode: {path_mode}. Expected one of ('undirected', 'qa_directed').")
+    node_index = {}
+    src, dst = [], []
+    for h, _, t in graph:
+        src.append(node_index.setdefault(h, len(node_index)))
+        dst.append(node_index.setdefault(t, len(node_index)))
+    seed_ids = [node_index[s] for s in seeds if s in node_index]
+    answer_ids = [node_index[a] for a in answers if a in node_index]
+    if not seed_ids or not answer_ids:
+        return False
+    dist = bfs_dist(len(node_index), src, dst, seed_ids, directed=path_mode == "qa_directed")
+    return any(dist[a] >= 0 for a in answer_ids)
+
+
 # ---- C2-C4: canonical edge selection --------------------------------------------------------------------
 
 def canonicalize_positive_edges(edge_src: Sequence[int], edge_dst: Sequence[int], edge_relation_ids: Sequence[int],
@@ -341,5 +431,6 @@ def seed_onehop_stats(heads: torch.Tensor, tails: torch.Tensor, labels: torch.Te
 
 
 __all__ = ["GraphBatch", "canonicalize_positive_edges", "bfs_dist", "bfs_dist_batch", "shortest_path_union_mask_by_pair",
+           "shortest_path_single", "shortest_path_single_batch", "has_connectivity",
            "shortest_path_union_mask_by_pair_batch", "node_softmax_logit", "select_topk_edges", "select_start_edges",
            "seed_onehop_stats"]

@@ -332,6 +332,79 @@ def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: Gr
     return ns
 
 
+# ---- segmented de-duplication / re-indexing (G5, f2) -------------------------------------------------
+
+def first_occurrence(keys: torch.Tensor, seg_ptr: torch.Tensor, drop: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """first[p] = segment-local position of the first entry with p's key (keys [T] or [T, W<=3] i64);
+    -1 where drop[p].  See evi_first_occurrence."""
+    dev = _require_gpu(keys, seg_ptr)
+    k = _i64c(keys if keys.dim() == 2 else keys.view(-1, 1), "keys")
+    ptr = _i64c(seg_ptr.view(-1), "seg_ptr")
+    T, W, S = k.size(0), k.size(1), ptr.numel() - 1
+    first = torch.empty(T, dtype=torch.int32, device=dev)
+    if T == 0 or S <= 0:
+        return first
+    d = None
+    if drop is not None:
+        d = drop.to(device=dev, dtype=torch.uint8).contiguous().view(-1)
+        if d.numel() != T:
+            raise ValueError(f"drop must have one entry per key ({T}), got {d.numel()}")
+    lib = _lib.load()
+    ws = _workspace(dev, "first_occurrence", int(lib.evi_first_occurrence_workspace_bytes(T, S)))
+    _lib.check(lib.evi_first_occurrence(_ptr(k), W, T, _ptr(ptr), S, _ptr(d), _ptr(first), ws.data_ptr(), ws.numel(),
+                                        _stream(dev)))
+    return first
+
+
+def first_seen_rank(first: torch.Tensor, seg_ptr: torch.Tensor, limit: Optional[torch.Tensor] = None):
+    """(rank [T] i32, count [S] i32, uniq_pos [T] i32) from first_occurrence's output: ids in first-seen
+    order, distinct keys per segment, and the position of each distinct key.  See evi_first_seen_rank."""
+    dev = _require_gpu(first, seg_ptr)
+    ptr = _i64c(seg_ptr.view(-1), "seg_ptr")
+    T, S = first.numel(), ptr.numel() - 1
+    rank = torch.empty(T, dtype=torch.int32, device=dev)
+    count = torch.zeros(max(S, 0), dtype=torch.int32, device=dev)
+    uniq = torch.empty(T, dtype=torch.int32, device=dev)
+    if S <= 0:
+        return rank, count, uniq
+    lim = None if limit is None else _i64c(limit.to(dev).view(-1), "limit")
+    lib = _lib.load()
+    _lib.check(lib.evi_first_seen_rank(_ptr(first.contiguous()), T, _ptr(ptr), S, _ptr(lim), _ptr(rank), _ptr(count),
+                                       _ptr(uniq), _stream(dev)))
+    return rank, count, uniq
+
+
+def segment_sort_rank(keys: torch.Tensor, seg_ptr: torch.Tensor, seg_len: Optional[torch.Tensor] = None):
+    """(rank [T] i32, sorted [T] i64): stable ascending position of the first seg_len[s] keys of each
+    segment and the sorted keys (entries beyond seg_len are left untouched)."""
+    dev = _require_gpu(keys, seg_ptr)
+    k = _i64c(keys.view(-1), "keys")
+    ptr = _i64c(seg_ptr.view(-1), "seg_ptr")
+    T, S = k.numel(), ptr.numel() - 1
+    rank = torch.empty(T, dtype=torch.int32, device=dev)
+    srt = torch.empty(T, dtype=torch.int64, device=dev)
+    if T == 0 or S <= 0:
+        return rank, srt
+    sl = None if seg_len is None else seg_len.to(device=dev, dtype=torch.int32).contiguous()
+    lib = _lib.load()
+    _lib.check(lib.evi_segment_sort_rank(_ptr(k), T, _ptr(ptr), _ptr(sl), S, _ptr(rank), _ptr(srt), _stream(dev)))
+    return rank, srt
+
+
+def group_max(values: torch.Tensor, group: torch.Tensor, num_groups: int) -> torch.Tensor:
+    """out[g] = max of values[i] with group[i] == g (group < 0 skipped); -inf for empty groups."""
+    dev = _require_gpu(values, group)
+    v = _f32c(values.view(-1), "values")
+    g = group.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+    if g.numel() != v.numel():
+        raise ValueError("values and group must have the same length")
+    out = torch.full((int(num_groups),), float("-inf"), dtype=torch.float32, device=dev)
+    if v.numel():
+        lib = _lib.load()
+        _lib.check(lib.evi_group_max_f32(_ptr(v), _ptr(g), v.numel(), _ptr(out), _stream(dev)))
+    return out
+
+
 # ---- dense building block --------------------------------------------------------------------------
 
 _ACT = {None: 0, "none": 0, "tanh": 1, "sigmoid": 2}

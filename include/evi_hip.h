@@ -270,6 +270,54 @@ int evi_shortest_path_pairs(int pass, const int32_t* pair_graph, const int32_t* 
                             int32_t* pair_edge_count, uint8_t* edge_mask, const int64_t* pair_edge_off,
                             int64_t* pair_edge_ids, void* stream);
 
+/* The reference's deterministic single shortest path between a source set and a target set over the
+ * undirected graph (G4).  Job j works on graph job_graph[j] with batch-global sources
+ * src_idx[src_ptr[j]..) and targets tgt_idx[tgt_ptr[j]..) (out-of-range ids are ignored) and uses
+ * dist_ws[dist_off[j] .. + 2 * N_g) as scratch.  out_len[j] = number of edges (-1: no source, no
+ * target or no path); out_nodes[j, 0..len] graph-local node ids from the source side;
+ * out_edges[j, 0..len) graph-local edge ids.  A path longer than path_cap is reported through
+ * out_len only (its first path_cap hops are written).  The target is the nearest reachable one
+ * (ties: smallest id); the path is the lexicographically smallest node sequence among all shortest
+ * paths, each hop on the smallest edge id joining its two nodes — what the reference's FIFO BFS over
+ * (neighbour, edge id)-sorted adjacency returns.  CSR (with edge ids) from evi_graph_csr.
+ * Replaces _shortest_path_single, scripts/build_retrieval_pipeline.py:453-530. */
+int evi_shortest_path_single(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
+                             const int64_t* tgt_ptr, const int64_t* tgt_idx, const int64_t* dist_off, int num_jobs,
+                             const int64_t* node_ptr, const int64_t* edge_ptr, const int32_t* in_ptr,
+                             const int32_t* in_nbr, const int32_t* in_eid, const int32_t* out_ptr,
+                             const int32_t* out_nbr, const int32_t* out_eid, int32_t* dist_ws, int path_cap,
+                             int32_t* out_len, int64_t* out_nodes, int64_t* out_edges, void* stream);
+
+/* ---- G5 / f2: segmented de-duplication and re-indexing ------------------------------------------- */
+
+/* keys [T, W] i64 row-major (W = 1, 2 or 3 words), segments seg_ptr [S+1].  out_first[p] = the
+ * segment-local position of the first entry of p's segment with the same key and drop == 0
+ * (-1 for entries with drop[p] != 0; drop may be null).  The dict / set bookkeeping of build_graph
+ * (node_index, edge_key_to_indices: scripts/build_retrieval_pipeline.py:1465-1497) and of
+ * GAgentBuilder._build_and_add_sample (triple_to_agg: src/data/components/g_agent_builder.py:338-354). */
+size_t evi_first_occurrence_workspace_bytes(int64_t T, int S);
+int evi_first_occurrence(const int64_t* keys, int W, int64_t T, const int64_t* seg_ptr, int S,
+                         const uint8_t* drop, int32_t* out_first, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* From out_first: out_rank[p] = index of p's key in first-seen order (the reference's
+ * local_index(), :1470-1476; list(triple_to_agg.keys()), g_agent_builder.py:356), out_count[s] = number
+ * of distinct keys, out_uniq_pos[seg_ptr[s] + r] = segment-local position of the r-th distinct key
+ * (may be null).  With limit (may be null), only positions < limit[s] found new keys; later entries
+ * are look-ups that take the rank of the entry they match, or -1. */
+int evi_first_seen_rank(const int32_t* first, int64_t T, const int64_t* seg_ptr, int S, const int64_t* limit,
+                        int32_t* out_rank, int32_t* out_count, int32_t* out_uniq_pos, void* stream);
+
+/* Stable ascending sort position of each of the first seg_len[s] (null: all) keys of every segment,
+ * and the sorted keys (out_sorted may be null).  Replaces torch.sort(torch.cat([heads, tails]).unique())
+ * and node_map, src/data/components/g_agent_builder.py:368-371. */
+int evi_segment_sort_rank(const int64_t* keys, int64_t T, const int64_t* seg_ptr, const int32_t* seg_len, int S,
+                          int32_t* out_rank, int64_t* out_sorted, void* stream);
+
+/* out[group[i]] = max(out[group[i]], values[i]) for group[i] >= 0; the caller pre-fills out (-inf).
+ * Replaces the score / label max aggregation at src/data/components/g_agent_builder.py:353-354. */
+int evi_group_max_f32(const float* values, const int32_t* group, int64_t T, float* out, void* stream);
+
 /* ---- G8/G9/G10: seed expansion and score post-processing ----------------------------------------- */
 
 /* logit of p = (softmax of the score over the head's out-edges + softmax over the tail's in-edges)/2,

@@ -410,3 +410,62 @@ def compute_qa_edge_mask(edge_index: np.ndarray, num_nodes: int, q_local_indices
     node_mask = np.zeros(num_nodes, dtype=bool)
     node_mask[qa] = True
     return node_mask[edge_index[0]] | node_mask[edge_index[1]]
+
+
+# ---- G5: build_graph (id-coded) ---------------------------------------------------------------------------
+def build_graph_ids(triples, q_entities, a_entities, answer_subgraph, ent_struct, ent_emb, *, directed: bool = False,
+                    dedup_edges: bool = True, remove_self_loops: bool = True):
+    """The integer core of build_graph: `triples` [T, 3] = (entity index, relation id, entity index)
+    in sample order; entities are indices into ent_struct / ent_emb (the vocabulary lookups).
+    Local node ids are assigned in first-seen order (head, then tail, of each KEPT edge); self loops
+    and repeated (h, r, t) triples are dropped before indexing; positives come from the
+    answer_subgraph edges when they yield at least one (seed, answer) pair, else from the whole graph.
+    reference: build_graph, scripts/build_retrieval_pipeline.py:1450-1603."""
+    node_index = {}
+    node_entity_ids: List[int] = []
+    node_embedding_ids: List[int] = []
+
+    def local_index(ent: int) -> int:
+        if ent not in node_index:
+            node_index[ent] = len(node_entity_ids)
+            node_entity_ids.append(int(ent_struct[ent]))
+            node_embedding_ids.append(int(ent_emb[ent]))
+        return node_index[ent]
+
+    edge_src: List[int] = []
+    edge_dst: List[int] = []
+    edge_rel: List[int] = []
+    key_to_indices = {}
+    for h, r, t in (tuple(int(v) for v in row) for row in np.asarray(triples, np.int64).reshape(-1, 3)):
+        if remove_self_loops and h == t:
+            continue
+        key = (h, r, t)
+        if dedup_edges and key in key_to_indices:
+            continue
+        edge_src.append(local_index(h))
+        edge_dst.append(local_index(t))
+        edge_rel.append(r)
+        key_to_indices.setdefault(key, []).append(len(edge_src) - 1)
+    q_local = [node_index[int(e)] for e in q_entities if int(e) in node_index]
+    a_local = [node_index[int(e)] for e in a_entities if int(e) in node_index]
+    answer_edges: List[int] = []
+    for row in np.asarray(answer_subgraph, np.int64).reshape(-1, 3):
+        answer_edges.extend(key_to_indices.get(tuple(int(v) for v in row), []))
+    n = len(node_entity_ids)
+    full = None
+    if answer_edges:
+        sub = list(dict.fromkeys(answer_edges))  # order-preserving dedup (:1520-1526)
+        mask, ps, pa, pe, pc, pl = shortest_path_union_mask_by_pair(
+            n, [edge_src[i] for i in sub], [edge_dst[i] for i in sub], q_local, a_local, directed=directed)
+        if len(ps) > 0:
+            positive = [False] * len(edge_src)
+            for j, keep in enumerate(mask):
+                if keep:
+                    positive[sub[j]] = True
+            full = (positive, ps, pa, [sub[j] for j in pe], pc, pl)
+    if full is None:
+        full = shortest_path_union_mask_by_pair(n, edge_src, edge_dst, q_local, a_local, directed=directed)
+    positive, ps, pa, pe, pc, pl = full
+    return {"node_entity_ids": node_entity_ids, "node_embedding_ids": node_embedding_ids, "edge_src": edge_src,
+            "edge_dst": edge_dst, "edge_rel": edge_rel, "positive": list(positive), "pair_start": ps, "pair_answer": pa,
+            "pair_edges": pe, "pair_counts": pc, "pair_len": pl}

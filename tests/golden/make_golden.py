@@ -324,6 +324,144 @@ def gen_g_agent(batch, logits):
     save("g_agent_select", scores=scores.numpy(), **arrays, **batch_arrays(batch, "b_"))
 
 
+# ---- G5: build_graph ----------------------------------------------------------------------------------
+def gen_build_graph():
+    """Runs the reference's build_graph on string samples; stores the id-coded inputs and the record."""
+    rng = np.random.default_rng(404)
+    n_ent, n_rel = 60, 7
+    ents = [f"m.{i:03d}" for i in range(n_ent)]
+    rels = [f"rel.{i}" for i in range(n_rel)]
+    struct = {e: 1000 + 3 * i for i, e in enumerate(ents)}            # structural entity ids (arbitrary, unique)
+    emb = {e: (i + 1 if i % 3 else 0) for i, e in enumerate(ents)}    # 0 = non-text entity
+    ent_lookup = brp.EntityLookup(entity_to_struct=struct, text_kg_id_to_embed_id={e: v for e, v in emb.items() if v})
+    rel_lookup = brp.RelationLookup(rel_to_id={r: 5 + i for i, r in enumerate(rels)})
+    arrays = {"ent_struct": np.asarray([struct[e] for e in ents], np.int64),
+              "ent_emb": np.asarray([emb[e] for e in ents], np.int64)}
+    cases = []
+    for c, (n_trip, n_pool, mode, dedup, noloop, sub) in enumerate([
+            (40, 14, "undirected", True, True, "none"), (80, 20, "undirected", True, True, "some"),
+            (80, 20, "qa_directed", True, True, "some"), (30, 10, "undirected", False, False, "some"),
+            (50, 25, "undirected", True, False, "absent"), (0, 5, "undirected", True, True, "none"),
+            (120, 30, "qa_directed", False, True, "none"), (60, 12, "undirected", True, True, "nopath")]):
+        pool = rng.choice(n_ent, size=n_pool, replace=False)
+        h = pool[rng.integers(0, n_pool, size=n_trip)]
+        t = pool[rng.integers(0, n_pool, size=n_trip)]
+        r = rng.integers(0, n_rel, size=n_trip)
+        if n_trip > 10:
+            t[3] = h[3]                                   # self loop
+            h[7], r[7], t[7] = h[2], r[2], t[2]           # duplicate triple
+            h[9], r[9], t[9] = h[2], r[2], t[2]
+        graph = [(ents[a], rels[b], ents[d]) for a, b, d in zip(h, r, t)]
+        q_ent = [ents[i] for i in rng.choice(pool, size=min(2, n_pool), replace=False)] + [ents[(int(pool[0]) + 1) % n_ent]]
+        a_ent = [ents[i] for i in rng.choice(pool, size=min(3, n_pool), replace=False)]
+        if sub == "some" and n_trip:
+            pick = rng.choice(n_trip, size=n_trip // 2, replace=False)
+            asub = [graph[i] for i in pick] + [(ents[0], rels[0], ents[1])]
+        elif sub == "absent":
+            asub = [(ents[0], rels[0], ents[0])]
+        elif sub == "nopath" and n_trip:
+            asub = [graph[0]]
+        else:
+            asub = []
+        sample = brp.Sample(dataset="syn", split="train", question_id=f"q{c}", kb="fb", question="?", graph=graph,
+                            q_entity=q_ent, a_entity=a_ent, answer_texts=[], answer_subgraph=asub)
+        rec = brp.build_graph(sample, ent_lookup, rel_lookup, f"syn/train/q{c}", path_mode=mode, dedup_edges=dedup,
+                              validate_graph_edges=True, remove_self_loops=noloop)
+        e2i = {e: i for i, e in enumerate(ents)}
+        arrays.update({
+            f"c{c}_triples": np.asarray([[e2i[a], rel_lookup.rel_to_id[b], e2i[d]] for a, b, d in graph], np.int64).reshape(-1, 3),
+            f"c{c}_q": np.asarray([e2i[e] for e in q_ent], np.int64), f"c{c}_a": np.asarray([e2i[e] for e in a_ent], np.int64),
+            f"c{c}_asub": np.asarray([[e2i[a], rel_lookup.rel_to_id[b], e2i[d]] for a, b, d in asub], np.int64).reshape(-1, 3),
+            f"c{c}_directed": mode == "qa_directed", f"c{c}_dedup": dedup, f"c{c}_noloop": noloop,
+            f"c{c}_node_entity_ids": np.asarray(rec.node_entity_ids, np.int64),
+            f"c{c}_node_embedding_ids": np.asarray(rec.node_embedding_ids, np.int64),
+            f"c{c}_edge_src": np.asarray(rec.edge_src, np.int64), f"c{c}_edge_dst": np.asarray(rec.edge_dst, np.int64),
+            f"c{c}_edge_rel": np.asarray(rec.edge_relation_ids, np.int64),
+            f"c{c}_positive": np.asarray(rec.positive_triple_mask, bool),
+            f"c{c}_pair_start": np.asarray(rec.pair_start_node_locals, np.int64),
+            f"c{c}_pair_answer": np.asarray(rec.pair_answer_node_locals, np.int64),
+            f"c{c}_pair_edges": np.asarray(rec.pair_edge_local_ids, np.int64),
+            f"c{c}_pair_counts": np.asarray(rec.pair_edge_counts, np.int64),
+            f"c{c}_pair_len": np.asarray(rec.pair_shortest_lengths, np.int64),
+        })
+        cases.append(c)
+    # triples are stored with ENTITY INDEX (0..n_ent) in columns 0/2; ent_struct / ent_emb map it to ids
+    save("build_graph", num_cases=len(cases), **arrays)
+
+
+# ---- f2: GAgentBuilder.process_batch / _build_and_add_sample -------------------------------------------
+class _FakeStore:
+    def __init__(self, samples):
+        self.samples = samples
+
+    def load_sample(self, sample_id):
+        return self.samples[sample_id]
+
+
+def gen_g_agent_build():
+    from src.data.components.g_agent_builder import GAgentSettings
+
+    rng = np.random.default_rng(505)
+    base = synthetic.make_batch(5, nodes_per_graph=50, edges_per_graph=140, emb_dim=8, num_relations=6, seed=11)
+    # re-assemble the batch with a few duplicated (h, r, t) edges per graph (different scores / labels)
+    ei, ea, lab, eptr = [], [], [], [0]
+    for g in range(base.num_graphs):
+        lo, hi = int(base.edge_ptr[g]), int(base.edge_ptr[g + 1])
+        idx = np.arange(lo, hi)
+        dup = rng.choice(idx, size=12, replace=False)
+        order = rng.permutation(np.concatenate([idx, dup]))
+        ei.append(base.edge_index[:, order])
+        ea.append(base.edge_attr[order])
+        lab.append((rng.random(order.size) < 0.2).astype(np.float32))
+        eptr.append(eptr[-1] + order.size)
+    edge_index = np.concatenate(ei, axis=1)
+    edge_attr, labels, edge_ptr = np.concatenate(ea), np.concatenate(lab), np.asarray(eptr, np.int64)
+    E = edge_index.shape[1]
+    logits = rng.standard_normal(E).astype(np.float32)
+    query_ids = np.repeat(np.arange(base.num_graphs), np.diff(edge_ptr))
+    sample_ids = [f"s{g}" for g in range(base.num_graphs)]
+    store = {}
+    seeds_all, answers_all = [], []
+    for g in range(base.num_graphs):
+        q = base.q_local_indices[int(base.q_ptr[g]): int(base.q_ptr[g + 1])]
+        seeds = base.node_global_ids[q].tolist() + [987654321]                       # one seed outside the graph
+        ans = base.answer_entity_ids[int(base.answer_ptr[g]): int(base.answer_ptr[g + 1])].tolist()
+        ans = ans + ans[:1] + [123456789]                                            # duplicate + unknown answer
+        if g == 3:
+            ans = [123456789]                                                        # no answer inside the graph
+        store[sample_ids[g]] = {"question_emb": base.question_emb[g].tolist(), "question": f"question {g}",
+                                "seed_entity_ids": seeds, "answer_entity_ids": ans}
+        seeds_all.append(np.asarray(seeds, np.int64))
+        answers_all.append(np.asarray(ans, np.int64))
+    batch = types.SimpleNamespace(
+        ptr=torch.from_numpy(base.ptr), edge_index=torch.from_numpy(edge_index), edge_attr=torch.from_numpy(edge_attr),
+        labels=torch.from_numpy(labels), node_global_ids=torch.from_numpy(base.node_global_ids),
+        node_embedding_ids=torch.from_numpy(base.node_embedding_ids), sample_id=sample_ids)
+    out = types.SimpleNamespace(logits=torch.from_numpy(logits), query_ids=torch.from_numpy(query_ids))
+    arrays = {"ptr": base.ptr, "edge_index": edge_index, "edge_attr": edge_attr, "labels": labels, "edge_ptr": edge_ptr,
+              "node_global_ids": base.node_global_ids, "node_embedding_ids": base.node_embedding_ids, "logits": logits,
+              "query_ids": query_ids, "question_emb": base.question_emb, "num_graphs": base.num_graphs,
+              "seed_ptr": np.cumsum([0] + [len(s) for s in seeds_all]), "seeds": np.concatenate(seeds_all),
+              "ans_ptr": np.cumsum([0] + [len(a) for a in answers_all]), "answers": np.concatenate(answers_all)}
+    configs = [dict(edge_top_k=20, start_keep_ratio=0.25, start_min_edges=1, allow_empty_answer=False),
+               dict(edge_top_k=500, start_keep_ratio=0.5, start_min_edges=2, start_max_edges=4, allow_empty_answer=True,
+                    score_mode="logits", score_temperature=2.0, score_bias=0.5)]
+    for ci, cfg in enumerate(configs):
+        b = GAgentBuilder(GAgentSettings(**cfg), embedding_store=_FakeStore(store))
+        b.process_batch(batch, out)
+        arrays[f"cfg{ci}_num_samples"] = b.stats["num_samples"]
+        arrays[f"cfg{ci}_retrieval_failed"] = b.stats["retrieval_failed"]
+        arrays[f"cfg{ci}_edge_counts"] = np.asarray(b.stats["edge_counts"], np.int64)
+        arrays[f"cfg{ci}_sample_ids"] = np.asarray([smp.sample_id for smp in b.samples])
+        for si, smp in enumerate(b.samples):
+            for name in ("question_emb", "edge_relations", "edge_scores", "edge_labels", "edge_head_locals", "edge_tail_locals",
+                         "node_entity_ids", "node_embedding_ids", "start_entity_ids", "answer_entity_ids", "start_node_locals",
+                         "answer_node_locals"):
+                arrays[f"cfg{ci}_s{si}_{name}"] = getattr(smp, name).numpy()
+            arrays[f"cfg{ci}_s{si}_flags"] = np.asarray([smp.gt_path_exists, smp.is_answer_reachable, smp.is_dummy_agent], bool)
+    save("g_agent_build", **arrays)
+
+
 # ---- E2/E3 -------------------------------------------------------------------------------------------
 class _FakeTokenizer:
     """Whitespace tokenizer with padding=True semantics (pad id 0, mask 0 on pads)."""
@@ -394,6 +532,8 @@ def main():
 
     gen_cosine()
     gen_bfs()
+    gen_build_graph()
+    gen_g_agent_build()
     # toy batch (BASELINE config 1 graph shape: 32 graphs, N_g = 64, E_g ~ 31), D = H = 32
     toy = synthetic.make_batch(32, nodes_per_graph=64, edges_per_graph=31, emb_dim=32, num_relations=16, seed=0)
     eb, eptr, near = gen_graph_utils(toy)

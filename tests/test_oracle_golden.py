@@ -230,3 +230,56 @@ def test_masked_mean_pool_and_table_scatter():
     table = oenc.scatter_rows(chunks, ids, int(z["max_embedding_id"]), int(z["D"]))
     assert np.array_equal(table, z["memmap_table"])
     assert np.all(table[0] == 0)  # row 0 = non-text placeholder stays zero
+
+
+def test_build_graph_ids_matches_reference():
+    from oracle import graph as ograph
+
+    z = load("build_graph")
+    for c in range(int(z["num_cases"])):
+        got = ograph.build_graph_ids(z[f"c{c}_triples"], z[f"c{c}_q"], z[f"c{c}_a"], z[f"c{c}_asub"], z["ent_struct"],
+                                     z["ent_emb"], directed=bool(z[f"c{c}_directed"]), dedup_edges=bool(z[f"c{c}_dedup"]),
+                                     remove_self_loops=bool(z[f"c{c}_noloop"]))
+        for name in ("node_entity_ids", "node_embedding_ids", "edge_src", "edge_dst", "edge_rel", "positive", "pair_start",
+                     "pair_answer", "pair_edges", "pair_counts", "pair_len"):
+            assert np.array_equal(np.asarray(got[name]), z[f"c{c}_{name}"]), (c, name)
+
+
+def _g_agent_cases(z):
+    cfgs = [dict(edge_top_k=20, start_keep_ratio=0.25, start_min_edges=1, start_max_edges=None, allow_empty_answer=False,
+                 node_softmax=True, temperature=1.0, bias=0.0),
+            dict(edge_top_k=500, start_keep_ratio=0.5, start_min_edges=2, start_max_edges=4, allow_empty_answer=True,
+                 node_softmax=False, temperature=2.0, bias=0.5)]
+    return cfgs
+
+
+def test_g_agent_build_sample_matches_reference():
+    from oracle import g_agent as og
+
+    z = load("g_agent_build")
+    for ci, cfg in enumerate(_g_agent_cases(z)):
+        temperature, bias = cfg.pop("temperature"), cfg.pop("bias")
+        scores_all = z["logits"].astype(np.float32)
+        if temperature != 1.0 or bias != 0.0:
+            scores_all = (scores_all / np.float32(temperature) + np.float32(bias)).astype(np.float32)
+        kept = []
+        for g in range(int(z["num_graphs"])):
+            lo, hi = int(z["edge_ptr"][g]), int(z["edge_ptr"][g + 1])
+            n0, n1 = int(z["ptr"][g]), int(z["ptr"][g + 1])
+            out = og.build_sample(
+                heads=z["edge_index"][0, lo:hi] - n0, tails=z["edge_index"][1, lo:hi] - n0, relations=z["edge_attr"][lo:hi],
+                labels=z["labels"][lo:hi], scores=scores_all[lo:hi], node_global_ids=z["node_global_ids"][n0:n1],
+                node_embedding_ids=z["node_embedding_ids"][n0:n1],
+                start_entity_ids=z["seeds"][int(z["seed_ptr"][g]): int(z["seed_ptr"][g + 1])],
+                answer_entity_ids=z["answers"][int(z["ans_ptr"][g]): int(z["ans_ptr"][g + 1])], **cfg)
+            if out is not None:
+                kept.append((f"s{g}", out))
+        assert [k for k, _ in kept] == z[f"cfg{ci}_sample_ids"].tolist()
+        assert len(kept) == int(z[f"cfg{ci}_num_samples"])
+        for si, (_, out) in enumerate(kept):
+            for name, val in out.items():
+                ref = z[f"cfg{ci}_s{si}_{name}"]
+                if val.dtype == np.float32:
+                    np.testing.assert_allclose(val, ref, rtol=1e-6, atol=1e-6, err_msg=f"{ci}/{si}/{name}")
+                else:
+                    assert np.array_equal(val, ref), (ci, si, name)
