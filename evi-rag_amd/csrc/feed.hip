@@ -9,6 +9,14 @@
 //                          class.  Building block of BridgeProbQuality / BridgePositiveCoverage,
 //                          src/metrics/retriever_metrics.py:270-327, 400-476.
 //
+//   evi_segment_offsets / evi_gather_segments
+//                          batch collation from a split that is resident in HBM as flat arrays
+//                          (all samples concatenated, one pointer array per field): a batch is B
+//                          segment copies per field, with the per-sample increment PyG's collate adds
+//                          to index fields (GRetrievalData.__inc__, src/data/g_retrieval_dataset.py:29-37;
+//                          Collater at src/data/components/loader.py:36-44).  Replaces LMDB get +
+//                          unpickle + Collater in 16 worker processes.
+//
 // Both are HBM-bound: the gather moves n*D*4 bytes in and out (one wave per row, 16-byte lanes);
 // the stats read E*(4+1) bytes.  Sums are formed in f64 through a fixed LDS tree: deterministic.
 #include "common.hpp"
@@ -69,9 +77,92 @@ __global__ __launch_bounds__(256) void k_graph_class_stats(const float* __restri
     if (tid < 4) out[(int64_t)g * 4 + tid] = red[tid][0];
 }
 
+// out_ptr[0] = 0, out_ptr[b+1] = sum_{i<=b} items of sample ids[b]; one workgroup, B is a batch size.
+__global__ __launch_bounds__(1024) void k_segment_offsets(const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ ids,
+                                                          int B, int64_t num_samples, int64_t* __restrict__ out_ptr,
+                                                          int32_t* __restrict__ status) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    // thread t owns the contiguous slice [t*per, (t+1)*per)
+    const int per = (B + 1023) / 1024;
+    int64_t local = 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < B; ++i) {
+        const int64_t s = ids[i];
+        if (s < 0 || s >= num_samples) {
+            atomicOr(status, 1);
+            continue;
+        }
+        local += src_ptr[s + 1] - src_ptr[s];
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t add = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int64_t run = part[tid] - local;  // exclusive prefix of this thread's slice
+    if (tid == 0) out_ptr[0] = 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < B; ++i) {
+        const int64_t s = ids[i];
+        if (s >= 0 && s < num_samples) run += src_ptr[s + 1] - src_ptr[s];
+        out_ptr[i + 1] = run;
+    }
+}
+
+// grid = (chunks, B): sample ids[b]'s items [src_ptr[s], src_ptr[s+1]) x row_words 8-byte (WORD 8) or
+// 4-byte (WORD 4) words are copied to out + out_ptr[b] * row_words; 8-byte words get add[b] added
+// (the collate increment of index fields).  Coalesced: consecutive lanes move consecutive words.
+template <typename Word>
+__global__ __launch_bounds__(256) void k_gather_segments(const Word* __restrict__ src, int64_t row_words,
+                                                         const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ ids,
+                                                         int64_t num_samples, const int64_t* __restrict__ out_ptr,
+                                                         const int64_t* __restrict__ add, Word* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int64_t s = ids[b];
+    if (s < 0 || s >= num_samples) return;
+    const int64_t n = (src_ptr[s + 1] - src_ptr[s]) * row_words;
+    const Word* from = src + src_ptr[s] * row_words;
+    Word* to = out + out_ptr[b] * row_words;
+    const Word inc = add ? (Word)add[b] : (Word)0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) to[i] = from[i] + inc;
+}
+
 }  // namespace evi
 
 using namespace evi;
+
+extern "C" int evi_segment_offsets(const int64_t* src_ptr, int64_t num_samples, const int64_t* ids, int B,
+                                   int64_t* out_ptr, int32_t* status, void* stream) {
+    EVI_REQUIRE(B >= 0 && num_samples >= 0, "evi_segment_offsets: need B >= 0 and num_samples >= 0");
+    EVI_REQUIRE(out_ptr && status && (B == 0 || (src_ptr && ids)), "evi_segment_offsets: null pointer");
+    hipLaunchKernelGGL(k_segment_offsets, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), src_ptr, ids, B,
+                       num_samples, out_ptr, status);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_gather_segments(const void* src, int word_bytes, int64_t row_words, const int64_t* src_ptr,
+                                   int64_t num_samples, const int64_t* ids, int B, const int64_t* out_ptr,
+                                   const int64_t* add, void* out, void* stream) {
+    EVI_REQUIRE(B >= 0 && row_words >= 1 && num_samples >= 0, "evi_gather_segments: bad sizes");
+    EVI_REQUIRE(word_bytes == 4 || word_bytes == 8, "evi_gather_segments: word_bytes must be 4 or 8, got %d", word_bytes);
+    EVI_REQUIRE(word_bytes == 8 || !add, "evi_gather_segments: increments apply to 8-byte (int64) fields only");
+    if (B == 0) return EVI_OK;
+    EVI_REQUIRE(src_ptr && ids && out_ptr, "evi_gather_segments: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(32, B);
+    if (word_bytes == 8)
+        hipLaunchKernelGGL(k_gather_segments<int64_t>, grid, dim3(256), 0, st, static_cast<const int64_t*>(src), row_words,
+                           src_ptr, ids, num_samples, out_ptr, add, static_cast<int64_t*>(out));
+    else
+        hipLaunchKernelGGL(k_gather_segments<int32_t>, grid, dim3(256), 0, st, static_cast<const int32_t*>(src), row_words,
+                           src_ptr, ids, num_samples, out_ptr, static_cast<const int64_t*>(nullptr), static_cast<int32_t*>(out));
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
 
 extern "C" int evi_gather_rows(const float* table, int64_t num_rows, int D, const int64_t* ids, int64_t n, float* out,
                                int32_t* status, void* stream) {

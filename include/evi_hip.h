@@ -208,6 +208,21 @@ int evi_graph_class_stats(const float* scores, const uint8_t* target, const int6
 int evi_gather_rows(const float* table, int64_t num_rows, int D, const int64_t* ids, int64_t n,
                     float* out, int32_t* status, void* stream);
 
+/* Batch collation from a split held in HBM as flat arrays (every sample's items concatenated, one
+ * pointer array src_ptr[num_samples + 1] per field family).  evi_segment_offsets: out_ptr[b + 1] =
+ * items of samples ids[0..b] (status bit 1 = an id outside [0, num_samples)).  evi_gather_segments
+ * copies sample ids[b]'s items (row_words words of word_bytes = 4 or 8 each) to
+ * out + out_ptr[b] * row_words, adding add[b] to 8-byte words when add != null — the per-sample
+ * increment PyG's collate applies to index fields (num_nodes for edge_index, q/a_local_indices and
+ * pair_*_node_locals, num_edges for pair_edge_local_ids: GRetrievalData.__inc__,
+ * src/data/g_retrieval_dataset.py:29-37).  Replaces LMDB get + unpickle + torch_geometric Collater
+ * (src/data/components/loader.py:22-99) for a resident split. */
+int evi_segment_offsets(const int64_t* src_ptr, int64_t num_samples, const int64_t* ids, int B,
+                        int64_t* out_ptr, int32_t* status, void* stream);
+int evi_gather_segments(const void* src, int word_bytes, int64_t row_words, const int64_t* src_ptr,
+                        int64_t num_samples, const int64_t* ids, int B, const int64_t* out_ptr,
+                        const int64_t* add, void* out, void* stream);
+
 /* ---- G11: edge -> graph assignment and the Q/A "near" mask --------------------------------- */
 
 /* edge_batch[e] = bucketize(edge_index[0, e], node_ptr[1:], right=True) (node_ptr[g] <= v <

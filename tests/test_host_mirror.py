@@ -61,3 +61,30 @@ def test_synthetic_batch_is_a_valid_pyg_style_batch():
         lo, hi = sb.edge_ptr[g], sb.edge_ptr[g + 1]
         trip = np.stack([sb.edge_index[0, lo:hi], sb.edge_attr[lo:hi], sb.edge_index[1, lo:hi]], 1)
         assert np.unique(trip, axis=0).shape[0] == hi - lo
+
+
+def test_write_packed_layout_and_validation(tmp_path):
+    """The flat split writer (host side of the HBM-resident dataset): pointer arrays, optional aux
+    fields, and the reference's fail-fast KeyError on a missing core key."""
+    import json
+
+    from evi_rag_amd import packed_dataset as pd, synthetic
+
+    base = synthetic.make_batch(5, nodes_per_graph=20, edges_per_graph=40, emb_dim=8, num_relations=4, seed=1)
+    samples = pd.samples_from_flat_batch(base)
+    samples[2].update(pair_start_node_locals=[1, 2], pair_answer_node_locals=[3, 4], pair_edge_counts=[1, 0], pair_edge_local_ids=[7])
+    meta = pd.write_packed(tmp_path / "s", samples)
+    assert meta["num_samples"] == 5 and meta["emb_dim"] == 8 and meta["num_topics"] == 2
+    assert json.loads((tmp_path / "s" / "meta.json").read_text())["sample_ids"] == meta["sample_ids"]
+    assert np.array_equal(np.load(tmp_path / "s" / "ptr_node.npy"), base.ptr)
+    assert np.array_equal(np.load(tmp_path / "s" / "ptr_edge.npy"), base.edge_ptr)
+    assert np.load(tmp_path / "s" / "ptr_pair.npy").tolist() == [0, 0, 0, 2, 2, 2]
+    assert np.load(tmp_path / "s" / "pair_shortest_lengths.npy").tolist() == [-1, -1]  # absent optional field
+    assert np.array_equal(np.load(tmp_path / "s" / "edge_src.npy") + np.repeat(base.ptr[:-1], np.diff(base.edge_ptr)), base.edge_index[0])
+    bad = dict(samples[0])
+    del bad["topic_one_hot"]
+    with pytest.raises(KeyError, match="missing key: topic_one_hot"):
+        pd.write_packed(tmp_path / "bad", [bad])
+    bad = dict(samples[0], edge_index=samples[0]["edge_index"] + 1000)
+    with pytest.raises(ValueError, match="out of range"):
+        pd.write_packed(tmp_path / "bad2", [bad])

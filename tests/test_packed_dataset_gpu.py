@@ -1,0 +1,103 @@
+"""GPU parity: the HBM-resident split and its device collation vs the collate oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import collate as ocollate
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(tmp_path, graphs=24, seed=4):
+    from evi_rag_amd import packed_dataset as pd, synthetic
+
+    base = synthetic.make_batch(graphs, nodes_per_graph=90, edges_per_graph=260, emb_dim=16, num_relations=12, seed=seed)
+    samples = pd.samples_from_flat_batch(base)
+    rng = np.random.default_rng(seed)
+    for i, s in enumerate(samples):  # ragged pair supervision on some samples, none on others
+        if i % 3:
+            npair = int(rng.integers(1, 4))
+            cnt = rng.integers(0, 5, npair)
+            s.update(pair_start_node_locals=rng.integers(0, s["num_nodes"], npair), pair_answer_node_locals=rng.integers(0, s["num_nodes"], npair),
+                     pair_edge_counts=cnt, pair_shortest_lengths=rng.integers(1, 4, npair),
+                     pair_edge_local_ids=rng.integers(0, s["edge_index"].shape[1], int(cnt.sum())))
+    meta = pd.write_packed(tmp_path / "split", samples)
+    return base, samples, meta
+
+
+def _check(batch, ref):
+    for key in ("edge_index", "edge_attr", "labels", "node_global_ids", "node_embedding_ids", "topic_one_hot", "q_local_indices",
+                "a_local_indices", "answer_entity_ids", "seed_entity_ids", "pair_start_node_locals", "pair_answer_node_locals",
+                "pair_edge_counts", "pair_shortest_lengths", "pair_edge_local_ids", "ptr", "edge_ptr", "batch", "question_emb"):
+        got = getattr(batch, key).cpu().numpy()
+        want = np.asarray(ref[key])
+        assert got.shape == want.reshape(got.shape).shape and np.array_equal(got, want.reshape(got.shape)), key
+    assert np.array_equal(batch.edge_batch.cpu().numpy(), np.repeat(np.arange(len(ref["ptr"]) - 1), np.diff(ref["edge_ptr"])))
+    sd = batch._slice_dict
+    assert np.array_equal(sd["q_local_indices"].cpu().numpy(), ref["slices"]["q_local_indices"])
+    assert np.array_equal(sd["answer_entity_ids"].cpu().numpy(), ref["slices"]["answer_entity_ids"])
+    assert np.array_equal(batch.answer_entity_ids_ptr.cpu().numpy(), ref["slices"]["answer_entity_ids"])
+    assert np.array_equal(sd["pair_edge_local_ids"].cpu().numpy(), ref["slices"]["pair_edge_local_ids"])
+
+
+def test_collate_matches_oracle_and_flat_batch(dev, tmp_path):
+    from evi_rag_amd import packed_dataset as pd
+
+    base, samples, meta = _split(tmp_path)
+    ds = pd.PackedRetrievalDataset(tmp_path / "split", device=dev)
+    assert len(ds) == 24 and meta["emb_dim"] == 16 and ds.nbytes() > 0
+    # in-order, the whole split: the flat batch it was cut from
+    full = ds.collate(list(range(24)))
+    assert np.array_equal(full.edge_index.cpu().numpy(), base.edge_index) and np.array_equal(full.ptr.cpu().numpy(), base.ptr)
+    assert np.array_equal(full.q_local_indices.cpu().numpy(), base.q_local_indices)
+    _check(full, ocollate.collate(samples))
+    # arbitrary order with repeats
+    for ids in ([5], [23, 0, 7, 7, 12], list(np.random.default_rng(1).permutation(24)[:17])):
+        _check(ds.collate(ids), ocollate.collate([samples[i] for i in ids]))
+    with pytest.raises(IndexError):
+        ds.collate([0, 24])
+    with pytest.raises(ValueError):
+        ds.collate([])
+    meta1 = ds.load_sample("sample_3") if "sample_3" in ds.sample_ids else ds.load_sample(ds.sample_ids[3])
+    assert torch.equal(meta1["seed_entity_ids"], torch.from_numpy(np.asarray(samples[3]["seed_entity_ids"])))
+    with pytest.raises(KeyError):
+        ds.load_sample("nope")
+
+
+def test_loader_feeds_retriever_and_metrics(dev, tmp_path):
+    """Packed split -> loader -> embedding attach -> Retriever.forward -> metrics == the same on the flat batch."""
+    from evi_rag_amd import metrics as M, packed_dataset as pd, synthetic
+    from evi_rag_amd.embedding_store import GlobalEmbeddingStore
+    from evi_rag_amd.retriever import Retriever
+
+    base, samples, _ = _split(tmp_path, graphs=12, seed=9)
+    rng = np.random.default_rng(0)
+    ent = torch.from_numpy(rng.standard_normal((int(base.node_embedding_ids.max()) + 1, 16)).astype(np.float32))
+    rel = torch.from_numpy(rng.standard_normal((12, 16)).astype(np.float32))
+    store = GlobalEmbeddingStore.from_tensors(ent, rel, device=dev)
+    ds = pd.PackedRetrievalDataset(tmp_path / "split", device=dev, embeddings=store)
+    loader = pd.PackedLoader(ds, batch_size=5)
+    assert len(loader) == 3
+    torch.manual_seed(0)
+    model = Retriever(emb_dim=16, hidden_dim=16).to(dev).eval()
+    coll = M.RetrieverMetricCollection(k_values=[1, 5, 10])
+    seen = 0
+    for batch in loader:
+        out = model(batch)
+        assert out.logits.shape[0] == batch.edge_index.shape[1]
+        coll.update(preds=out.logits, target=batch.labels > 0.5, indexes=out.query_ids, batch=batch, query_ids=out.query_ids,
+                    num_graphs=batch.num_graphs)
+        seen += batch.num_graphs
+    assert seen == 12
+    got = {k: float(v) for k, v in coll.compute().items()}
+    # the same 12 graphs as ONE batch
+    one = ds.collate(list(range(12)))
+    out = model(one)
+    ref = M.RetrieverMetricCollection(k_values=[1, 5, 10])
+    ref.update(preds=out.logits, target=one.labels > 0.5, indexes=out.query_ids, batch=one, query_ids=out.query_ids, num_graphs=12)
+    for k, v in ref.compute().items():
+        assert abs(got[k] - float(v)) < 1e-6, k
+    # shuffled, sharded loaders partition the split
+    parts = [pd.PackedLoader(ds, batch_size=4, shuffle=True, random_seed=3, rank=r, world_size=2) for r in range(2)]
+    ids = sorted(i for p in parts for b in p for i in b.idx.cpu().tolist())
+    assert ids == list(range(12))
