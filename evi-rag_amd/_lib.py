@@ -77,6 +77,8 @@ _SIGNATURES = {
     "evi_group_max_f32": (c_int, [_P, _P, c_int64, _P, _P]),
     "evi_segment_offsets": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P]),
     "evi_gather_segments": (c_int, [_P, c_int, c_int64, _P, c_int64, _P, c_int, _P, _P, _P, _P]),
+    "evi_retriever_loss_workspace_bytes": (c_size_t, [c_int]),
+    "evi_retriever_loss": (c_int, [_P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, c_size_t, _P]),
     "evi_topk_merge": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "evi_topk_packed_bytes": (c_size_t, [c_int, c_int]),
     "evi_topk_merge_packed": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),

@@ -1,0 +1,254 @@
+// Retriever loss on the eval path (S7) and its gradient w.r.t. the logits.
+//
+//   evi_retriever_loss   RetrieverLoss.forward, src/losses/retriever_loss.py:228-325:
+//                        multi-positive InfoNCE per graph (:72-143), optional per-graph BCE (:145-180),
+//                        optional near / bridge edge weights (:213-216), separation metrics (:218-226).
+//                        RetrieverModule._shared_eval_step logs it for every eval batch
+//                        (src/models/retriever_module.py:410-437).
+//
+// One workgroup per graph over its contiguous edge range (edges are grouped by graph: query_ids is
+// non-decreasing, as compute_edge_batch guarantees).  HBM-bound: E * (4 logit + 4 target [+1 near])
+// bytes read per pass, two passes (maxima, then sums); the gradient pass reads them once more and
+// writes E * 4.  Maxima are order-free; sums are accumulated in f64 through a fixed LDS tree, so the
+// result does not depend on scheduling (the reference's scatter_add_ is order-dependent in f32).
+#include "common.hpp"
+
+namespace evi {
+
+constexpr int kLossThreads = 256;
+constexpr int kGraphStats = 12;  // per-graph record, doubles
+// 0 lse_all - lse_pos   1 pos count   2 edge count   3 bce sum   4 bce denom   5 sum sigmoid(pos)
+// 6 sum sigmoid(neg)    7 max_all     8 sum_all      9 max_pos   10 sum_pos    11 weight sum
+
+struct LossArgs {
+    const float* logits;
+    const float* targets;
+    const int64_t* edge_ptr;
+    const uint8_t* near;  // null: no edge weights
+    float inv_temperature, w_near, w_bridge;
+    int want_bce;
+    double* stats;
+};
+
+__device__ inline double block_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int off = kLossThreads >> 1; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+__device__ inline float block_max(float v, float* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int off = kLossThreads >> 1; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    return red[0];
+}
+
+__device__ inline float edge_weight(const LossArgs& a, int64_t e) {
+    return a.near ? (a.near[e] ? a.w_near : a.w_bridge) : 1.0f;
+}
+
+__device__ inline float info_score(const LossArgs& a, int64_t e) {
+    float s = a.logits[e] * a.inv_temperature;
+    if (a.near) s += logf(fmaxf(edge_weight(a, e), 1e-6f));
+    return s;
+}
+
+__global__ __launch_bounds__(kLossThreads) void k_loss_graph_stats(LossArgs a) {
+    __shared__ double dred[kLossThreads];
+    __shared__ float fred[kLossThreads];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int64_t e0 = a.edge_ptr[g], e1 = a.edge_ptr[g + 1];
+    float mx_all = -INFINITY, mx_pos = -INFINITY;
+    for (int64_t e = e0 + tid; e < e1; e += kLossThreads) {
+        const float s = info_score(a, e);
+        mx_all = fmaxf(mx_all, s);
+        if (a.targets[e] > 0.5f) mx_pos = fmaxf(mx_pos, s);
+    }
+    mx_all = block_max(mx_all, fred);
+    mx_pos = block_max(mx_pos, fred);
+    double s_all = 0, s_pos = 0, n_pos = 0, bce = 0, wsum = 0, sg_pos = 0, sg_neg = 0;
+    for (int64_t e = e0 + tid; e < e1; e += kLossThreads) {
+        const float x = a.logits[e], t = a.targets[e];
+        const float s = info_score(a, e);
+        const bool pos = t > 0.5f;
+        s_all += (double)expf(s - mx_all);
+        if (pos) {
+            s_pos += (double)expf(s - mx_pos);
+            n_pos += 1.0;
+        }
+        const float sig = 1.0f / (1.0f + expf(-x));
+        if (pos)
+            sg_pos += (double)sig;
+        else
+            sg_neg += (double)sig;
+        const float w = edge_weight(a, e);
+        wsum += (double)w;
+        if (a.want_bce) bce += (double)((fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)))) * w);
+    }
+    s_all = block_sum(s_all, dred);
+    s_pos = block_sum(s_pos, dred);
+    n_pos = block_sum(n_pos, dred);
+    bce = block_sum(bce, dred);
+    wsum = block_sum(wsum, dred);
+    sg_pos = block_sum(sg_pos, dred);
+    sg_neg = block_sum(sg_neg, dred);
+    if (tid == 0) {
+        double* o = a.stats + (int64_t)g * kGraphStats;
+        const double n_edge = (double)(e1 - e0);
+        const float lse_all = mx_all + logf(fmaxf((float)s_all, 1e-12f));
+        const float lse_pos = mx_pos + logf(fmaxf((float)s_pos, 1e-12f));
+        o[0] = (n_pos > 0 && n_edge - n_pos > 0) ? (double)(lse_all - lse_pos) : 0.0;
+        o[1] = n_pos;
+        o[2] = n_edge;
+        o[3] = bce;
+        o[4] = a.near ? fmax(wsum, 1e-6) : n_edge;
+        o[5] = sg_pos;
+        o[6] = sg_neg;
+        o[7] = mx_all;
+        o[8] = s_all;
+        o[9] = mx_pos;
+        o[10] = s_pos;
+        o[11] = wsum;
+    }
+}
+
+// out[0] infonce  [1] bce  [2] total  [3] pos edges  [4] neg edges  [5] infonce graphs  [6] graphs without
+// positives  [7] graphs without negatives  [8] bce graphs  [9] bce edges  [10] pos_prob  [11] neg_prob
+// [12] separation.  One workgroup; sums over graphs in graph order per thread slice + LDS tree.
+__global__ __launch_bounds__(kLossThreads) void k_loss_finalize(const double* __restrict__ stats, int B, int weighted,
+                                                                int want_bce, float infonce_weight, float bce_weight,
+                                                                double* __restrict__ out) {
+    __shared__ double dred[kLossThreads];
+    const int tid = threadIdx.x;
+    double info = 0, nvalid = 0, npos = 0, nedge = 0, nopos = 0, noneg = 0, bce = 0, nbce = 0, sgp = 0, sgn = 0;
+    for (int g = tid; g < B; g += kLossThreads) {
+        const double* s = stats + (int64_t)g * kGraphStats;
+        const bool valid = s[1] > 0 && s[2] - s[1] > 0;
+        if (valid) {
+            info += s[0];
+            nvalid += 1;
+        }
+        npos += s[1];
+        nedge += s[2];
+        if (s[1] == 0) nopos += 1;
+        if (s[2] - s[1] == 0) noneg += 1;
+        const bool bvalid = weighted ? s[11] > 0 : s[2] > 0;
+        if (want_bce && bvalid) {
+            bce += (double)((float)s[3] / (float)s[4]);
+            nbce += 1;
+        }
+        sgp += s[5];
+        sgn += s[6];
+    }
+    info = block_sum(info, dred);
+    nvalid = block_sum(nvalid, dred);
+    npos = block_sum(npos, dred);
+    nedge = block_sum(nedge, dred);
+    nopos = block_sum(nopos, dred);
+    noneg = block_sum(noneg, dred);
+    bce = block_sum(bce, dred);
+    nbce = block_sum(nbce, dred);
+    sgp = block_sum(sgp, dred);
+    sgn = block_sum(sgn, dred);
+    if (tid == 0) {
+        const double nneg = nedge - npos;
+        const bool any = npos > 0 && nneg > 0 && nvalid > 0;  // :92-97, :124-131
+        const float l_info = any ? (float)(info / nvalid) : 0.f;
+        const float l_bce = (want_bce && nbce > 0) ? (float)(bce / nbce) : 0.f;
+        out[0] = l_info;
+        out[1] = l_bce;
+        out[2] = (double)(infonce_weight * l_info + bce_weight * l_bce);
+        out[3] = npos;
+        out[4] = nneg;
+        out[5] = any ? nvalid : 0.0;
+        out[6] = nopos;
+        out[7] = noneg;
+        out[8] = want_bce ? nbce : 0.0;
+        out[9] = want_bce ? nedge : 0.0;
+        const float pp = npos > 0 ? (float)(sgp / npos) : 0.f, pn = nneg > 0 ? (float)(sgn / nneg) : 0.f;
+        out[10] = pp;
+        out[11] = pn;
+        out[12] = (double)(pp - pn);
+        out[13] = nvalid;
+        out[14] = nbce;
+    }
+}
+
+// d total / d logit_e = infonce_weight * [graph valid] / (n_valid * T) * (softmax_all_e - [pos] softmax_pos_e)
+//                     + bce_weight * [graph valid] * w_e * (sigmoid(x_e) - t_e) / (denom_g * n_bce)
+__global__ __launch_bounds__(kLossThreads) void k_loss_grad(LossArgs a, const double* __restrict__ scalars,
+                                                            float infonce_weight, float bce_weight, int weighted,
+                                                            float* __restrict__ grad) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int64_t e0 = a.edge_ptr[g], e1 = a.edge_ptr[g + 1];
+    const double* s = a.stats + (int64_t)g * kGraphStats;
+    const double nvalid = scalars[5], nbce = scalars[14];
+    const bool valid = nvalid > 0 && s[1] > 0 && s[2] - s[1] > 0;
+    const bool bvalid = a.want_bce && nbce > 0 && (weighted ? s[11] > 0 : s[2] > 0);
+    const float mx_all = (float)s[7], mx_pos = (float)s[9];
+    const double inv_all = 1.0 / s[8], inv_pos = s[10] > 0 ? 1.0 / s[10] : 0.0;
+    for (int64_t e = e0 + tid; e < e1; e += kLossThreads) {
+        const float x = a.logits[e], t = a.targets[e];
+        double gsum = 0.0;
+        if (valid) {
+            const float sc = info_score(a, e);
+            double p = (double)expf(sc - mx_all) * inv_all;
+            if (t > 0.5f) p -= (double)expf(sc - mx_pos) * inv_pos;
+            gsum += (double)infonce_weight * p * (double)a.inv_temperature / nvalid;
+        }
+        if (bvalid) {
+            const double sig = 1.0 / (1.0 + exp(-(double)x));
+            gsum += (double)bce_weight * (double)edge_weight(a, e) * (sig - (double)t) / (s[4] * nbce);
+        }
+        grad[e] = (float)gsum;
+    }
+}
+
+}  // namespace evi
+
+using namespace evi;
+
+extern "C" size_t evi_retriever_loss_workspace_bytes(int B) {
+    return B > 0 ? (size_t)B * kGraphStats * sizeof(double) : 0;
+}
+
+extern "C" int evi_retriever_loss(const float* logits, const float* targets, const int64_t* edge_ptr, int B,
+                                  const uint8_t* edge_is_near, float infonce_temperature, float infonce_weight,
+                                  float bce_weight, float edge_weight_near, float edge_weight_bridge, double* out_scalars,
+                                  float* grad_logits, void* workspace, size_t workspace_bytes, void* stream) {
+    EVI_REQUIRE(B >= 1, "evi_retriever_loss: num_graphs must be positive, got %d", B);
+    EVI_REQUIRE(infonce_temperature > 0.f, "evi_retriever_loss: infonce_temperature must be positive, got %g",
+                (double)infonce_temperature);
+    EVI_REQUIRE(infonce_weight >= 0.f && bce_weight >= 0.f, "evi_retriever_loss: loss weights must be non-negative");
+    EVI_REQUIRE(logits && targets && edge_ptr && out_scalars && workspace, "evi_retriever_loss: null pointer");
+    if (workspace_bytes < evi_retriever_loss_workspace_bytes(B))
+        return fail(EVI_ERR_NOMEM, "evi_retriever_loss: workspace %zu B < %zu B", workspace_bytes,
+                    evi_retriever_loss_workspace_bytes(B));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int weighted = edge_is_near != nullptr;
+    const int want_bce = bce_weight > 0.f;
+    LossArgs a{logits, targets, edge_ptr, edge_is_near, 1.0f / infonce_temperature, edge_weight_near, edge_weight_bridge,
+               want_bce, static_cast<double*>(workspace)};
+    hipLaunchKernelGGL(k_loss_graph_stats, dim3(B), dim3(kLossThreads), 0, st, a);
+    EVI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kLossThreads), 0, st, a.stats, B, weighted, want_bce, infonce_weight,
+                       bce_weight, out_scalars);
+    EVI_LAUNCH_CHECK();
+    if (grad_logits) {
+        hipLaunchKernelGGL(k_loss_grad, dim3(B), dim3(kLossThreads), 0, st, a, out_scalars, infonce_weight, bce_weight, weighted,
+                           grad_logits);
+        EVI_LAUNCH_CHECK();
+    }
+    return EVI_OK;
+}

@@ -1,0 +1,133 @@
+"""The retriever evaluation step and epoch, without Lightning.
+
+Mirror of `RetrieverModule.forward / _shared_eval_step / _update_metrics / _compute_loss_output /
+test_step / on_test_epoch_end` (src/models/retriever_module.py:135-176, 251-275, 390-451): per batch
+forward -> loss -> metric update (`preds=logits, target=labels>0.5, indexes=query_ids`) -> callbacks'
+`on_test_batch_end`; per epoch the batch-size-weighted mean loss Lightning logs as `{split}/loss` and
+the metric dict with the `{split}/` prefix.  Everything between the loader and the final dict stays
+on the device; the host reads one block of loss scalars per batch and the metric states at the end.
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Dict, Iterable, Optional, Sequence
+
+import torch
+
+from . import ops
+from .loss import LossOutput, RetrieverLoss
+from .metrics import RetrieverMetricCollection
+
+DEFAULT_K_VALUES = (1, 10, 25, 50, 100, 200, 300, 400, 500)  # configs/window/default.yaml:8
+
+
+class RetrieverEvaluator:
+    def __init__(self, model, *, loss: Optional[RetrieverLoss] = None, k_values: Sequence[int] = DEFAULT_K_VALUES,
+                 split: str = "test", bridge_metrics: bool = False, callbacks: Sequence[Any] = (),
+                 emit_predict_outputs: bool = False) -> None:
+        if split not in ("val", "test"):
+            raise ValueError(f"split must be 'val' or 'test', got {split!r}")
+        self.model = model
+        self.loss = loss if loss is not None else RetrieverLoss()
+        self.split = split
+        self.metrics = RetrieverMetricCollection(k_values, bridge_metrics=bridge_metrics, prefix=f"{split}/")
+        self.callbacks = list(callbacks)
+        self.emit_predict_outputs = bool(emit_predict_outputs)
+        self.reset()
+
+    def reset(self) -> None:
+        self.metrics.reset()
+        self._loss_sum = 0.0
+        self._graphs = 0
+        self._batches = 0
+
+    @staticmethod
+    def _require_num_graphs(batch: Any) -> int:
+        n = getattr(batch, "num_graphs", None)
+        if n is None:
+            ptr = getattr(batch, "ptr", None)
+            if ptr is None:
+                raise ValueError("Batch missing num_graphs/ptr; cannot infer the number of graphs.")
+            n = int(ptr.numel() - 1)
+        n = int(n)
+        if n <= 0:
+            raise ValueError(f"num_graphs must be positive, got {n}")
+        return n
+
+    def _compute_loss_output(self, batch: Any, output, num_graphs: int) -> LossOutput:
+        targets = getattr(batch, "labels", None)
+        if targets is None:
+            raise ValueError("Batch missing labels required for retriever loss.")
+        edge_is_near = None
+        if self.loss.requires_edge_is_near:
+            edge_is_near = getattr(batch, "edge_is_near", None)
+            if edge_is_near is None:
+                edge_is_near = ops.qa_edge_mask(batch.edge_index, int(batch.ptr[-1].item()) if hasattr(batch, "ptr") else batch.num_nodes,
+                                                batch.q_local_indices, batch.a_local_indices)
+                batch.edge_is_near = edge_is_near
+        return self.loss(output, targets, edge_batch=output.query_ids, num_graphs=num_graphs, edge_is_near=edge_is_near)
+
+    @torch.no_grad()
+    def step(self, batch: Any, batch_idx: int = 0):
+        """`_shared_eval_step` (:410-451)."""
+        num_graphs = self._require_num_graphs(batch)
+        output = self.model(batch)
+        loss_out = self._compute_loss_output(batch, output, num_graphs)
+        self._loss_sum += float(loss_out.components["infonce"] * self.loss.infonce_weight
+                                + loss_out.components["bce"] * self.loss.bce_weight) * num_graphs
+        self._graphs += num_graphs
+        self._batches += 1
+        scores = output.logits.detach().view(-1)
+        if scores.numel():
+            labels = batch.labels.detach().view(-1).to(dtype=torch.float32)
+            if scores.numel() != labels.numel():
+                raise ValueError(f"scores/labels shape mismatch: {scores.shape} vs {labels.shape}")
+            query_ids = output.query_ids.detach().view(-1).to(dtype=torch.long)
+            self.metrics.update(preds=scores, target=labels > 0.5, indexes=query_ids, batch=batch, query_ids=query_ids,
+                                num_graphs=num_graphs, features=output.edge_embeddings)
+        for cb in self.callbacks:
+            if hasattr(cb, "on_test_batch_end"):
+                cb.on_test_batch_end(None, self, output, batch, batch_idx, 0)
+            elif hasattr(cb, "process_batch"):  # GAgentBuilder
+                cb.process_batch(batch, output)
+        if self.emit_predict_outputs:
+            pred = output.detach()
+            pred.edge_embeddings = None
+            return pred
+        return None
+
+    def epoch_end(self, *, sync: bool = False) -> Dict[str, float]:
+        """`on_test_epoch_end` (:401-403): metric dict + the epoch loss; sync=True sums the metric states
+        and the loss accumulators over ranks first (dist_reduce_fx="sum", sync_dist=True)."""
+        loss_sum, graphs = self._loss_sum, float(self._graphs)
+        if sync:
+            from .dist import all_reduce_sum_
+
+            self.metrics.sync()
+            loss_sum, graphs = all_reduce_sum_([loss_sum, graphs])
+        out = {k: float(v) for k, v in self.metrics.compute().items()}
+        out[f"{self.split}/loss"] = loss_sum / max(graphs, 1.0)
+        return out
+
+    def run(self, loader: Iterable[Any], *, sync: bool = False) -> Dict[str, Any]:
+        """One pass over the loader.  Returns {"metrics", "num_graphs", "seconds", "queries_per_sec"}; the
+        clock brackets the loop with device synchronisation on both sides."""
+        self.reset()
+        for cb in self.callbacks:
+            if hasattr(cb, "on_predict_start"):
+                cb.on_predict_start(None, self)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, batch in enumerate(loader):
+            self.step(batch, i)
+        metrics = self.epoch_end(sync=sync)
+        torch.cuda.synchronize()
+        seconds = time.perf_counter() - t0
+        for cb in self.callbacks:
+            if hasattr(cb, "on_predict_end"):
+                cb.on_predict_end(None, self)
+        return {"metrics": metrics, "num_graphs": self._graphs, "seconds": seconds,
+                "queries_per_sec": self._graphs / seconds if seconds > 0 else 0.0}
+
+
+__all__ = ["RetrieverEvaluator", "DEFAULT_K_VALUES"]

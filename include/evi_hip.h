@@ -333,6 +333,29 @@ int evi_segment_sort_rank(const int64_t* keys, int64_t T, const int64_t* seg_ptr
  * Replaces the score / label max aggregation at src/data/components/g_agent_builder.py:353-354. */
 int evi_group_max_f32(const float* values, const int32_t* group, int64_t T, float* out, void* stream);
 
+/* ---- S7: the loss the eval step logs ------------------------------------------------------------------ */
+
+/* RetrieverLoss.forward over a batch whose edges are grouped by graph (edge_ptr [B+1]):
+ *   InfoNCE  mean over graphs with >= 1 positive and >= 1 negative of
+ *            logsumexp_e(s_e) - logsumexp_{e positive}(s_e),  s_e = logit_e / temperature (+ log w_e),
+ *            0 when the batch has no positive or no negative edge at all;
+ *   BCE      (bce_weight > 0) mean over graphs of sum_e w_e * bce_with_logits(logit_e, target_e) / sum_e w_e;
+ *   w_e      = edge_weight_near / edge_weight_bridge by edge_is_near when it is non-null, else 1;
+ *   target_e > 0.5 marks a positive.
+ * out_scalars [15] f64: 0 infonce, 1 bce, 2 infonce_weight * infonce + bce_weight * bce, 3 positive edges,
+ * 4 negative edges, 5 InfoNCE graphs, 6 graphs without positives, 7 graphs without negatives,
+ * 8 BCE graphs, 9 BCE edges, 10 mean sigmoid(logit | positive), 11 mean sigmoid(logit | negative),
+ * 12 their difference, 13-14 internal.  grad_logits (nullable) receives d out[2] / d logits.
+ * Sums are formed in f64 in a fixed order (deterministic).
+ * Replaces RetrieverLoss, src/losses/retriever_loss.py:72-325 (called by
+ * RetrieverModule._compute_loss_output, src/models/retriever_module.py:251-275). */
+size_t evi_retriever_loss_workspace_bytes(int B);
+int evi_retriever_loss(const float* logits, const float* targets, const int64_t* edge_ptr, int B,
+                       const uint8_t* edge_is_near, float infonce_temperature, float infonce_weight,
+                       float bce_weight, float edge_weight_near, float edge_weight_bridge,
+                       double* out_scalars, float* grad_logits, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* ---- G8/G9/G10: seed expansion and score post-processing ----------------------------------------- */
 
 /* logit of p = (softmax of the score over the head's out-edges + softmax over the tail's in-edges)/2,

@@ -462,6 +462,44 @@ def gen_g_agent_build():
     save("g_agent_build", **arrays)
 
 
+# ---- loss on the eval path (S7: RetrieverModule._shared_eval_step logs {split}/loss) ----------------------
+def gen_loss():
+    from src.losses.retriever_loss import RetrieverLoss
+
+    rng = np.random.default_rng(606)
+    B = 7
+    counts = [40, 1, 25, 60, 3, 0, 30]                     # one single-edge graph, one empty graph
+    eb = np.repeat(np.arange(B), counts)
+    E = eb.size
+    logits = (rng.standard_normal(E) * 3).astype(np.float32)
+    targets = (rng.random(E) < 0.15).astype(np.float32)
+    targets[eb == 2] = 0.0                                  # a graph without positives
+    targets[eb == 4] = 1.0                                  # a graph without negatives
+    near = rng.random(E) < 0.4
+    arrays = {"logits": logits, "targets": targets, "edge_batch": eb, "edge_is_near": near, "num_graphs": B}
+    cfgs = [dict(), dict(infonce_temperature=0.5, bce_weight=0.3), dict(edge_weight_near=2.0, edge_weight_bridge=0.5, bce_weight=1.0),
+            dict(infonce_weight=0.0, bce_weight=1.0)]
+    arrays["cfgs"] = np.asarray([[c.get("infonce_temperature", 1.0), c.get("infonce_weight", 1.0), c.get("bce_weight", 0.0),
+                                  c.get("edge_weight_near", 1.0), c.get("edge_weight_bridge", 1.0)] for c in cfgs], np.float64)
+    variants = {"base": targets, "nopos": np.zeros_like(targets)}
+    for vi, (vname, tg) in enumerate(variants.items()):
+        for ci, cfg in enumerate(cfgs):
+            loss_fn = RetrieverLoss(**cfg)
+            lg = torch.from_numpy(logits).clone().requires_grad_(True)
+            out = loss_fn(types.SimpleNamespace(logits=lg), torch.from_numpy(tg), edge_batch=torch.from_numpy(eb), num_graphs=B,
+                          edge_is_near=torch.from_numpy(near))
+            grad = torch.autograd.grad(out.loss, lg, allow_unused=True)[0] if out.loss.requires_grad else None
+            tag = f"{vname}_c{ci}"
+            arrays[f"{tag}_loss"] = np.float64(out.loss.item())
+            arrays[f"{tag}_grad"] = grad.numpy() if grad is not None else np.zeros(E, np.float32)
+            arrays[f"{tag}_component_keys"] = np.asarray(sorted(out.components))
+            arrays[f"{tag}_component_vals"] = np.asarray([out.components[k] for k in sorted(out.components)], np.float64)
+            arrays[f"{tag}_metric_keys"] = np.asarray(sorted(out.metrics))
+            arrays[f"{tag}_metric_vals"] = np.asarray([out.metrics[k] for k in sorted(out.metrics)], np.float64)
+    arrays["nopos_targets"] = variants["nopos"]
+    save("loss", **arrays)
+
+
 # ---- E2/E3 -------------------------------------------------------------------------------------------
 class _FakeTokenizer:
     """Whitespace tokenizer with padding=True semantics (pad id 0, mask 0 on pads)."""
@@ -534,6 +572,7 @@ def main():
     gen_bfs()
     gen_build_graph()
     gen_g_agent_build()
+    gen_loss()
     # toy batch (BASELINE config 1 graph shape: 32 graphs, N_g = 64, E_g ~ 31), D = H = 32
     toy = synthetic.make_batch(32, nodes_per_graph=64, edges_per_graph=31, emb_dim=32, num_relations=16, seed=0)
     eb, eptr, near = gen_graph_utils(toy)

@@ -283,3 +283,24 @@ def test_g_agent_build_sample_matches_reference():
                     np.testing.assert_allclose(val, ref, rtol=1e-6, atol=1e-6, err_msg=f"{ci}/{si}/{name}")
                 else:
                     assert np.array_equal(val, ref), (ci, si, name)
+
+
+def _loss_cases(z):
+    for variant, tkey in (("base", "targets"), ("nopos", "nopos_targets")):
+        for ci, (T, wi, wb, wn, wbr) in enumerate(z["cfgs"].tolist()):
+            yield f"{variant}_c{ci}", z[tkey], dict(infonce_temperature=T, infonce_weight=wi, bce_weight=wb, edge_weight_near=wn,
+                                                   edge_weight_bridge=wbr)
+
+
+def test_retriever_loss_matches_reference():
+    from oracle import loss as oloss
+
+    z = load("loss")
+    for tag, targets, cfg in _loss_cases(z):
+        total, comps, mets, grad = oloss.retriever_loss(z["logits"], targets, z["edge_batch"], int(z["num_graphs"]),
+                                                        edge_is_near=z["edge_is_near"], **cfg)
+        assert abs(total - float(z[f"{tag}_loss"])) < 2e-6 * max(1.0, abs(total)), tag
+        np.testing.assert_allclose(grad, z[f"{tag}_grad"], rtol=2e-5, atol=2e-7, err_msg=tag)
+        assert sorted(comps) == z[f"{tag}_component_keys"].tolist() and sorted(mets) == z[f"{tag}_metric_keys"].tolist(), tag
+        np.testing.assert_allclose([comps[k] for k in sorted(comps)], z[f"{tag}_component_vals"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose([mets[k] for k in sorted(mets)], z[f"{tag}_metric_vals"], rtol=2e-6, atol=2e-6)
