@@ -56,3 +56,39 @@ def time_cosine_topk(q: torch.Tensor, x: torch.Tensor, k: int, *, n_total: int, 
         "sample": (f"torch-CPU f32 matmul+topk on the first {rows} of {n_total} index rows, Q={Q}, k={kk}, "
                    f"{iters} iters, {per_iter * 1e3:.1f} ms/iter, scaled x{n_total / rows:.1f} in rows"),
     }
+
+
+def time_graph_eval(weights, batch, k_values, *, num_rounds: int = 2, num_reverse_rounds: int = 2, budget_s: float = 10.0) -> Dict:
+    """The per-question stage on the CPU: the oracle's Retriever forward (numpy + multi-threaded BLAS,
+    the reference's as-written arithmetic: every edge's relation row is projected) followed by the
+    ranking metrics (per-graph top-k, recall, union-find reachability), on a small flat batch."""
+    import numpy as np
+
+    from . import metrics as omet
+    from . import scorer as oscorer
+
+    graphs = int(np.asarray(batch.ptr).shape[0] - 1)
+
+    def one():
+        out = oscorer.retriever_forward(weights, batch, num_rounds=num_rounds, num_reverse_rounds=num_reverse_rounds)
+        target = np.asarray(batch.labels) > 0.5
+        omet.edge_recall_at_k(out["logits"], target, np.asarray(batch.edge_ptr), k_values)
+        omet.answer_reachability(out["logits"], batch, k_values)
+        return out
+
+    one()
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or iters >= 20:
+            break
+    per_iter = dt / iters
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return {"value": graphs / per_iter, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": (f"numpy/BLAS oracle forward + ranking metrics on {graphs} graphs, E={int(np.asarray(batch.edge_index).shape[1])}, "
+                       f"{iters} iters, {per_iter * 1e3:.0f} ms/iter")}

@@ -34,7 +34,7 @@ def test_retriever_loss_matches_reference_golden(dev, shuffle):
                                    edge_batch=torch.from_numpy(z["edge_batch"][perm]).to(dev), num_graphs=int(z["num_graphs"]),
                                    edge_is_near=torch.from_numpy(z["edge_is_near"][perm]).to(dev))
         ref = float(z[f"{tag}_loss"])
-        assert abs(float(out.loss) - ref) < 3e-6 * max(1.0, abs(ref)), tag
+        assert abs(float(out.loss.detach()) - ref) < 3e-6 * max(1.0, abs(ref)), tag
         assert sorted(out.components) == z[f"{tag}_component_keys"].tolist() and sorted(out.metrics) == z[f"{tag}_metric_keys"].tolist(), tag
         np.testing.assert_allclose([out.components[k] for k in sorted(out.components)], z[f"{tag}_component_vals"], rtol=3e-6, atol=3e-6)
         np.testing.assert_allclose([out.metrics[k] for k in sorted(out.metrics)], z[f"{tag}_metric_vals"], rtol=3e-6, atol=3e-6)
