@@ -266,7 +266,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EVI_FORCE_EXCHANGE=1 under torch.distributed.run with ONE rank rehearses the multi-rank path (all-gather + merge
+    # on the side stream) on a single GPU
+    rehearse = world == 1 and os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or rehearse:
         dist.init_process_group("nccl", device_id=dev)
 
     from evi_rag_amd import _lib, ops
@@ -297,8 +300,10 @@ def main():
     index.workspace = ws
 
     def step(b):
-        # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge
-        return index.topk(queries[b], k)
+        # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge on a
+        # side stream, overlapped with the next batch's scan (every result is complete at the closing fence)
+        s, i, _ = index.topk_async(queries[b], k)
+        return s, i
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -388,7 +393,7 @@ def main():
             torch.cuda.empty_cache()
             result["graph_eval"] = bench_graph_eval(dev, D, cpu_seconds=0.0 if args.no_cpu_baseline else 8.0)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -3,7 +3,8 @@
 
   ShardedIndex      row-sharded embedding index: per-shard exact top-k, ONE fixed-shape all-gather
                     of the packed [Q, k] (score f32, id i64) lists, merge on every rank
-                    (SURVEY.md §8e).  Replaces the pickled `dist.all_gather_object` of per-sample
+                    (SURVEY.md §8e).  `topk_async` pipelines a stream of batches: the exchange of batch b
+                    runs on a side HIP stream under the scan of batch b + 1.  Replaces the pickled `dist.all_gather_object` of per-sample
                     lists at src/callbacks/retriever_topk_edge_writer.py:450-462.  The message is
                     Q*k*12 bytes per rank (192 KB at Q = 32, k = 500): latency-bound, so it is a
                     single all-gather, not a ring reduction.
@@ -16,6 +17,7 @@ merged result is bit-identical for every number of shards.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -74,10 +76,13 @@ class ShardedIndex:
         self._packed_local: Optional[torch.Tensor] = None
         self._packed_all: Optional[torch.Tensor] = None
         self.workspace: Optional[torch.Tensor] = None
+        self._pipe = None
+        # EVI_FORCE_EXCHANGE=1 runs the exchange even with one rank (rehearses the multi-rank path on one GPU)
+        self._exchange = self.world > 1 or (os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and dist.is_initialized())
 
     def topk(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Global top-k (scores [Q, k], global row ids [Q, k]) — identical on every rank."""
-        if self.world > 1 and self._packed_ok and queries.is_cuda:
+        if self._exchange and self._packed_ok and queries.is_cuda:
             return self._topk_packed(queries, k)
         if self.row_scale is not None:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale)
@@ -110,7 +115,52 @@ def _topk_packed(self: "ShardedIndex", queries: torch.Tensor, k: int):
     return ops.topk_merge_packed(self._packed_all, self.world, Q, k)
 
 
+def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
+    """Pipelined form of `topk` for a stream of query batches: (scores, ids, event).
+
+    The shard scan of this batch runs on the caller's stream; the all-gather and the merge run on a side
+    stream, so they overlap the scan of the NEXT batch (the exchange is latency-bound and a batch's scan
+    does not depend on the previous batch's merge).  Two slots of buffers alternate: the returned tensors
+    are valid once `event` has completed and until two further calls.  With one rank (no exchange) it is
+    `topk` plus an already-recorded event."""
+    from . import _lib, ops
+
+    dev = queries.device
+    main = torch.cuda.current_stream(dev)
+    if not (self._exchange and self._packed_ok and queries.is_cuda):
+        s, i = self.topk(queries, k)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        return s, i, ev
+    Q = queries.size(0)
+    p = self._pipe
+    if p is None or p["shape"] != (Q, k) or p["dev"] != dev:
+        rec = int(_lib.load().evi_topk_packed_bytes(Q, k))
+        mk = lambda n, dt: [torch.empty(n, dtype=dt, device=dev) for _ in range(2)]  # noqa: E731
+        p = self._pipe = {"shape": (Q, k), "dev": dev, "slot": 0, "used": [False, False], "side": torch.cuda.Stream(dev),
+                          "local": mk(rec, torch.uint8), "all": mk(self.world * rec, torch.uint8),
+                          "out_s": mk((Q, k), torch.float32), "out_i": mk((Q, k), torch.int64),
+                          "scan_done": [torch.cuda.Event() for _ in range(2)], "xchg_done": [torch.cuda.Event() for _ in range(2)]}
+    slot = p["slot"]
+    p["slot"] = slot ^ 1
+    if p["used"][slot]:
+        main.wait_event(p["xchg_done"][slot])  # the all-gather two batches ago has consumed this slot's record
+    sv, iv = ops.topk_packed_views(p["local"][slot], Q, k)
+    ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale, workspace=self.workspace,
+                    out=(sv, iv))
+    p["scan_done"][slot].record(main)
+    side = p["side"]
+    with torch.cuda.stream(side):
+        side.wait_event(p["scan_done"][slot])
+        dist.all_gather_into_tensor(p["all"][slot], p["local"][slot], group=self.group)
+        ops.topk_merge_packed(p["all"][slot], self.world, Q, k, out=(p["out_s"][slot], p["out_i"][slot]))
+        p["xchg_done"][slot].record(side)
+    p["used"][slot] = True
+    return p["out_s"][slot], p["out_i"][slot], p["xchg_done"][slot]
+
+
 ShardedIndex._topk_packed = _topk_packed
+ShardedIndex.topk_async = _topk_async
 
 
 def all_reduce_sum_(values: Sequence[float], *, device: Optional[torch.device] = None, group=None) -> List[float]:

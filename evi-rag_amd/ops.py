@@ -209,15 +209,22 @@ def topk_packed_views(packed: torch.Tensor, Q: int, k: int) -> Tuple[torch.Tenso
     return rec[: n * 4].view(torch.float32).view(Q, k), rec[ids_off: ids_off + n * 8].view(torch.int64).view(Q, k)
 
 
-def topk_merge_packed(packed: torch.Tensor, P: int, Q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def topk_merge_packed(packed: torch.Tensor, P: int, Q: int, k: int,
+                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge P packed per-shard records (the output of ONE all-gather) into the global top-k."""
     dev = _require_gpu(packed)
     lib = _lib.load()
     rec = int(lib.evi_topk_packed_bytes(Q, k))
     if packed.numel() * packed.element_size() < P * rec:
         raise ValueError(f"packed buffer holds {packed.numel() * packed.element_size()} B, need {P * rec} B")
-    out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
-    out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    if out is not None:
+        out_score, out_index = out
+        if out_score.shape != (Q, k) or out_index.shape != (Q, k) or out_score.dtype != torch.float32 or \
+                out_index.dtype != torch.int64 or not out_score.is_contiguous() or not out_index.is_contiguous():
+            raise ValueError("out must be contiguous (f32 [Q, k], i64 [Q, k]) tensors")
+    else:
+        out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     _lib.check(lib.evi_topk_merge_packed(packed.data_ptr(), P, Q, k, _ptr(out_score), _ptr(out_index), _stream(dev)))
     return out_score, out_index
 
