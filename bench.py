@@ -255,6 +255,11 @@ def bench_eval_pipeline(dev, D, model, *, graphs_total=128, batch_size=32, nodes
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE JSON line: native libraries that write to fd 1 (RCCL prints a version banner at
+    # communicator creation) are sent to stderr for the life of the process, and the result goes to the saved fd
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -392,7 +397,7 @@ def main():
             del shard, ws
             torch.cuda.empty_cache()
             result["graph_eval"] = bench_graph_eval(dev, D, cpu_seconds=0.0 if args.no_cpu_baseline else 8.0)
-        print(json.dumps(result), flush=True)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
