@@ -7,11 +7,20 @@
 //      per row), relations either per unique relation id (when the caller states num_relations <= E;
 //      a row's projection depends on nothing but the row) or per edge.          -> gemm.hip (MFMA f32)
 //   2. structure    CSR + DDE mean propagation -> node_struct [N, 2*(1+R+RR)]    -> graph.hip
-//   3. edge features, one wave per edge, both directions: struct MLP (K = 20, LN, exact GELU),
-//      nav gate, DistMult / TransE terms, written as rows of X [2*Ec, 3D+4]     -> k_edge_features
-//   4. state_net.0 (GEMM, K = 3D+1 zero-padded to 3D+4) -> LayerNorm + GELU in place -> state_net.4
-//      (GEMM) -> score_head + 2-way softmax combine                              -> gemm.hip, k_*
-// Bound: MFMA f32 (steps 1 and 4: 2*(2(3D+1)H + 2H^2) flops per edge); steps 2-3 are gathers.
+//   3. edge features, one wave per edge: struct MLP (K = 20, LN, exact GELU) and nav gate per
+//      direction, the DistMult product p = h*r_ctx*t, r_ctx, -||h + r_ctx - t||      -> k_edge_features
+//   4. state_net.0, FACTORED.  Its input is [p*nav | s | h + r_ctx - t | -dist] per direction
+//      (:471-481), so with W1 = [Wa | Wb | Wc | wd] by column block
+//          W1 x_dir = nav_dir (Wa p) + Wb s_dir + (+-)(Wc h - Wc t) + Wc r_ctx + wd (-dist_dir) + b1:
+//      p, r_ctx and the node terms do not depend on the direction and the node term only on the
+//      node, so the work is  Wc node_repr [N rows, once per batch],  Wa p and Wc r_ctx [E rows],
+//      Wb s [2E rows]  —  8 D H flops per edge instead of 12 D H for the concatenated form, and the
+//      [2E, 3D+1] input is never materialised                                      -> gemm*.hip
+//      then one wave per edge sums the terms, LayerNorm + GELU                    -> k_state_combine
+//   5. state_net.4 (GEMM) -> score_head + 2-way softmax combine                    -> k_score_combine
+//      When the caller does not ask for edge features (EviRetrieverOutput.edge_features == NULL) the
+//      head is folded, logit = (W2^T w) . h1 + (w . b2 + b), and state_net.4 is never formed.
+// Bound: MFMA (steps 1, 4, 5: 2*(4DH + 2H^2) flops per edge); steps 2-3 are gathers.
 #include "common.hpp"
 
 #include <stdlib.h>
@@ -62,13 +71,6 @@ __global__ void k_gather_relation_rows(const float* __restrict__ edge_emb, const
         rows[r * D + d] = e == 0x7FFFFFFF ? 0.f : edge_emb[(int64_t)e * D + d];
 }
 
-// state_net.0.weight [H, 3D+1] -> zero-padded [H, Kp]
-__global__ void k_pad_rows(const float* __restrict__ src, int rows, int K, int Kp, float* __restrict__ dst) {
-    const int r = blockIdx.x;
-    if (r >= rows) return;
-    for (int k = threadIdx.x; k < Kp; k += blockDim.x) dst[(int64_t)r * Kp + k] = k < K ? src[(int64_t)r * K + k] : 0.f;
-}
-
 // struct_proj.0.weight [D, F] -> transposed [F, D] so lanes read consecutive d
 __global__ void k_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,10 +97,13 @@ struct EdgeFeatArgs {
     const float* struct_ln_b;
     const float* struct_gate_w;  // [D]
     const float* struct_gate_b;  // [1]
-    int D, Kp;
+    int D;
     int64_t e_begin, e_count;  // chunk
     int dir_fwd, dir_bwd;
-    float* X;  // [(dir_fwd + dir_bwd) * e_count, Kp]
+    float* P;    // [e_count, D]  h * r_ctx * t
+    float* RCX;  // [e_count, D]  r_ctx
+    float* XS;   // [(dir_fwd + dir_bwd) * e_count, D]  struct context per direction
+    float* aux;  // [(dir_fwd + dir_bwd) * e_count, 2]  (nav gate, -||translation error||)
 };
 
 template <int DPL>
@@ -193,56 +198,173 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
                 }
             }
             const float nav = sigmoidf_(wsum(gacc) + gate_b);
-            float* x = a.X + ((int64_t)out_row * a.e_count + le) * a.Kp;
+            const int64_t row = (int64_t)out_row * a.e_count + le;
+            float* xs = a.XS + row * D;
             float dsq = 0.f;
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
                 const int d = lane + 64 * i;
                 if (d < D) {
-                    const float ha = dir == 0 ? h[i] : t[i];
-                    const float hb = dir == 0 ? t[i] : h[i];
-                    const float err = ha + rc[i] - hb;
-                    x[d] = ha * rc[i] * hb * nav;
-                    x[D + d] = s[i];
-                    x[2 * D + d] = err;
+                    const float err = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
+                    xs[d] = s[i];
                     dsq = fmaf(err, err, dsq);
                 }
             }
             dsq = wsum(dsq);
-            if (lane < a.Kp - 3 * D) x[3 * D + lane] = lane == 0 ? -sqrtf(dsq) : 0.f;
+            if (lane == 0) {
+                a.aux[row * 2] = nav;
+                a.aux[row * 2 + 1] = -sqrtf(dsq);
+            }
             ++out_row;
+        }
+        float* pp = a.P + le * D;
+        float* rx = a.RCX + le * D;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) {
+                pp[d] = h[i] * rc[i] * t[i];
+                rx[d] = rc[i];
+            }
         }
     }
 }
 
-// rows <- GELU(LayerNorm(rows)) in place, one wave per row.
-template <int DPL>
-__global__ __launch_bounds__(256) void k_layernorm_gelu(float* __restrict__ x, int64_t M, int H,
-                                                        const float* __restrict__ w, const float* __restrict__ b) {
+// state_net.0.weight [H, 3D+1] -> contiguous column blocks Wa, Wb, Wc [H, D] and the last column wd [H]
+__global__ void k_slice_state0(const float* __restrict__ w1, int H, int D, float* __restrict__ wa, float* __restrict__ wb,
+                               float* __restrict__ wc, float* __restrict__ wd) {
+    const int r = blockIdx.x;
+    const float* src = w1 + (int64_t)r * (3 * D + 1);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        wa[(int64_t)r * D + d] = src[d];
+        wb[(int64_t)r * D + d] = src[D + d];
+        wc[(int64_t)r * D + d] = src[2 * D + d];
+    }
+    if (threadIdx.x == 0) wd[r] = src[3 * D];
+}
+
+// Folded head for the logits-only path: v[j] = sum_i score_w[i] * W2[i, j], v[H] = score_w . b2 + score_b
+__global__ void k_fold_head(const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ score_w,
+                            const float* __restrict__ score_b, int H, float* __restrict__ v) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < H) {
+        float acc = 0.f;
+        for (int i = 0; i < H; ++i) acc = fmaf(score_w[i], w2[(int64_t)i * H + j], acc);
+        v[j] = acc;
+    }
+    if (j == 0) {
+        float acc = score_b[0];
+        for (int i = 0; i < H; ++i) acc = fmaf(score_w[i], b2[i], acc);
+        v[H] = acc;
+    }
+}
+
+// One wave per edge: h1_dir = nav_dir * PA[e] + SB[dir, e] + sign_dir * (HcN[head] - HcN[tail]) + RC[e]
+// + wd * (-dist_dir)   (SB already holds state_net.0.bias), then LayerNorm + exact GELU.
+// FOLD == 0: the normalised rows go to h1n [(dirs) * e_count, H] for state_net.4.
+// FOLD == 1: logit_dir = v . row + v[H] and the 2-way softmax combine (retriever.py:369-381) right here.
+struct CombineArgs {
+    const int64_t* edge_index;
+    int64_t E, e_begin, e_count;
+    const float* PA;   // [e_count, H]
+    const float* RC;   // [e_count, H]
+    const float* SB;   // [dirs * e_count, H]
+    const float* HcN;  // [N, H]
+    const float* aux;  // [dirs * e_count, 2]
+    const float* wd;   // [H]
+    const float* ln_w;
+    const float* ln_b;
+    int H, dir_fwd, dir_bwd;
+    float* h1n;
+    const float* v;  // [H + 1] folded head
+    float* logits;
+    float* logits_fwd;
+    float* logits_bwd;
+};
+
+template <int DPL, int FOLD>
+__global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float* p = x + row * H;
-    float v[DPL];
-    float sum = 0.f;
+    const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (le >= a.e_count) return;
+    const int H = a.H;
+    const int64_t e = a.e_begin + le;
+    const float* pa = a.PA + le * H;
+    const float* rc = a.RC + le * H;
+    const float* hh = a.HcN + a.edge_index[e] * H;
+    const float* ht = a.HcN + a.edge_index[a.E + e] * H;
+    float base[DPL], diff[DPL], pav[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; ++i) {
         const int d = lane + 64 * i;
-        v[i] = d < H ? p[d] : 0.f;
-        sum += v[i];
+        if (d < H) {
+            pav[i] = pa[d];
+            base[i] = rc[d];
+            diff[i] = hh[d] - ht[d];
+        } else {
+            pav[i] = base[i] = diff[i] = 0.f;
+        }
     }
-    const float mean = wsum(sum) / (float)H;
-    float var = 0.f;
+    float lg[2] = {0.f, 0.f};
+    int out_row = 0;
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const float c = (lane + 64 * i < H) ? v[i] - mean : 0.f;
-        var += c * c;
+    for (int dir = 0; dir < 2; ++dir) {
+        if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
+        const int64_t row = (int64_t)out_row * a.e_count + le;
+        const float nav = a.aux[row * 2], negdist = a.aux[row * 2 + 1];
+        const float* sb = a.SB + row * H;
+        float v[DPL];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < H) {
+                float x = fmaf(nav, pav[i], sb[d]);
+                x += dir == 0 ? diff[i] : -diff[i];
+                x += base[i];
+                x = fmaf(a.wd[d], negdist, x);
+                v[i] = x;
+                sum += x;
+            } else {
+                v[i] = 0.f;
+            }
+        }
+        const float mean = wsum(sum) / (float)H;
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const float c = (lane + 64 * i < H) ? v[i] - mean : 0.f;
+            var += c * c;
+        }
+        const float rstd = 1.0f / sqrtf(wsum(var) / (float)H + kLnEps);
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < H) {
+                const float y = gelu_erf((v[i] - mean) * rstd * a.ln_w[d] + a.ln_b[d]);
+                if (FOLD)
+                    dot = fmaf(a.v[d], y, dot);
+                else
+                    a.h1n[row * H + d] = y;
+            }
+        }
+        if (FOLD) lg[dir] = wsum(dot) + a.v[H];
+        ++out_row;
     }
-    const float rstd = 1.0f / sqrtf(wsum(var) / (float)H + kLnEps);
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int d = lane + 64 * i;
-        if (d < H) p[d] = gelu_erf((v[i] - mean) * rstd * w[d] + b[d]);
+    if (FOLD && lane == 0) {
+        const float lf = lg[0], lb = lg[1];
+        float out = lf;
+        if (a.dir_fwd && a.dir_bwd) {
+            const float m = fmaxf(lf, lb);
+            const float ef = expf(lf - m), eb = expf(lb - m);
+            out = (ef * lf + eb * lb) / (ef + eb);
+        } else if (a.dir_bwd) {
+            out = lb;
+        }
+        a.logits[e] = out;
+        if (a.logits_fwd && a.dir_fwd) a.logits_fwd[e] = lf;
+        if (a.logits_bwd && a.dir_bwd) a.logits_bwd[e] = lb;
     }
 }
 
@@ -330,9 +452,9 @@ static int dpl_for(int d) {
 
 struct FwdLayout {
     size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
-        in_eid, out_ptr, out_nbr, out_eid, csr_ws, w1p, wt, wsplit, X, h1, feats, total;
+        in_eid, out_ptr, out_nbr, out_eid, csr_ws, wa, wb, wc, wd, vhead, wt, wsplit, hcn, P, RCX, XS, aux, PA, RC, SB,
+        h1n, feats, total;
     int64_t ec;
-    int Kp;
     int dedupe;
 };
 
@@ -345,31 +467,42 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
         return at;
     };
     L.dedupe = (R > 0 && R <= E) ? 1 : 0;
-    L.Kp = 3 * D + 4;
     L.ec = E < kEdgeChunk ? (E > 0 ? E : 1) : kEdgeChunk;
     const size_t f = sizeof(float);
-    L.node_repr = take((size_t)(N > 0 ? N : 1) * D * f);
+    const size_t n1 = (size_t)(N > 0 ? N : 1), e1 = (size_t)(E > 0 ? E : 1);
+    L.node_repr = take(n1 * D * f);
     L.non_text = take((size_t)D * f);
     L.q_proj = take((size_t)B * D * f);
     L.gate_q = take((size_t)B * D * f);
     L.bias_q = take((size_t)B * D * f);
-    L.rel_repr = take((size_t)(L.dedupe ? R : (E > 0 ? E : 1)) * D * f);
+    L.rel_repr = take((size_t)(L.dedupe ? R : e1) * D * f);
     L.rel_rows = take(L.dedupe ? (size_t)R * D * f : 256);
     L.rel_first = take(L.dedupe ? (size_t)R * 4 : 256);
     L.status = take(256);
-    L.ns = take((size_t)(N > 0 ? N : 1) * (F / 2) * f);
+    L.ns = take(n1 * (F / 2) * f);
     L.in_ptr = take((size_t)(N + 1) * 4);
-    L.in_nbr = take((size_t)(E > 0 ? E : 1) * 4);
-    L.in_eid = take((size_t)(E > 0 ? E : 1) * 4);
+    L.in_nbr = take(e1 * 4);
+    L.in_eid = take(e1 * 4);
     L.out_ptr = take((size_t)(N + 1) * 4);
-    L.out_nbr = take((size_t)(E > 0 ? E : 1) * 4);
-    L.out_eid = take((size_t)(E > 0 ? E : 1) * 4);
-    L.csr_ws = take((size_t)(N > 0 ? N : 1) * 8);
-    L.w1p = take((size_t)H * L.Kp * f);
+    L.out_nbr = take(e1 * 4);
+    L.out_eid = take(e1 * 4);
+    L.csr_ws = take(n1 * 8);
+    L.wa = take((size_t)H * D * f);
+    L.wb = take((size_t)H * D * f);
+    L.wc = take((size_t)H * D * f);
+    L.wd = take((size_t)H * f);
+    L.vhead = take((size_t)(H + 1) * f);
     L.wt = take((size_t)F * D * f);
-    L.wsplit = take(gemm_bf16x3_workspace_bytes(H > D ? H : D, L.Kp > H ? L.Kp : H));
-    L.X = take((size_t)dirs * L.ec * L.Kp * f);
-    L.h1 = take((size_t)dirs * L.ec * H * f);
+    L.wsplit = take(gemm_bf16x3_workspace_bytes(H > D ? H : D, H > D ? H : D));
+    L.hcn = take(n1 * H * f);
+    L.P = take((size_t)L.ec * D * f);
+    L.RCX = take((size_t)L.ec * D * f);
+    L.XS = take((size_t)dirs * L.ec * D * f);
+    L.aux = take((size_t)dirs * L.ec * 2 * f);
+    L.PA = take((size_t)L.ec * H * f);
+    L.RC = take((size_t)L.ec * H * f);
+    L.SB = take((size_t)dirs * L.ec * H * f);
+    L.h1n = take((size_t)dirs * L.ec * H * f);
     L.feats = take((size_t)dirs * L.ec * H * f);
     L.total = off;
     return L;
@@ -475,11 +608,18 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
                                   I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
         return rc;
 
-    // 3-4. per edge chunk
-    const int K1 = 3 * D + 1;
-    hipLaunchKernelGGL(k_pad_rows, dim3(H), dim3(256), 0, st, w->state0_w, H, K1, L.Kp, F32(L.w1p));
+    // 3-5. factored state_net.0 (see the header), per edge chunk
+    float *wa = F32(L.wa), *wb = F32(L.wb), *wc = F32(L.wc), *wd = F32(L.wd), *vhead = F32(L.vhead), *hcn = F32(L.hcn);
+    hipLaunchKernelGGL(k_slice_state0, dim3(H), dim3(256), 0, st, w->state0_w, H, D, wa, wb, wc, wd);
     hipLaunchKernelGGL(k_transpose, dim3((F * D + 255) / 256), dim3(256), 0, st, w->struct_w, D, F, F32(L.wt));
     EVI_LAUNCH_CHECK();
+    const bool fold = out->edge_features == nullptr;  // logits only: the head is folded into one vector
+    if (fold) {
+        hipLaunchKernelGGL(k_fold_head, dim3((H + 255) / 256), dim3(256), 0, st, w->state4_w, w->state4_b, w->score_w,
+                           w->score_b, H, vhead);
+        EVI_LAUNCH_CHECK();
+    }
+    if ((rc = scorer_gemm(node_repr, N, D, D, wc, H, D, nullptr, 0, hcn, H, wsplit, st))) return rc;
     const int dpl_d = dpl_for(D), dpl_h = dpl_for(H);
     const size_t feat_lds = (size_t)(F + 4) * D * sizeof(float);
     for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
@@ -503,12 +643,14 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         a.struct_gate_w = w->struct_gate_w;
         a.struct_gate_b = w->struct_gate_b;
         a.D = D;
-        a.Kp = L.Kp;
         a.e_begin = e0;
         a.e_count = ec;
         a.dir_fwd = dir_fwd;
         a.dir_bwd = dir_bwd;
-        a.X = F32(L.X);
+        a.P = F32(L.P);
+        a.RCX = F32(L.RCX);
+        a.XS = F32(L.XS);
+        a.aux = F32(L.aux);
         int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
         if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS: 32 waves per CU hide the gather latency
         const int tok = timing_begin(kTimeEdge, st);
@@ -524,11 +666,39 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
         const int64_t M = (int64_t)dirs * ec;
-        if ((rc = scorer_gemm(F32(L.X), M, L.Kp, L.Kp, F32(L.w1p), H, L.Kp, w->state0_b, 0, F32(L.h1), H, wsplit, st))) return rc;
-        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_layernorm_gelu<DPL>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st,
-                                                   F32(L.h1), M, H, w->state_ln_w, w->state_ln_b));
+        if ((rc = scorer_gemm(F32(L.P), ec, D, D, wa, H, D, nullptr, 0, F32(L.PA), H, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.RCX), ec, D, D, wc, H, D, nullptr, 0, F32(L.RC), H, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.XS), M, D, D, wb, H, D, w->state0_b, 0, F32(L.SB), H, wsplit, st))) return rc;
+        CombineArgs c;
+        c.edge_index = b->edge_index;
+        c.E = E;
+        c.e_begin = e0;
+        c.e_count = ec;
+        c.PA = F32(L.PA);
+        c.RC = F32(L.RC);
+        c.SB = F32(L.SB);
+        c.HcN = hcn;
+        c.aux = F32(L.aux);
+        c.wd = wd;
+        c.ln_w = w->state_ln_w;
+        c.ln_b = w->state_ln_b;
+        c.H = H;
+        c.dir_fwd = dir_fwd;
+        c.dir_bwd = dir_bwd;
+        c.h1n = F32(L.h1n);
+        c.v = vhead;
+        c.logits = out->logits;
+        c.logits_fwd = out->logits_fwd;
+        c.logits_bwd = out->logits_bwd;
+        const dim3 cgrid((unsigned)((ec + 3) / 4));
+        if (fold) {
+            EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, 1>), cgrid, dim3(256), 0, st, c));
+            EVI_LAUNCH_CHECK();
+            continue;
+        }
+        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, 0>), cgrid, dim3(256), 0, st, c));
         EVI_LAUNCH_CHECK();
-        if ((rc = scorer_gemm(F32(L.h1), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.h1n), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st))) return rc;
         EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_score_combine<DPL>, dim3((unsigned)((ec + 3) / 4)), dim3(256), 0, st,
                                                    F32(L.feats), e0, ec, H, dir_fwd, dir_bwd, w->score_w, w->score_b,
                                                    out->logits, out->logits_fwd, out->logits_bwd, out->edge_features));

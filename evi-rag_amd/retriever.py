@@ -123,9 +123,13 @@ class Retriever(nn.Module):
         direction_mode: str = "bidirectional",
         hide_seek_cfg: Optional[Dict[str, Any]] = None,
         dedupe_relations: bool = True,
+        emit_edge_embeddings: bool = True,
         **_: Any,
     ) -> None:
         super().__init__()
+        # False: forward() returns edge_embeddings=None and the library folds score_head into state_net.4
+        # (logits-only evaluation, e.g. predict_step drops edge_embeddings anyway: retriever_module.py:277-285)
+        self.emit_edge_embeddings = bool(emit_edge_embeddings)
         self.emb_dim = int(emb_dim)
         self.hidden_dim = int(hidden_dim)
         self.use_topic_pe = bool(topic_pe)
@@ -316,7 +320,8 @@ class Retriever(nn.Module):
         both = self.direction_mode == "bidirectional"
         logits_fwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "backward" else None
         logits_bwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "forward" else None
-        features = torch.empty((E, H), dtype=torch.float32, device=dev)
+        want_features = return_features or self.emit_edge_embeddings
+        features = torch.empty((E, H), dtype=torch.float32, device=dev) if want_features else None
         w = self._weights_struct()
         b = _lib.EviRetrieverBatch()
         b.num_nodes, b.num_edges, b.num_graphs = N, E, B
@@ -330,7 +335,7 @@ class Retriever(nn.Module):
         o.logits = logits.data_ptr()
         o.logits_fwd = logits_fwd.data_ptr() if logits_fwd is not None else None
         o.logits_bwd = logits_bwd.data_ptr() if logits_bwd is not None else None
-        o.edge_features = features.data_ptr()
+        o.edge_features = features.data_ptr() if features is not None else None
         o.node_struct = None
         need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,
                                                              self.dde.num_reverse_rounds, num_relations))

@@ -496,7 +496,8 @@ typedef struct EviRetrieverOutput {
     float* logits;         /* [E] */
     float* logits_fwd;     /* [E] */
     float* logits_bwd;     /* [E] */
-    float* edge_features;  /* [E, H]  (RetrieverOutput.edge_embeddings / extract_edge_tokens) */
+    float* edge_features;  /* [E, H]  (RetrieverOutput.edge_embeddings / extract_edge_tokens); NULL = logits
+                            * only: score_head is folded into state_net.4 and the [2E, H] features are never formed */
     float* node_struct;    /* [N, 2*(1+rounds+rev)] */
 } EviRetrieverOutput;
 

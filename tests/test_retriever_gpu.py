@@ -261,3 +261,25 @@ def test_retriever_error_contract(dev):
     assert out.logits.numel() == 0 and out.edge_embeddings.shape == (0, 16)
     with pytest.raises(NotImplementedError):
         m.train()(synthetic.as_namespace(sb, device=dev))
+
+
+def test_logits_only_forward_matches_full(dev):
+    """emit_edge_embeddings=False folds score_head into state_net.4: same logits, no feature tensor."""
+    from evi_rag_amd import synthetic
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(6, nodes_per_graph=200, edges_per_graph=700, emb_dim=64, num_relations=30, seed=17)
+    batch = synthetic.as_namespace(sb, device=dev)
+    for mode in ("bidirectional", "forward", "backward"):
+        torch.manual_seed(3)
+        model = Retriever(emb_dim=64, hidden_dim=96, direction_mode=mode).to(dev).eval()
+        full = model(batch)
+        model.emit_edge_embeddings = False
+        lite = model(batch)
+        assert lite.edge_embeddings is None and full.edge_embeddings is not None
+        np.testing.assert_allclose(lite.logits.cpu().numpy(), full.logits.cpu().numpy(), rtol=0, atol=2e-5)
+        if mode == "bidirectional":
+            np.testing.assert_allclose(lite.logits_fwd.cpu().numpy(), full.logits_fwd.cpu().numpy(), rtol=0, atol=2e-5)
+            np.testing.assert_allclose(lite.logits_bwd.cpu().numpy(), full.logits_bwd.cpu().numpy(), rtol=0, atol=2e-5)
+        tokens = model.extract_edge_tokens(batch)  # still available on request
+        np.testing.assert_allclose(tokens.cpu().numpy(), full.edge_embeddings.cpu().numpy(), rtol=0, atol=1e-6)
