@@ -184,6 +184,16 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         coll.update(preds=out.logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=graphs)
     torch.cuda.synchronize(dev)
     t_met = (time.perf_counter() - t0) / iters
+    # logits-only forward (score_head folded into state_net.4; what predict_step keeps)
+    model.emit_edge_embeddings = False
+    model(batch)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        model(batch)
+    torch.cuda.synchronize(dev)
+    t_lite = (time.perf_counter() - t0) / iters
+    model.emit_edge_embeddings = True
     gemm_ms = ms[2] / iters
     tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     exact = os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
@@ -203,6 +213,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     return {
         "workload": f"{graphs} graphs, N={N}, E={E}, D=H={D}, DDE 2+2, bidirectional, k window {K_WINDOW[0]}..{K_WINDOW[-1]}",
         "forward_ms_per_batch": t_fwd * 1e3,
+        "forward_logits_only_ms_per_batch": t_lite * 1e3,
         "metrics_ms_per_batch": t_met * 1e3,
         "queries_per_s": graphs / (t_fwd + t_met),
         "edges_per_s": E / t_fwd,

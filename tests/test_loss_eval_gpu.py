@@ -65,7 +65,7 @@ def test_retriever_loss_webqsp_shape_matches_oracle(dev):
     out = RetrieverLoss(**cfg)(types.SimpleNamespace(logits=lg), torch.from_numpy(targets).to(dev), edge_batch=torch.from_numpy(eb).to(dev),
                                num_graphs=32, edge_is_near=torch.from_numpy(near).to(dev))
     total, comps, mets, grad = oloss.retriever_loss(logits, targets, eb, 32, edge_is_near=near, **cfg)
-    assert abs(float(out.loss) - total) < 2e-5 * max(1.0, abs(total))
+    assert abs(float(out.loss.detach()) - total) < 2e-5 * max(1.0, abs(total))
     for k, v in mets.items():
         assert abs(out.metrics[k] - v) < 2e-5 * max(1.0, abs(v)), k
     out.loss.backward()

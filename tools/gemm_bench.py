@@ -12,7 +12,8 @@ from evi_rag_amd import ops
 def main():
     dev = torch.device("cuda:0")
     shapes = [(131072, 2308, 768, "state_net.0 (one 65536-edge chunk, both directions)"),
-              (131072, 768, 768, "state_net.4"), (50787, 768, 768, "entity_proj")]
+              (131072, 768, 768, "state_net.4 / Wb s (both directions)"), (65536, 768, 768, "Wa p / Wc r_ctx (one chunk)"),
+              (50787, 768, 768, "entity_proj / Wc node_repr")]
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     for M, K, N, name in shapes:
