@@ -89,7 +89,8 @@ struct GraphShared {
     int carry;
 };
 
-// Exclusive scan of cnt[n0..n1) into ptr[n0..n1) (+ base); ptr[n1] = base + total.  All threads call.
+// Exclusive scan of cnt[0..n1-n0) (one counter per node of the graph) into ptr[n0..n1) (+ base);
+// ptr[n1] = base + total.  All threads call.
 __device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt, int32_t* ptr, int64_t n0,
                                             int64_t n1, int base) {
     const int tid = threadIdx.x;
@@ -97,7 +98,7 @@ __device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt,
     __syncthreads();
     for (int64_t v0 = n0; v0 < n1; v0 += kGraphThreads) {
         const int64_t v = v0 + tid;
-        const int val = v < n1 ? cnt[v] : 0;
+        const int val = v < n1 ? cnt[v - n0] : 0;
         sh.scan[tid] = val;
         __syncthreads();
         for (int off = 1; off < kGraphThreads; off <<= 1) {
@@ -117,44 +118,60 @@ __device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kGraphThreads) void k_graph_csr(
-    const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ node_ptr,
-    const int64_t* __restrict__ edge_ptr, int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_nbr,
-    int32_t* __restrict__ in_eid, int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_nbr,
-    int32_t* __restrict__ out_eid, int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out) {
-    __shared__ GraphShared sh;
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
-    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
-    for (int64_t v = n0 + tid; v < n1; v += kGraphThreads) {
-        cnt_in[v] = 0;
-        cnt_out[v] = 0;
-    }
+// Counting-sort CSR of one graph.  cin / cout are the per-node counters, indexed by LOCAL node id: in
+// LDS when the graph's 2 * N_g counters fit the launch's dynamic LDS (ds_add_rtn instead of L2 atomics),
+// else in the global workspace.
+__device__ inline void csr_build(GraphShared& sh, const int64_t* __restrict__ edge_index, int64_t E, int64_t n0,
+                                 int64_t n1, int64_t e0, int64_t e1, int32_t* cin, int32_t* cout,
+                                 int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_nbr, int32_t* __restrict__ in_eid,
+                                 int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_nbr,
+                                 int32_t* __restrict__ out_eid) {
+    const int tid = threadIdx.x;
+    const int ng = (int)(n1 - n0);
+    for (int v = tid; v < ng; v += kGraphThreads) cin[v] = cout[v] = 0;
     __syncthreads();
     for (int64_t e = e0 + tid; e < e1; e += kGraphThreads) {
         const int64_t s = edge_index[e], d = edge_index[E + e];
         if (s < n0 || s >= n1 || d < n0 || d >= n1) continue;  // validated upstream; never scatter outside
-        atomicAdd(&cnt_in[d], 1);
-        atomicAdd(&cnt_out[s], 1);
+        atomicAdd(&cin[d - n0], 1);
+        atomicAdd(&cout[s - n0], 1);
     }
     __syncthreads();
-    block_exclusive_scan(sh, cnt_in, in_ptr, n0, n1, (int)e0);
-    block_exclusive_scan(sh, cnt_out, out_ptr, n0, n1, (int)e0);
-    for (int64_t v = n0 + tid; v < n1; v += kGraphThreads) {
-        cnt_in[v] = in_ptr[v];
-        cnt_out[v] = out_ptr[v];
+    block_exclusive_scan(sh, cin, in_ptr, n0, n1, (int)e0);
+    block_exclusive_scan(sh, cout, out_ptr, n0, n1, (int)e0);
+    for (int v = tid; v < ng; v += kGraphThreads) {
+        cin[v] = in_ptr[n0 + v];
+        cout[v] = out_ptr[n0 + v];
     }
     __syncthreads();
     for (int64_t e = e0 + tid; e < e1; e += kGraphThreads) {
         const int64_t s = edge_index[e], d = edge_index[E + e];
         if (s < n0 || s >= n1 || d < n0 || d >= n1) continue;
-        const int pi = atomicAdd(&cnt_in[d], 1);
+        const int pi = atomicAdd(&cin[d - n0], 1);
         in_nbr[pi] = (int32_t)s;
         in_eid[pi] = (int32_t)e;
-        const int po = atomicAdd(&cnt_out[s], 1);
+        const int po = atomicAdd(&cout[s - n0], 1);
         out_nbr[po] = (int32_t)d;
         out_eid[po] = (int32_t)e;
     }
+}
+
+__global__ __launch_bounds__(kGraphThreads) void k_graph_csr(
+    const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_nbr,
+    int32_t* __restrict__ in_eid, int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_nbr,
+    int32_t* __restrict__ out_eid, int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out, int lds_nodes) {
+    __shared__ GraphShared sh;
+    extern __shared__ int32_t lds_cnt[];  // [2 * lds_nodes]
+    const int g = blockIdx.x;
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    if (n1 - n0 <= lds_nodes)
+        csr_build(sh, edge_index, E, n0, n1, e0, e1, lds_cnt, lds_cnt + lds_nodes, in_ptr, in_nbr, in_eid, out_ptr,
+                  out_nbr, out_eid);
+    else
+        csr_build(sh, edge_index, E, n0, n1, e0, e1, cnt_in + n0, cnt_out + n0, in_ptr, in_nbr, in_eid, out_ptr, out_nbr,
+                  out_eid);
 }
 
 // ---- DDE --------------------------------------------------------------------------------------------
@@ -303,9 +320,11 @@ extern "C" int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t
                     evi_graph_csr_workspace_bytes(N));
     int32_t* cnt_in = static_cast<int32_t*>(workspace);
     int32_t* cnt_out = cnt_in + (N > 0 ? N : 1);
-    hipLaunchKernelGGL(k_graph_csr, dim3(B), dim3(kGraphThreads), 0, reinterpret_cast<hipStream_t>(stream),
-                       edge_index, E, node_ptr, edge_ptr, in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid,
-                       cnt_in, cnt_out);
+    // 48 KiB of dynamic LDS: the counters of graphs up to 6144 nodes stay on chip (larger graphs use the workspace)
+    constexpr int kLdsNodes = 6144;
+    hipLaunchKernelGGL(k_graph_csr, dim3(B), dim3(kGraphThreads), 2 * kLdsNodes * sizeof(int32_t),
+                       reinterpret_cast<hipStream_t>(stream), edge_index, E, node_ptr, edge_ptr, in_ptr, in_nbr, in_eid,
+                       out_ptr, out_nbr, out_eid, cnt_in, cnt_out, kLdsNodes);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
