@@ -61,13 +61,15 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
     const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ in_ptr,
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
-    int mode, int32_t* __restrict__ dist_out) {
+    int mode, int32_t* __restrict__ dist_out, int lds_nodes) {
     __shared__ int changed;
+    extern __shared__ int32_t lds_dist[];  // [lds_nodes]: the levels of graphs that fit stay on chip until the end
     const int j = blockIdx.x, tid = threadIdx.x;
     const int g = job_graph[j];
     const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
     const int ng = (int)(n1 - n0);
-    int32_t* dist = dist_out + dist_off[j];  // local node id -> level
+    int32_t* out = dist_out + dist_off[j];  // local node id -> level
+    int32_t* dist = ng <= lds_nodes ? lds_dist : out;
     for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
     __syncthreads();
     for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
@@ -75,6 +77,10 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
         if (s >= n0 && s < n1) dist[s - n0] = 0;  // out-of-range sources are ignored (:619)
     }
     bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &changed);
+    if (dist != out) {
+        __syncthreads();
+        for (int v = tid; v < ng; v += kBfsThreads) out[v] = dist[v];
+    }
 }
 
 // One workgroup per job (graph, source set, target set): the reference's deterministic single shortest
@@ -246,8 +252,10 @@ extern "C" int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, 
     EVI_REQUIRE(mode >= 0 && mode <= 2, "evi_bfs_levels: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
     if (num_jobs == 0) return EVI_OK;
     EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels: null pointer");
-    hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), 0, reinterpret_cast<hipStream_t>(stream),
-                       job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, mode, dist_out);
+    constexpr int kLdsNodes = 12288;  // 48 KiB of dynamic LDS
+    hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), kLdsNodes * sizeof(int32_t),
+                       reinterpret_cast<hipStream_t>(stream), job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr,
+                       out_ptr, out_nbr, mode, dist_out, kLdsNodes);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
