@@ -19,20 +19,42 @@ namespace evi {
 
 constexpr int kBfsThreads = 1024;
 
+constexpr int kBfsHubDegree = 128;  // frontier nodes with more neighbours are expanded by a whole wave
+constexpr int kBfsHubCap = 1024;
+
+struct BfsShared {
+    int changed;
+    int hub_count;
+    int hubs[kBfsHubCap];
+};
+
 // Level-synchronous expansion of the sources already marked 0 in dist[0..ng) (everything else -1).
 // mode 0: undirected (out- and in-rows), 1: follow edges (out-rows), 2: against edges (in-rows).
+// A frontier node is expanded by the thread that finds it, unless its rows are long (power-law hubs):
+// those are queued in LDS and expanded by one wave each, lanes striding the row.
 // Every thread of the workgroup calls; returns after the first empty frontier.
 __device__ inline void bfs_block(int32_t* __restrict__ dist, int ng, int64_t n0, const int32_t* __restrict__ in_ptr,
                                  const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr,
-                                 const int32_t* __restrict__ out_nbr, int mode, int* changed) {
-    const int tid = threadIdx.x;
+                                 const int32_t* __restrict__ out_nbr, int mode, BfsShared* sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int level = 0;; ++level) {
-        if (tid == 0) *changed = 0;
+        if (tid == 0) {
+            sh->changed = 0;
+            sh->hub_count = 0;
+        }
         __syncthreads();
         bool any = false;
         for (int v = tid; v < ng; v += kBfsThreads) {
             if (dist[v] != level) continue;
             const int64_t gv = n0 + v;
+            const int deg = (mode != 2 ? out_ptr[gv + 1] - out_ptr[gv] : 0) + (mode != 1 ? in_ptr[gv + 1] - in_ptr[gv] : 0);
+            if (deg > kBfsHubDegree) {
+                const int slot = atomicAdd(&sh->hub_count, 1);
+                if (slot < kBfsHubCap) {
+                    sh->hubs[slot] = v;
+                    continue;
+                }  // queue full: expand it here (correct, slower)
+            }
             if (mode != 2)
                 for (int p = out_ptr[gv]; p < out_ptr[gv + 1]; ++p) {
                     const int w = out_nbr[p] - (int)n0;
@@ -50,9 +72,30 @@ __device__ inline void bfs_block(int32_t* __restrict__ dist, int ng, int64_t n0,
                     }
                 }
         }
-        if (any) *changed = 1;
         __syncthreads();
-        if (!*changed) break;  // every wave reaches this: the frontier is empty
+        const int nh = sh->hub_count < kBfsHubCap ? sh->hub_count : kBfsHubCap;
+        for (int h = wave; h < nh; h += kBfsThreads / 64) {
+            const int64_t gv = n0 + sh->hubs[h];
+            if (mode != 2)
+                for (int p = out_ptr[gv] + lane; p < out_ptr[gv + 1]; p += 64) {
+                    const int w = out_nbr[p] - (int)n0;
+                    if (dist[w] < 0) {
+                        dist[w] = level + 1;
+                        any = true;
+                    }
+                }
+            if (mode != 1)
+                for (int p = in_ptr[gv] + lane; p < in_ptr[gv + 1]; p += 64) {
+                    const int w = in_nbr[p] - (int)n0;
+                    if (dist[w] < 0) {
+                        dist[w] = level + 1;
+                        any = true;
+                    }
+                }
+        }
+        if (any) sh->changed = 1;
+        __syncthreads();
+        if (!sh->changed) break;  // every wave reaches this: the frontier is empty
         __syncthreads();
     }
 }
@@ -62,7 +105,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ in_ptr,
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
     int mode, int32_t* __restrict__ dist_out, int lds_nodes) {
-    __shared__ int changed;
+    __shared__ BfsShared sh;
     extern __shared__ int32_t lds_dist[];  // [lds_nodes]: the levels of graphs that fit stay on chip until the end
     const int j = blockIdx.x, tid = threadIdx.x;
     const int g = job_graph[j];
@@ -76,7 +119,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
         const int64_t s = src_idx[i];
         if (s >= n0 && s < n1) dist[s - n0] = 0;  // out-of-range sources are ignored (:619)
     }
-    bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &changed);
+    bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &sh);
     if (dist != out) {
         __syncthreads();
         for (int v = tid; v < ng; v += kBfsThreads) out[v] = dist[v];
@@ -98,7 +141,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_shortest_path_single(
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ in_eid, const int32_t* __restrict__ out_ptr,
     const int32_t* __restrict__ out_nbr, const int32_t* __restrict__ out_eid, int32_t* __restrict__ dist_ws, int path_cap,
     int32_t* __restrict__ out_len, int64_t* __restrict__ out_nodes, int64_t* __restrict__ out_edges) {
-    __shared__ int changed;
+    __shared__ BfsShared sh;
     __shared__ unsigned long long best;
     const int j = blockIdx.x, tid = threadIdx.x;
     const int g = job_graph[j];
@@ -116,7 +159,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_shortest_path_single(
         const int64_t s = src_idx[i];
         if (s >= n0 && s < n1) ds[s - n0] = 0;
     }
-    bfs_block(ds, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, 0, &changed);
+    bfs_block(ds, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, 0, &sh);
     // nearest reachable target, smallest id on ties (:501-508)
     for (int64_t i = tgt_ptr[j] + tid; i < tgt_ptr[j + 1]; i += kBfsThreads) {
         const int64_t t = tgt_idx[i];
@@ -136,7 +179,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_shortest_path_single(
         dt[target] = 0;
         best = kNone;
     }
-    bfs_block(dt, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, 0, &changed);
+    bfs_block(dt, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, 0, &sh);
     for (int v = tid; v < ng; v += kBfsThreads)
         if (ds[v] == 0 && dt[v] == D) atomicMin(&best, (unsigned long long)v);
     __syncthreads();
