@@ -21,8 +21,10 @@ from . import _lib, ops
 logger = logging.getLogger(__name__)
 
 
-def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """table[ids] on the device (IndexError for ids outside the table, like index_select)."""
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, *, status: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """table[ids] on the device (IndexError for ids outside the table, like index_select).  With a
+    caller-owned `status` (int32 [1], zeroed) the range check is DEFERRED: the kernel ORs a flag into it
+    and the caller reads it later (no host synchronisation here)."""
     dev = ops._require_gpu(table)
     table = ops._f32c(table, "table")
     if table.dim() != 2:
@@ -32,11 +34,13 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     out = torch.empty((n, D), dtype=torch.float32, device=dev)
     if n == 0 or D == 0:
         return out
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    deferred = status is not None
+    if not deferred:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
     lib = _lib.load()
     _lib.check(lib.evi_gather_rows(ops._ptr(table), table.size(0), D, ops._ptr(ids), n, ops._ptr(out), status.data_ptr(),
                                    ops._stream(dev)))
-    if int(status.item()) != 0:
+    if not deferred and int(status.item()) != 0:
         raise IndexError(f"index out of range in gather_rows: table has {table.size(0)} rows")
     return out
 
@@ -96,21 +100,36 @@ class GlobalEmbeddingStore:
         t = torch.load(path, map_location="cpu", weights_only=True)
         return t.to(self.device, torch.float32).contiguous()
 
-    def get_entity_embeddings(self, entity_ids: torch.Tensor, *, device: Optional[torch.device] = None) -> torch.Tensor:
+    def get_entity_embeddings(self, entity_ids: torch.Tensor, *, device: Optional[torch.device] = None,
+                              status: Optional[torch.Tensor] = None) -> torch.Tensor:
         if entity_ids.numel() == 0:
             return torch.empty((0, int(self.entity_embeddings.size(1))), dtype=self.entity_embeddings.dtype, device=self.device)
-        return gather_rows(self.entity_embeddings, entity_ids)
+        return gather_rows(self.entity_embeddings, entity_ids, status=status)
 
-    def get_relation_embeddings(self, relation_ids: torch.Tensor, *, device: Optional[torch.device] = None) -> torch.Tensor:
+    def get_relation_embeddings(self, relation_ids: torch.Tensor, *, device: Optional[torch.device] = None,
+                                status: Optional[torch.Tensor] = None) -> torch.Tensor:
         if relation_ids.numel() == 0:
             return torch.empty((0, int(self.relation_embeddings.size(1))), dtype=self.relation_embeddings.dtype, device=self.device)
-        return gather_rows(self.relation_embeddings, relation_ids)
+        return gather_rows(self.relation_embeddings, relation_ids, status=status)
 
-    def attach(self, batch) -> None:
-        """`RetrievalCollater._attach_embeddings` (src/data/components/loader.py:60-66), on the device."""
-        batch.node_embeddings = self.get_entity_embeddings(torch.as_tensor(batch.node_embedding_ids))
-        batch.edge_embeddings = self.get_relation_embeddings(torch.as_tensor(batch.edge_attr))
+    def attach(self, batch, *, check: bool = True) -> None:
+        """`RetrievalCollater._attach_embeddings` (src/data/components/loader.py:60-66), on the device.
+        check=False defers the id range check to `raise_if_failed()` (one read per epoch, not per batch)."""
+        status = None
+        if not check:
+            if getattr(self, "_deferred_status", None) is None:
+                self._deferred_status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            status = self._deferred_status
+        batch.node_embeddings = self.get_entity_embeddings(torch.as_tensor(batch.node_embedding_ids), status=status)
+        batch.edge_embeddings = self.get_relation_embeddings(torch.as_tensor(batch.edge_attr), status=status)
         batch.num_relations = int(self.relation_embeddings.size(0))
+
+    def raise_if_failed(self) -> None:
+        """Reports an out-of-range id seen by any deferred gather since the last call."""
+        st = getattr(self, "_deferred_status", None)
+        if st is not None and int(st.item()) != 0:
+            st.zero_()
+            raise IndexError("index out of range in gather_rows: an embedding id exceeds its table")
 
     @property
     def entity_dim(self) -> int:

@@ -37,7 +37,8 @@ class RetrieverEvaluator:
 
     def reset(self) -> None:
         self.metrics.reset()
-        self._loss_sum = 0.0
+        self._loss_sum = 0.0          # host part (batches whose loss was read eagerly)
+        self._loss_dev = None         # device accumulator: sum over batches of loss * num_graphs
         self._graphs = 0
         self._batches = 0
 
@@ -72,9 +73,22 @@ class RetrieverEvaluator:
         """`_shared_eval_step` (:410-451)."""
         num_graphs = self._require_num_graphs(batch)
         output = self.model(batch)
-        loss_out = self._compute_loss_output(batch, output, num_graphs)
-        self._loss_sum += float(loss_out.components["infonce"] * self.loss.infonce_weight
-                                + loss_out.components["bce"] * self.loss.bce_weight) * num_graphs
+        edge_ptr = getattr(batch, "edge_ptr", None)
+        if edge_ptr is not None and isinstance(self.loss, RetrieverLoss):
+            # edges grouped by graph (compute_edge_batch validated it): loss scalars stay on the device
+            near = None
+            if self.loss.requires_edge_is_near:
+                near = getattr(batch, "edge_is_near", None)
+                if near is None:
+                    near = batch.edge_is_near = ops.qa_edge_mask(batch.edge_index, int(batch.num_nodes), batch.q_local_indices,
+                                                                 batch.a_local_indices)
+            sc = self.loss.device_scalars(output.logits, batch.labels, edge_ptr, near)
+            term = sc[2] * float(num_graphs)
+            self._loss_dev = term if self._loss_dev is None else self._loss_dev + term
+        else:
+            loss_out = self._compute_loss_output(batch, output, num_graphs)
+            self._loss_sum += float(loss_out.components["infonce"] * self.loss.infonce_weight
+                                    + loss_out.components["bce"] * self.loss.bce_weight) * num_graphs
         self._graphs += num_graphs
         self._batches += 1
         scores = output.logits.detach().view(-1)
@@ -100,6 +114,9 @@ class RetrieverEvaluator:
         """`on_test_epoch_end` (:401-403): metric dict + the epoch loss; sync=True sums the metric states
         and the loss accumulators over ranks first (dist_reduce_fx="sum", sync_dist=True)."""
         loss_sum, graphs = self._loss_sum, float(self._graphs)
+        if self._loss_dev is not None:
+            loss_sum += float(self._loss_dev.item())
+            self._loss_dev = None
         if sync:
             from .dist import all_reduce_sum_
 
@@ -120,6 +137,9 @@ class RetrieverEvaluator:
         t0 = time.perf_counter()
         for i, batch in enumerate(loader):
             self.step(batch, i)
+        check = getattr(getattr(loader, "dataset", None), "check_deferred", None)
+        if check is not None:
+            check()  # deferred embedding-id range checks of the collated batches
         metrics = self.epoch_end(sync=sync)
         torch.cuda.synchronize()
         seconds = time.perf_counter() - t0

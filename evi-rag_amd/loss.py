@@ -120,6 +120,30 @@ class RetrieverLoss(torch.nn.Module):
             metrics={"pos_prob": v[10], "neg_prob": v[11], "separation": v[12], **infonce_metrics, "bce_graphs": v[8],
                      "bce_edges": v[9], "path_graphs": 0.0})
 
+    def device_scalars(self, logits: torch.Tensor, targets: torch.Tensor, edge_ptr: torch.Tensor,
+                       edge_is_near: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The 15 loss scalars of `evi_retriever_loss` as a DEVICE tensor (index 2 = the weighted total),
+        for callers that accumulate over batches and read once per epoch.  Edges must be grouped by
+        graph (edge_ptr [B+1]); nothing is copied to the host."""
+        dev = ops._require_gpu(logits)
+        x = logits.detach().view(-1).to(torch.float32).contiguous()
+        t = targets.to(dev).view(-1).float().contiguous()
+        ptr = edge_ptr.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+        B = int(ptr.numel() - 1)
+        near_u8 = None
+        if self.requires_edge_is_near:
+            if edge_is_near is None:
+                raise ValueError("RetrieverLoss requires edge_is_near when edge weights are enabled.")
+            near_u8 = edge_is_near.to(device=dev).view(-1).to(torch.uint8).contiguous()
+        scalars = torch.zeros(16, dtype=torch.float64, device=dev)
+        lib = _lib.load()
+        ws = ops._workspace(dev, "retriever_loss", int(lib.evi_retriever_loss_workspace_bytes(B)))
+        _lib.check(lib.evi_retriever_loss(
+            ops._ptr(x), ops._ptr(t), ops._ptr(ptr), B, ops._ptr(near_u8), self.infonce_temperature, self.infonce_weight,
+            self.bce_weight, self.edge_weight_near, self.edge_weight_bridge, scalars.data_ptr(), None, ws.data_ptr(), ws.numel(),
+            ops._stream(dev)))
+        return scalars
+
     def _launch(self, x, targets, edge_batch, num_graphs, near, want_grad):
         dev = x.device
         counts = torch.bincount(edge_batch.clamp(0, num_graphs - 1), minlength=num_graphs)

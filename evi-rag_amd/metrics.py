@@ -128,7 +128,8 @@ def rank_batch(preds: torch.Tensor, target: Optional[torch.Tensor], batch: Any, 
             raise ValueError(f"preds/target/indexes mismatch: {tuple(scores.shape)} vs {tuple(tgt.shape)}")
 
     nk, k_max = len(ks), ks[-1]
-    N = int(node_ptr[-1].item()) if node_ptr.numel() else 0
+    N = _attr(batch, "num_nodes")
+    N = int(N) if N is not None else (int(node_ptr[-1].item()) if node_ptr.numel() else 0)
     f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
     u8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)  # noqa: E731
     res = dict(edge_recall=f32(B, nk), recall_valid=u8(B), reach=u8(B, nk), reach_valid=u8(B), answer_hit=u8(B, nk),
@@ -148,22 +149,61 @@ def rank_batch(preds: torch.Tensor, target: Optional[torch.Tensor], batch: Any, 
         p(res["answer_hit"]), p(res["answer_recall"]), p(res["answer_valid"]), p(res["score_margin"]),
         p(res["margin_valid"]), p(res.get("topk_index")), p(res.get("topk_score")), p(res.get("topk_count")),
         uf_ws.data_ptr(), ops._stream(dev)))
-    if have_answers and bool((res["answer_valid"] == 2).any().item()):
-        raise NotImplementedError("a graph has more than 2048 answer entities")
-    return RankedBatch(ks, edge_ptr=edge_ptr, have_answers=have_answers, **res)
+    # answer_valid == 2 marks a graph with more than 2048 answer entities; metrics raise when their states are read
+    too_many = (res["answer_valid"] == 2).any() if have_answers else None
+    return RankedBatch(ks, edge_ptr=edge_ptr, have_answers=have_answers, too_many_answers=too_many, **res)
 
 
 class _SumMetric:
-    """Minimal torchmetrics-style base: named f64 sum states, reset(), sync()."""
+    """Minimal torchmetrics-style base: named f64 sum states, reset(), sync().
+
+    `update` never reads the device: every batch's contributions are added to one f64 device vector
+    (`_accumulate`), and the host-side `_states` are brought up to date only when somebody looks
+    (`compute`, `sync`, `_flush`) — the reference's `.item()` per metric per batch stalls the stream."""
 
     def __init__(self, **_: Any) -> None:
         self._states: Dict[str, float] = {}
+        self._order: Dict[str, int] = {}
+        self._dev_acc: Optional[torch.Tensor] = None
+        self._idx_cache: Dict[Any, torch.Tensor] = {}
+        self._overflow: Optional[torch.Tensor] = None
         self._shared: Optional[RankedBatch] = None  # set by RetrieverMetricCollection for the current batch
 
     def _add_state(self, name: str) -> None:
+        self._order[name] = len(self._states)
         self._states[name] = 0.0
 
+    def _accumulate(self, names: Sequence[str], values: torch.Tensor) -> None:
+        """states[names[i]] += values[i], on the device (values: 1-D, any float dtype)."""
+        dev = values.device
+        if self._dev_acc is None or self._dev_acc.device != dev:
+            self._flush()
+            self._dev_acc = torch.zeros(len(self._states), dtype=torch.float64, device=dev)
+        key = (tuple(names), dev)
+        idx = self._idx_cache.get(key)
+        if idx is None:
+            idx = self._idx_cache[key] = torch.tensor([self._order[n] for n in names], dtype=torch.long, device=dev)
+        self._dev_acc.index_add_(0, idx, values.to(torch.float64).view(-1))
+
+    def _note_overflow(self, flag: Optional[torch.Tensor]) -> None:
+        if flag is not None:
+            self._overflow = flag if self._overflow is None else (self._overflow | flag)
+
+    def _flush(self) -> None:
+        if self._overflow is not None:
+            bad = bool(self._overflow.item())
+            self._overflow = None
+            if bad:
+                raise NotImplementedError("a graph has more than 2048 answer entities")
+        if self._dev_acc is not None:
+            vals = self._dev_acc.tolist()
+            self._dev_acc.zero_()
+            for n, i in self._order.items():
+                self._states[n] += vals[i]
+
     def reset(self) -> None:
+        self._dev_acc = None
+        self._overflow = None
         for k in self._states:
             self._states[k] = 0.0
 
@@ -171,6 +211,7 @@ class _SumMetric:
         """All-reduce (SUM) the states across ranks — the reference's dist_reduce_fx="sum"."""
         import torch.distributed as dist
 
+        self._flush()
         if not (dist.is_available() and dist.is_initialized()):
             return
         names = sorted(self._states)
@@ -206,12 +247,13 @@ class EdgeRecallAtK(_SumMetric):
             return
         rb = self._ranked(preds, target, batch, self.k_values, num_graphs, indexes)
         valid = rb.recall_valid.bool()
-        self._states["graph_count"] += float(valid.sum().item())
-        sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0).tolist()
-        for k in self.k_values:
-            self._states[f"recall_sum_at_{k}"] += sums[self._col(rb, k)]
+        sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0)
+        cols = [self._col(rb, k) for k in self.k_values]
+        self._accumulate([f"recall_sum_at_{k}" for k in self.k_values] + ["graph_count"],
+                         torch.cat([sums[cols], valid.sum().double().view(1)]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         denom = max(self._states["graph_count"], 1.0)
         return {f"edge/recall@{k}": torch.tensor(self._states[f"recall_sum_at_{k}"] / denom, dtype=torch.float32)
                 for k in self.k_values}
@@ -232,15 +274,12 @@ class AnswerReachability(_SumMetric):
             return
         rb = self._ranked(preds, target, batch, self.k_values, num_graphs, query_ids)
         valid = rb.reach_valid.bool()
-        n_valid = float(valid.sum().item())
-        if n_valid <= 0:
-            return
-        self._states["total"] += n_valid
-        hits = (rb.reach.double() * valid.unsqueeze(1)).sum(0).tolist()
-        for k in self.k_values:
-            self._states[f"hits_at_{k}"] += hits[self._col(rb, k)]
+        hits = (rb.reach.double() * valid.unsqueeze(1)).sum(0)
+        cols = [self._col(rb, k) for k in self.k_values]
+        self._accumulate([f"hits_at_{k}" for k in self.k_values] + ["total"], torch.cat([hits[cols], valid.sum().double().view(1)]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         denom = max(self._states["total"], 1.0)
         return {f"answer/reachability@{k}": torch.tensor(self._states[f"hits_at_{k}"] / denom, dtype=torch.float32)
                 for k in self.k_values}
@@ -265,15 +304,16 @@ class AnswerHitAtK(_SumMetric):
         rb = self._ranked(preds, target, batch, self.k_values, num_graphs, indexes)
         if not rb.have_answers:
             raise ValueError("Batch missing node_global_ids/answer_entity_ids required for answer hit metrics.")
-        valid = rb.answer_valid.bool()
-        self._states["sample_count"] += float(valid.sum().item())
-        hit = (rb.answer_hit.double() * valid.unsqueeze(1)).sum(0).tolist()
-        rec = (rb.answer_recall.double() * valid.unsqueeze(1)).sum(0).tolist()
-        for k in self.k_values:
-            self._states[f"hit_sum_at_{k}"] += hit[self._col(rb, k)]
-            self._states[f"recall_sum_at_{k}"] += rec[self._col(rb, k)]
+        self._note_overflow(rb.too_many_answers)
+        valid = rb.answer_valid == 1
+        hit = (rb.answer_hit.double() * valid.unsqueeze(1)).sum(0)
+        rec = (rb.answer_recall.double() * valid.unsqueeze(1)).sum(0)
+        cols = [self._col(rb, k) for k in self.k_values]
+        self._accumulate([f"hit_sum_at_{k}" for k in self.k_values] + [f"recall_sum_at_{k}" for k in self.k_values] + ["sample_count"],
+                         torch.cat([hit[cols], rec[cols], valid.sum().double().view(1)]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         n = self._states["sample_count"]
         out = {}
         for k in self.k_values:
@@ -296,10 +336,11 @@ class ScoreMargin(_SumMetric):
             return
         rb = self._ranked(preds, target, batch, [1], num_graphs, indexes)
         valid = rb.margin_valid.bool()
-        self._states["graph_count"] += float(valid.sum().item())
-        self._states["margin_sum"] += float((rb.score_margin.double() * valid).sum().item())
+        self._accumulate(["graph_count", "margin_sum"],
+                         torch.stack([valid.sum().double(), (rb.score_margin.double() * valid).sum()]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         denom = max(self._states["graph_count"], 1.0)
         return {"edge/score_margin": torch.tensor(self._states["margin_sum"] / denom, dtype=torch.float32)}
 
@@ -372,12 +413,13 @@ class BridgeEdgeRecallAtK(_SumMetric):
         rb = rank_batch(s, t, fake, self.k_values, num_graphs=B)
         stats = _class_stats(s, t.to(torch.uint8), eptr, B)
         valid = (stats[:, 0] > 0) & rb.recall_valid.bool()  # graphs without a bridge positive are skipped (:239-241)
-        self._states["graph_count"] += float(valid.sum().item())
-        sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0).tolist()
-        for k in self.k_values:
-            self._states[f"recall_sum_at_{k}"] += sums[self._col(rb, k)]
+        sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0)
+        cols = [self._col(rb, k) for k in self.k_values]
+        self._accumulate([f"recall_sum_at_{k}" for k in self.k_values] + ["graph_count"],
+                         torch.cat([sums[cols], valid.sum().double().view(1)]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         denom = max(self._states["graph_count"], 1.0)
         return {f"bridge/recall@{k}": torch.tensor(self._states[f"recall_sum_at_{k}"] / denom, dtype=torch.float32)
                 for k in self.k_values}
@@ -397,13 +439,13 @@ class BridgePositiveCoverage(_SumMetric):
         s, t, eptr, bridge, tgt_all, full_ptr, B = _bridge_sublists(preds, target, batch, num_graphs, indexes)
         all_stats = _class_stats(preds.detach().reshape(-1).float().contiguous(), tgt_all.to(torch.uint8).contiguous(), full_ptr, B)
         br_stats = _class_stats(s, t.to(torch.uint8), eptr, B) if s.numel() else torch.zeros((B, 4), dtype=torch.float64, device=s.device)
-        self._states["total_pos_edges"] += float(all_stats[:, 0].sum().item())
-        self._states["bridge_pos_edges"] += float(br_stats[:, 0].sum().item())
         has_pos = all_stats[:, 0] > 0
-        self._states["graphs_with_pos"] += float(has_pos.sum().item())
-        self._states["graphs_with_bridge_pos"] += float((has_pos & (br_stats[:, 0] > 0)).sum().item())
+        self._accumulate(["total_pos_edges", "bridge_pos_edges", "graphs_with_pos", "graphs_with_bridge_pos"],
+                         torch.stack([all_stats[:, 0].sum(), br_stats[:, 0].sum(), has_pos.sum().double(),
+                                      (has_pos & (br_stats[:, 0] > 0)).sum().double()]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         e = max(self._states["total_pos_edges"], 1.0)
         g = max(self._states["graphs_with_pos"], 1.0)
         return {"bridge/pos_edge_frac": torch.tensor(self._states["bridge_pos_edges"] / e, dtype=torch.float32),
@@ -429,12 +471,12 @@ class BridgeProbQuality(_SumMetric):
         valid = (st[:, 0] > 0) & (st[:, 1] > 0)
         pos_mean = (st[:, 2] / st[:, 0].clamp(min=1.0)).float().double()  # per-graph means are f32 in the reference
         neg_mean = (st[:, 3] / st[:, 1].clamp(min=1.0)).float().double()
-        self._states["pos_prob_sum"] += float((pos_mean * valid).sum().item())
-        self._states["neg_prob_sum"] += float((neg_mean * valid).sum().item())
-        self._states["sep_sum"] += float(((pos_mean - neg_mean) * valid).sum().item())
-        self._states["graph_count"] += float(valid.sum().item())
+        self._accumulate(["pos_prob_sum", "neg_prob_sum", "sep_sum", "graph_count"],
+                         torch.stack([(pos_mean * valid).sum(), (neg_mean * valid).sum(), ((pos_mean - neg_mean) * valid).sum(),
+                                      valid.sum().double()]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         d = max(self._states["graph_count"], 1.0)
         return {"bridge/pos_prob": torch.tensor(self._states["pos_prob_sum"] / d, dtype=torch.float32),
                 "bridge/neg_prob": torch.tensor(self._states["neg_prob_sum"] / d, dtype=torch.float32),

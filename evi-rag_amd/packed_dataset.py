@@ -141,6 +141,7 @@ class PackedRetrievalDataset:
         self.global_embeddings = embeddings
         load = lambda name: torch.from_numpy(np.load(self.root / f"{name}.npy", mmap_mode="r")[...].copy()).to(self.device)  # noqa: E731
         self.ptr = {fam: load(f"ptr_{fam}") for fam in _FAMILIES}
+        self.ptr_h = {fam: np.load(self.root / f"ptr_{fam}.npy") for fam in _FAMILIES}  # host copies: batch offsets need no device read
         self.cols = {key: load(key) for key in _FIELDS}
         self.question_emb = load("question_emb")
         self.num_topics = int(self.meta["num_topics"])
@@ -159,22 +160,26 @@ class PackedRetrievalDataset:
     def collate(self, indices: Union[Sequence[int], torch.Tensor]) -> SimpleNamespace:
         """The batch the reference's loader yields for these samples, assembled on the device."""
         dev = self.device
-        ids = torch.as_tensor(indices, dtype=torch.int64).to(dev).contiguous().view(-1)
-        B = int(ids.numel())
+        ids_h = np.asarray(indices.cpu() if isinstance(indices, torch.Tensor) else indices, dtype=np.int64).reshape(-1)
+        B = int(ids_h.size)
         if B == 0:
             raise ValueError("cannot collate an empty batch")
-        lib = _lib.load()
         S = len(self)
-        st = ops._stream(dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
-        out_ptr: Dict[str, torch.Tensor] = {}
-        for fam in _FAMILIES:
-            p = torch.empty(B + 1, dtype=torch.int64, device=dev)
-            _lib.check(lib.evi_segment_offsets(self.ptr[fam].data_ptr(), S, ids.data_ptr(), B, p.data_ptr(), status.data_ptr(), st))
-            out_ptr[fam] = p
-        totals = torch.stack([out_ptr[f][-1] for f in _FAMILIES]).cpu().tolist()  # the one host read of a batch
-        if int(status.item()) != 0:
+        if ids_h.min() < 0 or ids_h.max() >= S:
             raise IndexError(f"sample index out of range for a split of {S} samples")
+        lib = _lib.load()
+        st = ops._stream(dev)
+        # batch offsets of every field family from the host copies of the pointer arrays: one small H2D copy,
+        # no device->host read anywhere in the collation (evi_segment_offsets does the same on the device
+        # for callers whose sample ids live there)
+        offs = np.zeros((len(_FAMILIES), B + 1), np.int64)
+        for f, fam in enumerate(_FAMILIES):
+            p = self.ptr_h[fam]
+            np.cumsum(p[ids_h + 1] - p[ids_h], out=offs[f, 1:])
+        packed = torch.from_numpy(np.concatenate([ids_h, offs.reshape(-1)])).to(dev, non_blocking=True)
+        ids = packed[:B]
+        out_ptr = {fam: packed[B + f * (B + 1): B + (f + 1) * (B + 1)] for f, fam in enumerate(_FAMILIES)}
+        totals = offs[:, -1]
         total = dict(zip(_FAMILIES, (int(t) for t in totals)))
         inc = {"nodes": out_ptr["node"], "edges": out_ptr["edge"], None: None}
         got: Dict[str, torch.Tensor] = {}
@@ -196,20 +201,25 @@ class PackedRetrievalDataset:
         b.ptr = out_ptr["node"]
         b.edge_ptr = out_ptr["edge"]
         b.num_graphs, b.num_nodes = B, total["node"]
-        b.batch = torch.repeat_interleave(torch.arange(B, device=dev), b.ptr[1:] - b.ptr[:-1])
-        b.edge_batch = torch.repeat_interleave(torch.arange(B, device=dev), b.edge_ptr[1:] - b.edge_ptr[:-1])
+        graph_ids = torch.arange(B, device=dev)  # output sizes are known on the host: no device read
+        b.batch = torch.repeat_interleave(graph_ids, b.ptr[1:] - b.ptr[:-1], output_size=total["node"])
+        b.edge_batch = torch.repeat_interleave(graph_ids, b.edge_ptr[1:] - b.edge_ptr[:-1], output_size=total["edge"])
         b.question_emb = self.question_emb.index_select(0, ids)
         b.answer_entity_ids_ptr = out_ptr["answer"]
         b._slice_dict = {"edge_index": out_ptr["edge"], "q_local_indices": out_ptr["q"], "a_local_indices": out_ptr["a"],
                          "answer_entity_ids": out_ptr["answer"], "pair_edge_local_ids": out_ptr["pair_edge"],
                          "pair_start_node_locals": out_ptr["pair"], "seed_entity_ids": out_ptr["seed"]}
-        ids_h = ids.cpu().tolist()
         b.idx = ids
-        b.sample_id = [self.sample_ids[i] for i in ids_h]
-        b.question = [self.questions[i] for i in ids_h]
+        b.sample_id = [self.sample_ids[i] for i in ids_h.tolist()]
+        b.question = [self.questions[i] for i in ids_h.tolist()]
         if self.global_embeddings is not None:
-            self.global_embeddings.attach(b)
+            self.global_embeddings.attach(b, check=False)  # range check deferred: check_deferred()
         return b
+
+    def check_deferred(self) -> None:
+        """Raises if any batch collated since the last call carried an embedding id outside its table."""
+        if self.global_embeddings is not None:
+            self.global_embeddings.raise_if_failed()
 
     def load_sample(self, sample_id: str) -> Dict[str, Any]:
         """Per-sample metadata with the LMDB keys `GAgentBuilder` reads (question_emb, question,

@@ -311,9 +311,13 @@ class Retriever(nn.Module):
         num_relations = 0
         if self.dedupe_relations:
             hint = getattr(batch, "num_relations", None)
-            num_relations = int(hint) if hint is not None else int(edge_attr.max().item()) + 1
-            if num_relations > E or int(edge_attr.min().item()) < 0:
-                num_relations = 0
+            if hint is not None:
+                # stated by whoever gathered edge_embeddings by these ids (the gather range-checks them): no device read
+                num_relations = int(hint) if 0 < int(hint) <= E else 0
+            else:
+                num_relations = int(edge_attr.max().item()) + 1
+                if num_relations > E or int(edge_attr.min().item()) < 0:
+                    num_relations = 0
 
         lib = _lib.load()
         logits = torch.empty(E, dtype=torch.float32, device=dev)

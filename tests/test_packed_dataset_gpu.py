@@ -101,3 +101,37 @@ def test_loader_feeds_retriever_and_metrics(dev, tmp_path):
     parts = [pd.PackedLoader(ds, batch_size=4, shuffle=True, random_seed=3, rank=r, world_size=2) for r in range(2)]
     ids = sorted(i for p in parts for b in p for i in b.idx.cpu().tolist())
     assert ids == list(range(12))
+
+
+def test_segment_offsets_kernel_matches_numpy(dev):
+    """evi_segment_offsets (device-side batch offsets for sample ids that live on the device)."""
+    from evi_rag_amd import _lib, ops
+
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 50, 400)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for B in (1, 7, 1024, 3000):
+        ids = rng.integers(0, 400, B).astype(np.int64)
+        out = torch.empty(B + 1, dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().evi_segment_offsets(torch.from_numpy(ptr).to(dev).data_ptr(), 400, torch.from_numpy(ids).to(dev).data_ptr(),
+                                                   B, out.data_ptr(), status.data_ptr(), ops._stream(dev)))
+        assert np.array_equal(out.cpu().numpy(), np.concatenate([[0], np.cumsum(lens[ids])])) and int(status.item()) == 0
+    bad = torch.tensor([3, 400], dtype=torch.int64, device=dev)
+    out = torch.empty(3, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().evi_segment_offsets(torch.from_numpy(ptr).to(dev).data_ptr(), 400, bad.data_ptr(), 2, out.data_ptr(),
+                                               status.data_ptr(), ops._stream(dev)))
+    assert int(status.item()) == 1
+
+
+def test_deferred_embedding_id_check(dev, tmp_path):
+    from evi_rag_amd import packed_dataset as pd
+    from evi_rag_amd.embedding_store import GlobalEmbeddingStore
+
+    base, samples, _ = _split(tmp_path, graphs=4, seed=2)
+    small = GlobalEmbeddingStore.from_tensors(torch.zeros(3, 16), torch.zeros(12, 16), device=dev)  # entity table too small
+    ds = pd.PackedRetrievalDataset(tmp_path / "split", device=dev, embeddings=small)
+    ds.collate([0, 1])  # does not raise here ...
+    with pytest.raises(IndexError):
+        ds.check_deferred()  # ... but the epoch-end check does
+    ds.check_deferred()  # flag cleared
