@@ -169,7 +169,6 @@ extern "C" int evi_gather_rows(const float* table, int64_t num_rows, int D, cons
     EVI_REQUIRE(num_rows >= 0 && D >= 0 && n >= 0, "evi_gather_rows: bad sizes");
     EVI_REQUIRE(status, "evi_gather_rows: null status");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    EVI_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
     if (n == 0 || D == 0) return EVI_OK;
     EVI_REQUIRE(ids && out && (table || num_rows == 0), "evi_gather_rows: null pointer");
     int64_t blocks = (n + 3) / 4;

@@ -201,8 +201,9 @@ int evi_graph_class_stats(const float* scores, const uint8_t* target, const int6
 
 /* ---- D1: embedding feed ---------------------------------------------------------------------- */
 
-/* out[i, :] = table[ids[i], :] from an HBM-resident table (status bit 1 = an id outside
- * [0, num_rows); that row is zero-filled).  Replaces the CPU index_select + pinned-buffer H2D copy of
+/* out[i, :] = table[ids[i], :] from an HBM-resident table.  An id outside [0, num_rows) zero-fills its
+ * row and ORs 1 into *status, which the CALLER zeroes (so several gathers can share one flag that is
+ * read once).  Replaces the CPU index_select + pinned-buffer H2D copy of
  * GlobalEmbeddingStore.get_entity_embeddings / get_relation_embeddings,
  * src/data/components/embedding_store.py:101-150. */
 int evi_gather_rows(const float* table, int64_t num_rows, int D, const int64_t* ids, int64_t n,
