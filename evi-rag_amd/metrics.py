@@ -231,6 +231,14 @@ class _SumMetric:
     def _col(rb: RankedBatch, k: int) -> int:
         return rb.k_values.index(k)
 
+    def _cols(self, rb: RankedBatch, dev: torch.device) -> torch.Tensor:
+        """Device index of this metric's k columns inside the shared ranking (cached: no per-batch H2D)."""
+        key = ("cols", tuple(rb.k_values), dev)
+        idx = self._idx_cache.get(key)
+        if idx is None:
+            idx = self._idx_cache[key] = torch.tensor([self._col(rb, k) for k in self.k_values], dtype=torch.long, device=dev)
+        return idx
+
 
 class EdgeRecallAtK(_SumMetric):
     """reference: EdgeRecallAtK, src/metrics/retriever_metrics.py:83-166."""
@@ -248,7 +256,7 @@ class EdgeRecallAtK(_SumMetric):
         rb = self._ranked(preds, target, batch, self.k_values, num_graphs, indexes)
         valid = rb.recall_valid.bool()
         sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0)
-        cols = [self._col(rb, k) for k in self.k_values]
+        cols = self._cols(rb, valid.device)
         self._accumulate([f"recall_sum_at_{k}" for k in self.k_values] + ["graph_count"],
                          torch.cat([sums[cols], valid.sum().double().view(1)]))
 
@@ -275,7 +283,7 @@ class AnswerReachability(_SumMetric):
         rb = self._ranked(preds, target, batch, self.k_values, num_graphs, query_ids)
         valid = rb.reach_valid.bool()
         hits = (rb.reach.double() * valid.unsqueeze(1)).sum(0)
-        cols = [self._col(rb, k) for k in self.k_values]
+        cols = self._cols(rb, valid.device)
         self._accumulate([f"hits_at_{k}" for k in self.k_values] + ["total"], torch.cat([hits[cols], valid.sum().double().view(1)]))
 
     def compute(self) -> Dict[str, torch.Tensor]:
@@ -308,7 +316,7 @@ class AnswerHitAtK(_SumMetric):
         valid = rb.answer_valid == 1
         hit = (rb.answer_hit.double() * valid.unsqueeze(1)).sum(0)
         rec = (rb.answer_recall.double() * valid.unsqueeze(1)).sum(0)
-        cols = [self._col(rb, k) for k in self.k_values]
+        cols = self._cols(rb, valid.device)
         self._accumulate([f"hit_sum_at_{k}" for k in self.k_values] + [f"recall_sum_at_{k}" for k in self.k_values] + ["sample_count"],
                          torch.cat([hit[cols], rec[cols], valid.sum().double().view(1)]))
 
@@ -414,7 +422,7 @@ class BridgeEdgeRecallAtK(_SumMetric):
         stats = _class_stats(s, t.to(torch.uint8), eptr, B)
         valid = (stats[:, 0] > 0) & rb.recall_valid.bool()  # graphs without a bridge positive are skipped (:239-241)
         sums = (rb.edge_recall.double() * valid.unsqueeze(1)).sum(0)
-        cols = [self._col(rb, k) for k in self.k_values]
+        cols = self._cols(rb, valid.device)
         self._accumulate([f"recall_sum_at_{k}" for k in self.k_values] + ["graph_count"],
                          torch.cat([sums[cols], valid.sum().double().view(1)]))
 

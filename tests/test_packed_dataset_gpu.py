@@ -110,17 +110,20 @@ def test_segment_offsets_kernel_matches_numpy(dev):
     rng = np.random.default_rng(3)
     lens = rng.integers(0, 50, 400)
     ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ptr_d = torch.from_numpy(ptr).to(dev)
     for B in (1, 7, 1024, 3000):
         ids = rng.integers(0, 400, B).astype(np.int64)
+        ids_d = torch.from_numpy(ids).to(dev)
         out = torch.empty(B + 1, dtype=torch.int64, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(_lib.load().evi_segment_offsets(torch.from_numpy(ptr).to(dev).data_ptr(), 400, torch.from_numpy(ids).to(dev).data_ptr(),
-                                                   B, out.data_ptr(), status.data_ptr(), ops._stream(dev)))
-        assert np.array_equal(out.cpu().numpy(), np.concatenate([[0], np.cumsum(lens[ids])])) and int(status.item()) == 0
+        _lib.check(_lib.load().evi_segment_offsets(ptr_d.data_ptr(), 400, ids_d.data_ptr(), B, out.data_ptr(), status.data_ptr(),
+                                                   ops._stream(dev)))
+        assert np.array_equal(out.cpu().numpy(), np.concatenate([[0], np.cumsum(lens[ids])])), B
+        assert int(status.item()) == 0
     bad = torch.tensor([3, 400], dtype=torch.int64, device=dev)
     out = torch.empty(3, dtype=torch.int64, device=dev)
-    _lib.check(_lib.load().evi_segment_offsets(torch.from_numpy(ptr).to(dev).data_ptr(), 400, bad.data_ptr(), 2, out.data_ptr(),
-                                               status.data_ptr(), ops._stream(dev)))
+    _lib.check(_lib.load().evi_segment_offsets(ptr_d.data_ptr(), 400, bad.data_ptr(), 2, out.data_ptr(), status.data_ptr(),
+                                               ops._stream(dev)))
     assert int(status.item()) == 1
 
 
