@@ -253,6 +253,58 @@ __global__ __launch_bounds__(kSelectThreads) void k_retriever_metrics(MetricsArg
     }
 }
 
+// Adds one batch's per-graph results (the outputs of k_retriever_metrics) into the epoch's f64 states:
+//   acc[0 .. nk)        sum of edge recall@k over graphs with edges       acc[nk]      their count
+//   acc[nk+1 .. 2nk+1)  reachability hits@k over graphs with seeds+answers  acc[2nk+1]   their count
+//   acc[2nk+2 .. 3nk+2) answer hit@k, acc[3nk+2 .. 4nk+2) answer recall@k   acc[4nk+2]   graphs with answer ids
+//   acc[4nk+3]          sum of score margins                              acc[4nk+4]   graphs with both classes
+//   acc[4nk+5]          graphs whose answer list exceeded the kernel's capacity (answer_valid == 2)
+// One thread per state walks the graphs in order: a fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void k_metric_accumulate(
+    const float* __restrict__ edge_recall, const uint8_t* __restrict__ recall_valid, const uint8_t* __restrict__ reach,
+    const uint8_t* __restrict__ reach_valid, const uint8_t* __restrict__ answer_hit, const float* __restrict__ answer_recall,
+    const uint8_t* __restrict__ answer_valid, const float* __restrict__ score_margin, const uint8_t* __restrict__ margin_valid,
+    int B, int nk, double* __restrict__ acc) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = 4 * nk + 6;
+    if (s >= total) return;
+    double sum = 0.0;
+    if (s < nk) {
+        for (int g = 0; g < B; ++g)
+            if (recall_valid[g]) sum += (double)edge_recall[(int64_t)g * nk + s];
+    } else if (s == nk) {
+        for (int g = 0; g < B; ++g) sum += recall_valid[g] ? 1.0 : 0.0;
+    } else if (s < 2 * nk + 1) {
+        const int c = s - nk - 1;
+        for (int g = 0; g < B; ++g)
+            if (reach_valid[g]) sum += (double)reach[(int64_t)g * nk + c];
+    } else if (s == 2 * nk + 1) {
+        for (int g = 0; g < B; ++g) sum += reach_valid[g] ? 1.0 : 0.0;
+    } else if (s < 3 * nk + 2) {
+        const int c = s - 2 * nk - 2;
+        if (answer_valid)
+            for (int g = 0; g < B; ++g)
+                if (answer_valid[g] == 1) sum += (double)answer_hit[(int64_t)g * nk + c];
+    } else if (s < 4 * nk + 2) {
+        const int c = s - 3 * nk - 2;
+        if (answer_valid)
+            for (int g = 0; g < B; ++g)
+                if (answer_valid[g] == 1) sum += (double)answer_recall[(int64_t)g * nk + c];
+    } else if (s == 4 * nk + 2) {
+        if (answer_valid)
+            for (int g = 0; g < B; ++g) sum += answer_valid[g] == 1 ? 1.0 : 0.0;
+    } else if (s == 4 * nk + 3) {
+        for (int g = 0; g < B; ++g)
+            if (margin_valid[g]) sum += (double)score_margin[g];
+    } else if (s == 4 * nk + 4) {
+        for (int g = 0; g < B; ++g) sum += margin_valid[g] ? 1.0 : 0.0;
+    } else {
+        if (answer_valid)
+            for (int g = 0; g < B; ++g) sum += answer_valid[g] == 2 ? 1.0 : 0.0;
+    }
+    acc[s] += sum;
+}
+
 }  // namespace evi
 
 using namespace evi;
@@ -300,6 +352,23 @@ extern "C" int evi_retriever_metrics(
     }
     hipLaunchKernelGGL(k_retriever_metrics, dim3(B), dim3(kSelectThreads), sizeof(MetricsShared),
                        reinterpret_cast<hipStream_t>(stream), a);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_metric_accumulate(const float* edge_recall, const uint8_t* recall_valid, const uint8_t* reach,
+                                     const uint8_t* reach_valid, const uint8_t* answer_hit, const float* answer_recall,
+                                     const uint8_t* answer_valid, const float* score_margin, const uint8_t* margin_valid,
+                                     int B, int num_k, double* acc, void* stream) {
+    EVI_REQUIRE(B >= 0 && num_k >= 1 && num_k <= kMaxKValues, "evi_metric_accumulate: bad sizes B=%d num_k=%d", B, num_k);
+    if (B == 0) return EVI_OK;
+    EVI_REQUIRE(edge_recall && recall_valid && reach && reach_valid && score_margin && margin_valid && acc,
+                "evi_metric_accumulate: null pointer");
+    EVI_REQUIRE(!answer_valid || (answer_hit && answer_recall), "evi_metric_accumulate: answer arrays must come together");
+    const int total = 4 * num_k + 6;
+    hipLaunchKernelGGL(k_metric_accumulate, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       edge_recall, recall_valid, reach, reach_valid, answer_hit, answer_recall, answer_valid, score_margin,
+                       margin_valid, B, num_k, acc);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -511,13 +511,47 @@ class RetrieverMetricCollection:
             self.metrics["bridge_coverage"] = BridgePositiveCoverage()
             self.metrics["bridge_quality"] = BridgeProbQuality()
 
+    # (metric, state name) of every slot of evi_metric_accumulate's vector, in its order
+    def _slots(self):
+        ks = self.k_values
+        er, re, ah, sm = (self.metrics.get(n) for n in ("edge_recall", "reachability", "answer_hit", "score_margin"))
+        return ([(er, f"recall_sum_at_{k}") for k in ks] + [(er, "graph_count")] + [(re, f"hits_at_{k}") for k in ks] + [(re, "total")]
+                + [(ah, f"hit_sum_at_{k}") for k in ks] + [(ah, f"recall_sum_at_{k}") for k in ks] + [(ah, "sample_count")]
+                + [(sm, "margin_sum"), (sm, "graph_count")])
+
+    def _flush(self) -> None:
+        """Moves the fused device accumulator into the metrics' host states (one read)."""
+        acc = getattr(self, "_acc", None)
+        if acc is None:
+            return
+        vals = acc.tolist()
+        acc.zero_()
+        if vals[-1] > 0:
+            raise NotImplementedError("a graph has more than 2048 answer entities")
+        for (m, name), v in zip(self._slots(), vals):
+            if m is not None:
+                m._states[name] += v
+
     def update(self, *, preds, target, indexes, batch, query_ids=None, num_graphs=None, features=None, **_: Any) -> None:
         if preds.numel() == 0:
             return
         shared = rank_batch(preds, target, batch, self.k_values, num_graphs=num_graphs, indexes=indexes)
+        # the four ranking metrics share the ranking AND one fused accumulation launch
+        dev = shared.edge_recall.device
+        nk = len(self.k_values)
+        acc = getattr(self, "_acc", None)
+        if acc is None or acc.device != dev:
+            self._flush()
+            acc = self._acc = torch.zeros(4 * nk + 6, dtype=torch.float64, device=dev)
+        p = ops._ptr
+        ans = shared.have_answers and "answer_hit" in self.metrics
+        _lib.check(_lib.load().evi_metric_accumulate(
+            p(shared.edge_recall), p(shared.recall_valid), p(shared.reach), p(shared.reach_valid),
+            p(shared.answer_hit) if ans else None, p(shared.answer_recall) if ans else None, p(shared.answer_valid) if ans else None,
+            p(shared.score_margin), p(shared.margin_valid), int(shared.recall_valid.numel()), nk, acc.data_ptr(), ops._stream(dev)))
         for name, m in self.metrics.items():
-            if name == "answer_hit" and not shared.have_answers:
-                continue
+            if not name.startswith("bridge"):
+                continue  # ranking metrics were accumulated above
             m._shared = None if name.startswith("bridge") else shared
             try:
                 m.update(preds=preds, target=target, indexes=indexes, batch=batch, query_ids=query_ids,
@@ -526,16 +560,19 @@ class RetrieverMetricCollection:
                 m._shared = None
 
     def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
         out: Dict[str, torch.Tensor] = {}
         for m in self.metrics.values():
             out.update({self.prefix + k: v for k, v in m.compute().items()})
         return out
 
     def reset(self) -> None:
+        self._acc = None
         for m in self.metrics.values():
             m.reset()
 
     def sync(self, group=None) -> None:
+        self._flush()
         for m in self.metrics.values():
             m.sync(group)
 

@@ -192,6 +192,20 @@ int evi_retriever_metrics(
     uint8_t* answer_valid, float* score_margin, uint8_t* margin_valid, int32_t* topk_index,
     float* topk_score, int32_t* topk_count, int32_t* uf_workspace, void* stream);
 
+/* Adds one batch's per-graph outputs of evi_retriever_metrics into the epoch's f64 state vector
+ * acc [4 * num_k + 6] (fixed summation order, nothing read back):
+ *   [0, nk) sum edge recall@k, [nk] graphs with edges; [nk+1, 2nk+1) reachability hits@k, [2nk+1] graphs
+ *   with seeds and answers; [2nk+2, 3nk+2) answer hit@k, [3nk+2, 4nk+2) answer recall@k, [4nk+2] graphs
+ *   with answer ids; [4nk+3] sum of score margins, [4nk+4] graphs with both classes; [4nk+5] graphs
+ *   whose answer list exceeded the kernel's capacity.  answer_* may be null (no answer ids in the batch).
+ * The torchmetrics `add_state(..., dist_reduce_fx="sum")` bookkeeping of EdgeRecallAtK /
+ * AnswerReachability / ScoreMargin (src/metrics/retriever_metrics.py:95-99,141-166; reachability.py:27-33)
+ * without their per-batch `.item()` reads. */
+int evi_metric_accumulate(const float* edge_recall, const uint8_t* recall_valid, const uint8_t* reach,
+                          const uint8_t* reach_valid, const uint8_t* answer_hit, const float* answer_recall,
+                          const uint8_t* answer_valid, const float* score_margin, const uint8_t* margin_valid,
+                          int B, int num_k, double* acc, void* stream);
+
 /* per graph: out[g, 0..3] = {positives, negatives, sum sigmoid(score) over positives, over negatives}
  * (f64, deterministic).  Building block of BridgeProbQuality / BridgePositiveCoverage,
  * src/metrics/retriever_metrics.py:270-327, 400-476 (applied to the bridge-edge sub-lists).
