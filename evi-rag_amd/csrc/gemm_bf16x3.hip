@@ -71,53 +71,54 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     uint4 rwh[2], rwl[2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const uint4 zero16 = make_uint4(0u, 0u, 0u, 0u);
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // A: 2048 float4 chunks, 8 per row (128 B contiguous)
-            const int s = tid + kXThreads * i;
-            const int r = s >> 3, c4 = s & 7;
-            const int k = k0 + c4 * 4;
-            const int64_t am = m0 + r;
-            ra[i] = (am < M && k < K) ? *reinterpret_cast<const f32x4*>(A + am * lda + k) : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {  // W planes: 1024 16-byte chunks each, 4 per row
-            const int s = tid + kXThreads * i;
-            const int r = s >> 2, c = s & 3;
-            const int wr = n0 + r;
-            if (wr < N) {
-                const int64_t off = (int64_t)wr * Kp + k0 + c * 8;
-                rwh[i] = *reinterpret_cast<const uint4*>(Whi + off);
-                rwl[i] = *reinterpret_cast<const uint4*>(Wlo + off);
-            } else {
-                rwh[i] = rwl[i] = zero16;
-            }
-        }
+    // The staging work of one k-tile is cut into six pieces (four A pieces of 512 float4 chunks, two W
+    // pieces of 512 16-byte chunks per plane) so that it can be issued BETWEEN the MFMA groups of the
+    // tile being multiplied: a 32x32x16 MFMA holds the SIMD's issue port for 8 of its 32 cycles, the
+    // conversions and LDS writes of the next tile run in its shadow instead of in a phase of their own.
+    // Loads are branch-free (an out-of-range chunk reads the array's first 16 bytes and is zeroed by a
+    // select), so the whole k-loop body is straight-line code and the compiler can count exactly which
+    // outstanding loads each staging piece has to wait for.
+    auto load_a = [&](int i, int k0) {  // A: 2048 float4 chunks, 8 per row (128 B contiguous)
+        const int s = tid + kXThreads * i;
+        const int r = s >> 3, c4 = s & 7;
+        const int k = k0 + c4 * 4;
+        const int64_t am = m0 + r;
+        const bool ok = am < M && k < K;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(A + (ok ? am * lda + k : 0));
+        ra[i] = ok ? v : zero4;
     };
-    auto store_tiles = [&](int buf) {
+    auto load_w = [&](int i, int k0) {  // W planes: 1024 16-byte chunks each, 4 per row
+        const int s = tid + kXThreads * i;
+        const int r = s >> 2, c = s & 3;
+        const int wr = n0 + r;
+        const int k = k0 + c * 8;
+        const bool ok = wr < N && k < Kp;
+        const int64_t off = ok ? (int64_t)wr * Kp + k : 0;
+        const uint4 vh = *reinterpret_cast<const uint4*>(Whi + off);
+        const uint4 vl = *reinterpret_cast<const uint4*>(Wlo + off);
+        rwh[i] = ok ? vh : zero16;
+        rwl[i] = ok ? vl : zero16;
+    };
+    auto store_a = [&](int i, int buf) {
+        const int s = tid + kXThreads * i;
+        const int r = s >> 3, c4 = s & 7;
+        bf16x4 h, l;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = tid + kXThreads * i;
-            const int r = s >> 3, c4 = s & 7;
-            bf16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[e] = (__bf16)ra[i][e];
-                l[e] = (__bf16)(ra[i][e] - (float)h[e]);
-            }
-            // 8-byte halves of the 16-byte chunk c = c4 >> 1
-            uint2* dh = reinterpret_cast<uint2*>(&sAhi[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
-            uint2* dl = reinterpret_cast<uint2*>(&sAlo[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
-            *dh = *reinterpret_cast<uint2*>(&h);
-            *dl = *reinterpret_cast<uint2*>(&l);
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (__bf16)ra[i][e];
+            l[e] = (__bf16)(ra[i][e] - (float)h[e]);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int s = tid + kXThreads * i;
-            const int r = s >> 2, c = s & 3;
-            sWhi[buf][slot3(r, c)] = rwh[i];
-            sWlo[buf][slot3(r, c)] = rwl[i];
-        }
+        // 8-byte halves of the 16-byte chunk c = c4 >> 1
+        uint2* dh = reinterpret_cast<uint2*>(&sAhi[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
+        uint2* dl = reinterpret_cast<uint2*>(&sAlo[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
+        *dh = *reinterpret_cast<uint2*>(&h);
+        *dl = *reinterpret_cast<uint2*>(&l);
+    };
+    auto store_w = [&](int i, int buf) {
+        const int s = tid + kXThreads * i;
+        const int r = s >> 2, c = s & 3;
+        sWhi[buf][slot3(r, c)] = rwh[i];
+        sWlo[buf][slot3(r, c)] = rwl[i];
     };
 
     f32x16 acc[4][2];
@@ -129,16 +130,24 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    // Two LDS stages: while stage `cur` is multiplied, the next tile (already in registers) is split
-    // and written to the other stage and the tile after it is fetched; one barrier per k-tile.
-    load_tiles(0);
-    store_tiles(0);
+    // Two LDS stages: stage `cur` is multiplied while the next tile (already in registers) is split and
+    // written to the other stage piece by piece and the tile after it is fetched into the freed
+    // registers; one barrier per k-tile.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) load_w(i, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_a(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) store_w(i, 0);
     __syncthreads();
-    if (XK < K) load_tiles(XK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(i, XK);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) load_w(i, XK);
     int cur = 0;
     for (int k0 = 0; k0 < K; k0 += XK, cur ^= 1) {
-        if (k0 + XK < K) store_tiles(cur ^ 1);
-        if (k0 + 2 * XK < K) load_tiles(k0 + 2 * XK);
 #pragma unroll
         for (int kk = 0; kk < XK; kk += 16) {
             const int c = (kk >> 3) + fh;  // chunk holding k = kk + 8 h .. + 7
@@ -160,11 +169,34 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
+                // one staging piece in the shadow of this group's MFMAs (pieces 0-3: A, 4-5: W).  Past the last
+                // tile the pieces move zeros into a stage nobody reads: cheaper than a branch in this loop.
+                const int piece = (kk >> 4) * 4 + i;
+                if (piece < 4) {
+                    store_a(piece, cur ^ 1);
+                    load_a(piece, k0 + 2 * XK);
+                } else if (piece < 6) {
+                    store_w(piece - 4, cur ^ 1);
+                    load_w(piece - 4, k0 + 2 * XK);
+                }
             }
         }
         __syncthreads();
     }
 
+    if (m0 + XM <= M && n0 + XN <= N) {  // interior tile: no bounds checks, the 128 stores of a lane issue back to back
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fr;
+            const float bv = bias ? bias[n] : 0.f;
+            float* cp = C + (m0 + wm * 128 + 4 * fh) * ldc + n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = act3(acc[i][j][r] + bv, ACT);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + fr;
