@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // a 16-byte chunk (ext vector: selects stay in registers)
 
 constexpr int XM = 256, XN = 256, XK = 32;
 constexpr int kXThreads = 512;
@@ -68,9 +69,9 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const int n0 = (int)(tile % nblocks_n) * XN;
 
     f32x4 ra[4];
-    uint4 rwh[2], rwl[2];
+    u32x4 rwh[2], rwl[2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const uint4 zero16 = make_uint4(0u, 0u, 0u, 0u);
+    const u32x4 zero16 = {0u, 0u, 0u, 0u};
     // The staging work of one k-tile is cut into six pieces (four A pieces of 512 float4 chunks, two W
     // pieces of 512 16-byte chunks per plane) so that it can be issued BETWEEN the MFMA groups of the
     // tile being multiplied: a 32x32x16 MFMA holds the SIMD's issue port for 8 of its 32 cycles, the
@@ -84,8 +85,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const int k = k0 + c4 * 4;
         const int64_t am = m0 + r;
         const bool ok = am < M && k < K;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(A + (ok ? am * lda + k : 0));
-        ra[i] = ok ? v : zero4;
+        ra[i] = *reinterpret_cast<const f32x4*>(A + (ok ? am * lda + k : 0));  // zeroed where it is consumed (store_a)
     };
     auto load_w = [&](int i, int k0) {  // W planes: 1024 16-byte chunks each, 4 per row
         const int s = tid + kXThreads * i;
@@ -94,19 +94,21 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const int k = k0 + c * 8;
         const bool ok = wr < N && k < Kp;
         const int64_t off = ok ? (int64_t)wr * Kp + k : 0;
-        const uint4 vh = *reinterpret_cast<const uint4*>(Whi + off);
-        const uint4 vl = *reinterpret_cast<const uint4*>(Wlo + off);
-        rwh[i] = ok ? vh : zero16;
-        rwl[i] = ok ? vl : zero16;
+        rwh[i] = *reinterpret_cast<const u32x4*>(Whi + off);
+        rwl[i] = *reinterpret_cast<const u32x4*>(Wlo + off);
     };
-    auto store_a = [&](int i, int buf) {
+    // k0 = first k of the tile the registers hold: the range check of the load is repeated here, so the
+    // select sits next to the conversion and not behind the load (where it would stall on the load's latency)
+    auto store_a = [&](int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 3, c4 = s & 7;
+        const bool ok = m0 + r < M && k0 + c4 * 4 < K;
+        const f32x4 v = ok ? ra[i] : zero4;
         bf16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            h[e] = (__bf16)ra[i][e];
-            l[e] = (__bf16)(ra[i][e] - (float)h[e]);
+            h[e] = (__bf16)v[e];
+            l[e] = (__bf16)(v[e] - (float)h[e]);
         }
         // 8-byte halves of the 16-byte chunk c = c4 >> 1
         uint2* dh = reinterpret_cast<uint2*>(&sAhi[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
@@ -114,11 +116,12 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         *dh = *reinterpret_cast<uint2*>(&h);
         *dl = *reinterpret_cast<uint2*>(&l);
     };
-    auto store_w = [&](int i, int buf) {
+    auto store_w = [&](int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
-        sWhi[buf][slot3(r, c)] = rwh[i];
-        sWlo[buf][slot3(r, c)] = rwl[i];
+        const bool ok = n0 + r < N && k0 + c * 8 < Kp;
+        *reinterpret_cast<u32x4*>(&sWhi[buf][slot3(r, c)]) = ok ? rwh[i] : zero16;
+        *reinterpret_cast<u32x4*>(&sWlo[buf][slot3(r, c)]) = ok ? rwl[i] : zero16;
     };
 
     f32x16 acc[4][2];
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
 #pragma unroll
     for (int i = 0; i < 2; ++i) load_w(i, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) store_a(i, 0);
+    for (int i = 0; i < 4; ++i) store_a(i, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) store_w(i, 0);
+    for (int i = 0; i < 2; ++i) store_w(i, 0, 0);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_a(i, XK);
@@ -173,12 +176,15 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
                 // tile the pieces move zeros into a stage nobody reads: cheaper than a branch in this loop.
                 const int piece = (kk >> 4) * 4 + i;
                 if (piece < 4) {
-                    store_a(piece, cur ^ 1);
+                    store_a(piece, cur ^ 1, k0 + XK);
                     load_a(piece, k0 + 2 * XK);
                 } else if (piece < 6) {
-                    store_w(piece - 4, cur ^ 1);
+                    store_w(piece - 4, cur ^ 1, k0 + XK);
                     load_w(piece - 4, k0 + 2 * XK);
                 }
+                // keep each piece (and the reload of its registers) in its own MFMA group: left alone, the
+                // scheduler sinks all eight loads to the end of the loop, one barrier before they are needed
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
