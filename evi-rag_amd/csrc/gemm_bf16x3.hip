@@ -151,41 +151,50 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     for (int i = 0; i < 2; ++i) load_w(i, XK);
     int cur = 0;
     for (int k0 = 0; k0 < K; k0 += XK, cur ^= 1) {
-#pragma unroll
-        for (int kk = 0; kk < XK; kk += 16) {
-            const int c = (kk >> 3) + fh;  // chunk holding k = kk + 8 h .. + 7
-            bf16x8 bh[2], bl[2];
+        // Eight MFMA groups per k-tile (two 16-wide k-steps x four 32-row blocks of the wave's 128 rows).  The
+        // fragments of group g + 1 are read from LDS before group g's MFMAs are issued (ping-pong registers),
+        // so an MFMA never waits on the LDS latency of its own operands.
+        bf16x8 fah[2], fal[2], fbh[2][2], fbl[2][2];
+        auto read_a = [&](int g) {
+            const int c = ((g >> 2) << 1) + fh;  // chunk holding k = 16 (g >> 2) + 8 h .. + 7
+            const int row = wm * 128 + (g & 3) * 32 + fr;
+            fah[g & 1] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
+            fal[g & 1] = *reinterpret_cast<const bf16x8*>(&sAlo[cur][slot3(row, c)]);
+        };
+        auto read_b = [&](int ks) {
+            const int c = (ks << 1) + fh;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + fr;
-                bh[j] = *reinterpret_cast<const bf16x8*>(&sWhi[cur][slot3(row, c)]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&sWlo[cur][slot3(row, c)]);
+                fbh[ks][j] = *reinterpret_cast<const bf16x8*>(&sWhi[cur][slot3(row, c)]);
+                fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sWlo[cur][slot3(row, c)]);
             }
+        };
+        read_b(0);
+        read_a(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 128 + i * 32 + fr;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAlo[cur][slot3(row, c)]);
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) read_a(g + 1);
+            if (g == 2) read_b(1);
+            const int i = g & 3, ks = g >> 2;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                }
-                // one staging piece in the shadow of this group's MFMAs (pieces 0-3: A, 4-5: W).  Past the last
-                // tile the pieces move zeros into a stage nobody reads: cheaper than a branch in this loop.
-                const int piece = (kk >> 4) * 4 + i;
-                if (piece < 4) {
-                    store_a(piece, cur ^ 1, k0 + XK);
-                    load_a(piece, k0 + 2 * XK);
-                } else if (piece < 6) {
-                    store_w(piece - 4, cur ^ 1, k0 + XK);
-                    load_w(piece - 4, k0 + 2 * XK);
-                }
-                // keep each piece (and the reload of its registers) in its own MFMA group: left alone, the
-                // scheduler sinks all eight loads to the end of the loop, one barrier before they are needed
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g & 1], fbh[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbl[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbh[ks][j], acc[i][j], 0, 0, 0);
             }
+            // one staging piece in the shadow of this group's MFMAs (pieces 0-3: A, 4-5: W).  Past the last
+            // tile the pieces move zeros into a stage nobody reads: cheaper than a branch in this loop.
+            if (g < 4) {
+                store_a(g, cur ^ 1, k0 + XK);
+                load_a(g, k0 + 2 * XK);
+            } else if (g < 6) {
+                store_w(g - 4, cur ^ 1, k0 + XK);
+                load_w(g - 4, k0 + 2 * XK);
+            }
+            // keep each piece (and the reload of its registers) in its own MFMA group: left alone, the
+            // scheduler sinks all eight loads to the end of the loop, one barrier before they are needed
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
