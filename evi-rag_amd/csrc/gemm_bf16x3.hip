@@ -15,6 +15,7 @@
 #include "common.hpp"
 
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 namespace evi {
 
@@ -49,7 +50,7 @@ __global__ void k_split_weight(const float* __restrict__ W, int N, int K, int64_
     lo[i] = (__bf16)(x - (float)h);
 }
 
-template <int ACT>
+template <int ACT, int PF>
 __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
@@ -174,8 +175,13 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         read_a(0);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (g + 1 < 8) read_a(g + 1);
-            if (g == 2) read_b(1);
+            if (PF) {
+                if (g + 1 < 8) read_a(g + 1);
+                if (g == 2) read_b(1);
+            } else {
+                if (g > 0) read_a(g);
+                if (g == 4) read_b(1);
+            }
             const int i = g & 3, ks = g >> 2;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -245,16 +251,21 @@ int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const f
     EVI_LAUNCH_CHECK();
     const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
     const int tok = timing_begin(kTimeGemm, st);
+    static const bool prefetch = [] {  // EVI_GEMM_PREFETCH=0: read each group's fragments inside the group (tuning knob)
+        const char* e = getenv("EVI_GEMM_PREFETCH");
+        return !(e && e[0] == '0');
+    }();
+#define EVI_LAUNCH_X3(ACT)                                                                                              \
+    if (prefetch)                                                                                                       \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc); \
+    else                                                                                                                \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
     switch (act) {
-        case 1:
-            hipLaunchKernelGGL(k_gemm_nt_bf16x3<1>, grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
-            break;
-        case 2:
-            hipLaunchKernelGGL(k_gemm_nt_bf16x3<2>, grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
-            break;
-        default:
-            hipLaunchKernelGGL(k_gemm_nt_bf16x3<0>, grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
+        case 1: EVI_LAUNCH_X3(1) break;
+        case 2: EVI_LAUNCH_X3(2) break;
+        default: EVI_LAUNCH_X3(0)
     }
+#undef EVI_LAUNCH_X3
     timing_end(tok, st);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
