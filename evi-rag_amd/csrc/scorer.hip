@@ -243,13 +243,27 @@ __global__ void k_slice_state0(const float* __restrict__ w1, int H, int D, float
     if (threadIdx.x == 0) wd[r] = src[3 * D];
 }
 
-// Folded head for the logits-only path: v[j] = sum_i score_w[i] * W2[i, j], v[H] = score_w . b2 + score_b
-__global__ void k_fold_head(const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ score_w,
-                            const float* __restrict__ score_b, int H, float* __restrict__ v) {
+// Folded head for the logits-only path: v[j] = sum_i score_w[i] * W2[i, j], v[H] = score_w . b2 + score_b.
+// Two steps so that the H x H read is spread over the chip and still summed in a fixed order:
+// partial[s][j] over row slice s (blockIdx.y), then the slices are added in slice order.
+constexpr int kFoldSlices = 32;
+__global__ void k_fold_head_partial(const float* __restrict__ w2, const float* __restrict__ score_w, int H,
+                                    float* __restrict__ partial) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    const int per = (H + kFoldSlices - 1) / kFoldSlices;
+    const int i0 = blockIdx.y * per, i1 = (i0 + per < H) ? i0 + per : H;
+    float acc = 0.f;
+    for (int i = i0; i < i1; ++i) acc = fmaf(score_w[i], w2[(int64_t)i * H + j], acc);
+    partial[(int64_t)blockIdx.y * H + j] = acc;
+}
+__global__ void k_fold_head_final(const float* __restrict__ partial, const float* __restrict__ b2,
+                                  const float* __restrict__ score_w, const float* __restrict__ score_b, int H,
+                                  float* __restrict__ v) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < H) {
         float acc = 0.f;
-        for (int i = 0; i < H; ++i) acc = fmaf(score_w[i], w2[(int64_t)i * H + j], acc);
+        for (int s = 0; s < kFoldSlices; ++s) acc += partial[(int64_t)s * H + j];
         v[j] = acc;
     }
     if (j == 0) {
@@ -452,7 +466,7 @@ static int dpl_for(int d) {
 
 struct FwdLayout {
     size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
-        in_eid, out_ptr, out_nbr, out_eid, csr_ws, wa, wb, wc, wd, vhead, wt, wsplit, hcn, P, RCX, XS, aux, PA, RC, SB,
+        in_eid, out_ptr, out_nbr, out_eid, csr_ws, wa, wb, wc, wd, vhead, fold, wt, wsplit, hcn, P, RCX, XS, aux, PA, RC, SB,
         h1n, feats, total;
     int64_t ec;
     int dedupe;
@@ -492,6 +506,7 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.wc = take((size_t)H * D * f);
     L.wd = take((size_t)H * f);
     L.vhead = take((size_t)(H + 1) * f);
+    L.fold = take((size_t)32 * H * f);  // kFoldSlices partial rows of the folded head
     L.wt = take((size_t)F * D * f);
     L.wsplit = take(gemm_bf16x3_workspace_bytes(H > D ? H : D, H > D ? H : D));
     L.hcn = take(n1 * H * f);
@@ -615,7 +630,10 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     EVI_LAUNCH_CHECK();
     const bool fold = out->edge_features == nullptr;  // logits only: the head is folded into one vector
     if (fold) {
-        hipLaunchKernelGGL(k_fold_head, dim3((H + 255) / 256), dim3(256), 0, st, w->state4_w, w->state4_b, w->score_w,
+        float* partial = F32(L.fold);
+        hipLaunchKernelGGL(k_fold_head_partial, dim3((H + 255) / 256, kFoldSlices), dim3(256), 0, st, w->state4_w,
+                           w->score_w, H, partial);
+        hipLaunchKernelGGL(k_fold_head_final, dim3((H + 255) / 256), dim3(256), 0, st, partial, w->state4_b, w->score_w,
                            w->score_b, H, vhead);
         EVI_LAUNCH_CHECK();
     }
