@@ -48,6 +48,10 @@ def parse_args():
                     help="storage dtype of the resident index (f16 / fp8 e4m3 + per-row scale: BASELINE configs 4 / 5; "
                          "the headline is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-kernels", action="store_true",
+                    help="run ONLY the BASELINE config 3 leg (CWQ-shaped CSR / DDE / BFS / seed expansion kernels with their "
+                         "CPU-oracle baseline) and print its JSON object")
+    ap.add_argument("--graph-batch", type=int, default=64, help="graphs per batch of the --graph-kernels leg")
     ap.add_argument("--no-graph-eval", action="store_true")
     return ap.parse_args()
 
@@ -264,6 +268,92 @@ def bench_eval_pipeline(dev, D, model, *, graphs_total=128, batch_size=32, nodes
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, iters=20, cpu_graphs=8, cpu=True):
+    """BASELINE config 3 (CWQ-shaped 2-hop expansion): CSR build, DDE structure features, multi-source BFS levels,
+    seed-incident edge selection on batches of CWQ-shaped graphs (N_g ~ 3 000, E_g ~ 10 000, DDE 2 + 2 rounds,
+    ratio 0.25), the algorithmic bytes of each kernel as GB/s, beside the CPU oracle on a sample."""
+    from evi_rag_amd import _lib, ops, synthetic
+
+    lib = _lib.load()
+    B = batch
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    sb = synthetic.make_batch(B, nodes_per_graph=nodes, edges_per_graph=edges, emb_dim=8, num_relations=512, seed=2,
+                              attach_embeddings=False)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ei, ptr, eptr, topic = t(sb.edge_index), t(sb.ptr), t(sb.edge_ptr), t(sb.topic_one_hot)
+    N, E = sb.num_nodes, sb.num_edges
+    scores = torch.randn(E, device=dev)
+    seeds = t(sb.q_local_indices)
+    res = {"workload": f"{B} CWQ-shaped graphs per batch, N={N}, E={E} (N_g~{nodes}, E_g~{edges}), {graphs} graphs per epoch",
+           "kernels": {}}
+
+    def rec(name, ms, nbytes, note):
+        res["kernels"][name] = {"ms_per_batch": ms, "algorithmic_bytes": nbytes, "GB_per_s": nbytes / (ms * 1e-3) / 1e9,
+                                "graphs_per_s": B / (ms * 1e-3), "note": note}
+
+    csr = ops.graph_csr(ei, ptr, eptr)
+    rec("evi_graph_csr", timed(lambda: ops.graph_csr(ei, ptr, eptr)), E * 16 + 2 * (E * 8 + N * 4),
+        "edge_index read (16 B/edge) + both CSR halves written (nbr + eid per edge, ptr per node)")
+    rounds = 2
+    rec("evi_dde_node_struct", timed(lambda: ops.dde_node_struct(topic, ptr, csr, rounds, rounds)),
+        2 * rounds * (E * 12 + N * 16) + N * 10 * 4, "per round E*(4 nbr + 8 gathered) + N*(8 ptr + 8 out); 2 + 2 rounds")
+    jg = torch.arange(B, dtype=torch.int32, device=dev)
+    sp, doff = t(sb.q_ptr), t(sb.ptr[:-1])
+    dist_lv = torch.empty(N, dtype=torch.int32, device=dev)
+
+    def bfs():
+        _lib.check(lib.evi_bfs_levels(jg.data_ptr(), sp.data_ptr(), seeds.data_ptr(), doff.data_ptr(), B, ptr.data_ptr(),
+                                      csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
+                                      csr.out_nbr.data_ptr(), 0, dist_lv.data_ptr(), ops._stream(dev)))
+
+    ms = timed(bfs)
+    levels = int(dist_lv.max().item()) + 1
+    rec("evi_bfs_levels", ms, levels * N * 4 + 2 * E * 8,
+        f"undirected, {levels} levels: N*4 scanned per level + every CSR row once (nbr + dist probe)")
+    res["two_hop_frontier_nodes_per_graph"] = int(((dist_lv >= 0) & (dist_lv <= 2)).sum().item()) / B
+    mask = torch.empty(E, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def expand():
+        _lib.check(lib.evi_select_start_edges(scores.data_ptr(), E, seeds.data_ptr(), seeds.numel(), csr.in_ptr.data_ptr(),
+                                              csr.in_eid.data_ptr(), csr.out_ptr.data_ptr(), csr.out_eid.data_ptr(), N, 0.25, 1,
+                                              -1, mask.data_ptr(), status.data_ptr(), ops._stream(dev)))
+
+    deg = (csr.in_ptr[seeds + 1] - csr.in_ptr[seeds] + csr.out_ptr[seeds + 1] - csr.out_ptr[seeds]).sum().item()
+    rec("evi_select_start_edges", timed(expand), int(deg) * 8 + E, "incident (eid, score) of every seed + the E-byte mask")
+    total_ms = sum(k["ms_per_batch"] for k in res["kernels"].values())
+    res["gpu_graphs_per_s"] = B / (total_ms * 1e-3)
+    res["gpu_epoch_seconds"] = graphs / res["gpu_graphs_per_s"]
+    if cpu:  # the reference's own Python / numpy algorithms, restated (oracle), on a sample of the same graphs
+        from oracle import graph as og
+
+        g = min(cpu_graphs, B)
+        t0 = time.perf_counter()
+        for i in range(g):
+            n0, n1, e0, e1 = int(sb.ptr[i]), int(sb.ptr[i + 1]), int(sb.edge_ptr[i]), int(sb.edge_ptr[i + 1])
+            src, dst = sb.edge_index[0, e0:e1] - n0, sb.edge_index[1, e0:e1] - n0
+            adj = og.build_undirected_adjacency(n1 - n0, src.tolist(), dst.tolist())
+            q = (sb.q_local_indices[int(sb.q_ptr[i]): int(sb.q_ptr[i + 1])] - n0).tolist()
+            og.bfs_dist(n1 - n0, adj, q)
+            og.node_structure_features(sb.topic_one_hot[n0:n1], np.stack([src, dst]), rounds, rounds)
+            og.select_start_edges(src, dst, np.zeros(e1 - e0, np.float32), np.asarray(q), n1 - n0, 0.25, 1, None)
+        cpu_s = (time.perf_counter() - t0) / g
+        res["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "graphs/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle adjacency + BFS + DDE + seed expansion on {g} of the graphs, {cpu_s * 1e3:.1f} ms/graph"}
+    return res
+
+
 def main():
     args = parse_args()
     # stdout carries exactly ONE JSON line: native libraries that write to fd 1 (RCCL prints a version banner at
@@ -290,6 +380,11 @@ def main():
 
     from evi_rag_amd import _lib, ops
 
+    if args.graph_kernels:  # config 3 leg only
+        if rank == 0:
+            res = bench_graph_kernels(dev, args.graph_batch, cpu=not args.no_cpu_baseline)
+            os.write(result_fd, (json.dumps(res) + "\n").encode())
+        return
     lib = _lib.load()
     N, D, Q, k = args.rows, args.dim, args.queries, args.k
     row_begin = N * rank // world
