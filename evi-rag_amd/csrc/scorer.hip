@@ -144,9 +144,12 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
 
     for (int64_t le = (int64_t)blockIdx.x * waves + wave; le < a.e_count; le += (int64_t)gridDim.x * waves) {
         const int64_t e = a.e_begin + le;
-        const int64_t hv = a.edge_index[e], tv = a.edge_index[a.E + e];
-        const int64_t g = a.edge_batch[e];
-        const int64_t rrow = a.rel_by_edge ? e : a.edge_attr[e];
+        // one edge per wave: its ids are wave-uniform — say so (readfirstlane), and the row bases and the raw
+        // structure features below become scalar loads instead of per-lane address arithmetic and shuffles
+        const int64_t hv = __builtin_amdgcn_readfirstlane((int)a.edge_index[e]);
+        const int64_t tv = __builtin_amdgcn_readfirstlane((int)a.edge_index[a.E + e]);
+        const int64_t g = __builtin_amdgcn_readfirstlane((int)a.edge_batch[e]);
+        const int64_t rrow = a.rel_by_edge ? e : (int64_t)__builtin_amdgcn_readfirstlane((int)a.edge_attr[e]);
         const float* hp = a.node_repr + hv * D;
         const float* tp = a.node_repr + tv * D;
         const float* rp = a.rel_repr + rrow * D;
@@ -164,31 +167,37 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
                 h[i] = t[i] = rc[i] = 0.f;
             }
         }
-        // raw structure features of head and tail (lane j < half holds element j of each)
-        const float sh_ = lane < half ? a.node_struct[hv * half + lane] : 0.f;
-        const float st_ = lane < half ? a.node_struct[tv * half + lane] : 0.f;
+        // struct_proj.0 for BOTH directions in one pass over the weights: struct_raw = cat(ns[a], ns[b]) with
+        // (a, b) = (head, tail) forward and (tail, head) backward, so every weight row is read from LDS once and
+        // feeds two accumulators; the raw features are wave-uniform scalars.
+        const float* nsh = a.node_struct + hv * half;
+        const float* nst = a.node_struct + tv * half;
+        float s2[2][DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            s2[0][i] = s2[1][i] = d < D ? l_b[d] : 0.f;
+        }
+        for (int j = 0; j < half; ++j) {
+            const float xh = nsh[j], xt = nst[j];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                if (d < D) {
+                    const float w1 = lds_wt[j * D + d], w2 = lds_wt[(half + j) * D + d];
+                    s2[0][i] = fmaf(w2, xt, fmaf(w1, xh, s2[0][i]));
+                    s2[1][i] = fmaf(w2, xh, fmaf(w1, xt, s2[1][i]));
+                }
+            }
+        }
 
         int out_row = 0;
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
-            // struct_raw = cat(ns[a], ns[b]); a = head for fwd, tail for bwd
             float s[DPL];
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
-                s[i] = d < D ? l_b[d] : 0.f;
-            }
-            for (int j = 0; j < F; ++j) {
-                const float first_half = dir == 0 ? sh_ : st_;
-                const float second_half = dir == 0 ? st_ : sh_;
-                const float raw = j < half ? __shfl(first_half, j, 64) : __shfl(second_half, j - half, 64);
-#pragma unroll
-                for (int i = 0; i < DPL; ++i) {
-                    const int d = lane + 64 * i;
-                    if (d < D) s[i] = fmaf(lds_wt[j * D + d], raw, s[i]);
-                }
-            }
+            for (int i = 0; i < DPL; ++i) s[i] = s2[dir][i];
             // LayerNorm over D, exact GELU
             float sum = 0.f;
 #pragma unroll
