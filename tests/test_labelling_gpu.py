@@ -213,3 +213,35 @@ def test_embedding_store_gather(dev):
     b = types.SimpleNamespace(node_embedding_ids=ids[:10], edge_attr=rids[:20])
     store.attach(b)
     assert b.node_embeddings.shape == (10, 96) and b.edge_embeddings.shape == (20, 96) and b.num_relations == 37
+
+
+def test_large_graph_takes_the_global_memory_paths(dev):
+    """A 20 000-node graph exceeds the LDS capacity of the CSR counters (6 144 nodes) and of the BFS levels
+    (12 288 nodes): both kernels must fall back to their global-memory paths with identical results; a hub
+    of degree 5 000 exercises the wave-cooperative frontier expansion on that path too."""
+    from evi_rag_amd import labelling as L
+
+    rng = np.random.default_rng(31)
+    n, e = 20000, 60000
+    src = rng.integers(0, n, size=e)
+    dst = rng.integers(0, n, size=e)
+    src[:5000] = 17  # hub
+    small_n, small_e = 300, 900
+    s2, d2 = rng.integers(0, small_n, size=small_e), rng.integers(0, small_n, size=small_e)
+    gb = L.GraphBatch([n, small_n], [src, s2], [dst, d2])  # one graph on each path, same launch
+    seeds = [[5, 17, 19999], [0, 7]]
+    for mode, directed in ((0, False), (1, True)):
+        got = L.bfs_dist_batch(gb, seeds, mode=mode)
+        for g, (nn, a, b) in enumerate(((n, src, dst), (small_n, s2, d2))):
+            adj = (ograph.build_directed_adjacency if directed else ograph.build_undirected_adjacency)(nn, a.tolist(), b.tolist())
+            assert got[g].tolist() == ograph.bfs_dist(nn, adj, seeds[g]), (g, mode)
+    # CSR rows (as sets: row order is unspecified) against the oracle adjacency
+    csr = gb.csr
+    out_ptr, out_nbr = csr.out_ptr.cpu().numpy(), csr.out_nbr.cpu().numpy()
+    dadj = ograph.build_directed_adjacency(n, src.tolist(), dst.tolist())
+    for v in (0, 17, 4242, n - 1):
+        assert sorted(out_nbr[out_ptr[v]: out_ptr[v + 1]].tolist()) == dadj[v]
+    res = L.shortest_path_single_batch(gb, [[5], [0]], [[19999, 123], [250]])
+    for g, (nn, a, b, s, t) in enumerate(((n, src, dst, [5], [19999, 123]), (small_n, s2, d2, [0], [250]))):
+        ref = ograph.shortest_path_single(nn, a.tolist(), b.tolist(), s, t)
+        assert res[g] == (list(ref[0]), list(ref[1])), g
