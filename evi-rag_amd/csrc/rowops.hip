@@ -30,7 +30,7 @@ __device__ inline float row_sumsq(const float* __restrict__ row, int D, int lane
     return wave_sum(acc);
 }
 
-// MODE 0: inv_norm only.  MODE 1: write normalised rows (true division).
+// MODE 0: inv_norm only.  MODE 1: write normalised rows (true division).  MODE 2: the norm itself (no clamp).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_row_norm(const float* __restrict__ x, int64_t n, int D,
                                                   float eps, float* __restrict__ out) {
@@ -43,6 +43,8 @@ __global__ __launch_bounds__(256) void k_row_norm(const float* __restrict__ x, i
         const float denom = fmaxf(sqrtf(ss), eps);
         if (MODE == 0) {
             if (lane == 0) out[r] = 1.0f / denom;
+        } else if (MODE == 2) {
+            if (lane == 0) out[r] = sqrtf(ss);
         } else {
             float* o = out + r * (int64_t)D;
             if ((D & 3) == 0) {
@@ -113,6 +115,16 @@ extern "C" int evi_row_normalize(const float* x, int64_t n, int D, float eps, fl
     EVI_REQUIRE(x && out, "evi_row_normalize: null pointer");
     hipLaunchKernelGGL(k_row_norm<1>, dim3(norm_grid(n)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), x, n, D, eps, out);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_row_norms(const float* x, int64_t n, int D, float* norms, void* stream) {
+    EVI_REQUIRE(n >= 0 && D >= 1, "evi_row_norms: need n >= 0 and D >= 1, got n=%lld D=%d", (long long)n, D);
+    if (n == 0) return EVI_OK;
+    EVI_REQUIRE(x && norms, "evi_row_norms: null pointer");
+    hipLaunchKernelGGL(k_row_norm<2>, dim3(norm_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, D, 0.f,
+                       norms);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -491,12 +491,48 @@ class BridgeProbQuality(_SumMetric):
                 "bridge/separation": torch.tensor(self._states["sep_sum"] / d, dtype=torch.float32)}
 
 
+class FeatureMonitor(_SumMetric):
+    """Mean sigmoid(score) of positive / negative edges over the whole epoch and the mean L2 norm of the
+    edge features.  reference: FeatureMonitor, src/metrics/feature_monitor.py:9-58 (enabled by
+    evaluation_cfg.feature_metrics, src/models/retriever_module.py:112-113)."""
+
+    def __init__(self, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        for n in ("pos_score_sum", "pos_count", "neg_score_sum", "neg_count", "feat_norm_sum", "feat_count"):
+            self._add_state(n)
+
+    def update(self, preds, target, features=None, **_: Any) -> None:
+        scores = preds.detach().reshape(-1)
+        if scores.numel() == 0:
+            return
+        dev = ops._require_gpu(scores)
+        tgt = target.detach().reshape(-1).to(dev)
+        tgt = (tgt > 0.5) if tgt.dtype != torch.bool else tgt
+        ptr = torch.tensor([0, scores.numel()], dtype=torch.long, device=dev)
+        st = _class_stats(scores.float().contiguous(), tgt.to(torch.uint8).contiguous(), ptr, 1)[0]  # pos, neg, sum p|pos, sum p|neg
+        self._accumulate(["pos_count", "neg_count", "pos_score_sum", "neg_score_sum"], st)
+        if features is not None and features.numel() > 0:
+            norms = ops.row_norms(features.detach().reshape(-1, features.shape[-1]))
+            self._accumulate(["feat_norm_sum", "feat_count"],
+                             torch.stack([norms.sum().double(), torch.tensor(float(norms.numel()), dtype=torch.float64, device=dev)]))
+
+    def compute(self) -> Dict[str, torch.Tensor]:
+        self._flush()
+        s = self._states
+        pos = s["pos_score_sum"] / max(s["pos_count"], 1.0)
+        neg = s["neg_score_sum"] / max(s["neg_count"], 1.0)
+        return {"features/pos_prob_avg": torch.tensor(pos, dtype=torch.float32),
+                "features/neg_prob_avg": torch.tensor(neg, dtype=torch.float32),
+                "features/separation_gap": torch.tensor(pos - neg, dtype=torch.float32),
+                "features/norm_avg": torch.tensor(s["feat_norm_sum"] / max(s["feat_count"], 1.0), dtype=torch.float32)}
+
+
 class RetrieverMetricCollection:
     """The metric set RetrieverModule builds (src/models/retriever_module.py:100-131), sharing one
     ranking pass per batch.  `update` takes the module's keyword set; `compute` merges the dicts."""
 
     def __init__(self, k_values: Sequence[int], *, answer_hit: bool = True, bridge_metrics: bool = False,
-                 prefix: str = "") -> None:
+                 feature_metrics: bool = False, prefix: str = "") -> None:
         self.k_values = normalize_k_values(k_values)
         self.prefix = prefix
         self.metrics: Dict[str, _SumMetric] = {
@@ -510,6 +546,8 @@ class RetrieverMetricCollection:
             self.metrics["bridge_recall"] = BridgeEdgeRecallAtK(self.k_values)
             self.metrics["bridge_coverage"] = BridgePositiveCoverage()
             self.metrics["bridge_quality"] = BridgeProbQuality()
+        if feature_metrics:  # evaluation_cfg.feature_metrics (src/models/retriever_module.py:112-113)
+            self.metrics["features"] = FeatureMonitor()
 
     # (metric, state name) of every slot of evi_metric_accumulate's vector, in its order
     def _slots(self):
@@ -549,6 +587,8 @@ class RetrieverMetricCollection:
             p(shared.edge_recall), p(shared.recall_valid), p(shared.reach), p(shared.reach_valid),
             p(shared.answer_hit) if ans else None, p(shared.answer_recall) if ans else None, p(shared.answer_valid) if ans else None,
             p(shared.score_margin), p(shared.margin_valid), int(shared.recall_valid.numel()), nk, acc.data_ptr(), ops._stream(dev)))
+        if "features" in self.metrics:
+            self.metrics["features"].update(preds=preds, target=target, features=features)
         for name, m in self.metrics.items():
             if not name.startswith("bridge"):
                 continue  # ranking metrics were accumulated above
@@ -578,5 +618,5 @@ class RetrieverMetricCollection:
 
 
 __all__ = ["normalize_k_values", "rank_batch", "RankedBatch", "EdgeRecallAtK", "AnswerReachability", "AnswerHitAtK",
-           "ScoreMargin", "BridgeEdgeRecallAtK", "BridgePositiveCoverage", "BridgeProbQuality",
+           "ScoreMargin", "BridgeEdgeRecallAtK", "BridgePositiveCoverage", "BridgeProbQuality", "FeatureMonitor",
            "RetrieverMetricCollection"]

@@ -82,6 +82,19 @@ def row_inv_norm(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     return out
 
 
+def row_norms(x: torch.Tensor) -> torch.Tensor:
+    """||x_i||_2 per row (f32).  reference: torch.norm(features, p=2, dim=-1), src/metrics/feature_monitor.py:43."""
+    dev = _require_gpu(x)
+    if x.dim() != 2:
+        raise ValueError(f"x must be 2D [n, D], got shape {tuple(x.shape)}")
+    x = _f32c(x, "x")
+    n, D = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    if n:
+        _lib.check(_lib.load().evi_row_norms(_ptr(x), n, D, _ptr(out), _stream(dev)))
+    return out
+
+
 def normalize_embeddings(embeddings: torch.Tensor, eps: float = 1e-6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x / clamp(||x||, min=eps) row-wise; empty tensors pass through.
     reference: _normalize_embeddings, scripts/build_retrieval_pipeline.py:833-837."""

@@ -114,6 +114,10 @@ int evi_cosine_topk_f16(const float* q, int Q, const void* idx_f16, int64_t N, i
                         float* out_score, int64_t* out_index,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* norms[i] = ||x_i||_2 (f32 sum of squares, one wave per row).  torch.norm(features, p=2, dim=-1) of
+ * FeatureMonitor.update, src/metrics/feature_monitor.py:42-46. */
+int evi_row_norms(const float* x, int64_t n, int D, float* norms, void* stream);
+
 /* fp8 storage (BASELINE config 5): rows quantised to OCP e4m3 with one f32 scale per row,
  *   scale = max|x| / 448 (1 for an all-zero row), out = e4m3(x / scale), round-to-nearest-even. */
 int evi_quantize_rows_fp8(const float* x, int64_t n, int D, uint8_t* out_fp8, float* out_scale, void* stream);

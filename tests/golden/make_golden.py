@@ -500,6 +500,31 @@ def gen_loss():
     save("loss", **arrays)
 
 
+# ---- FeatureMonitor (evaluation_cfg.feature_metrics) ------------------------------------------------------
+def gen_feature_monitor():
+    from src.metrics.feature_monitor import FeatureMonitor
+
+    rng = np.random.default_rng(707)
+    arrays = {}
+    m = FeatureMonitor()
+    for b, (n, h) in enumerate([(500, 48), (37, 48), (1, 48)]):
+        preds = (rng.standard_normal(n) * 2).astype(np.float32)
+        target = rng.random(n) < 0.2
+        feats = rng.standard_normal((n, h)).astype(np.float32)
+        feats[0] = 0.0
+        m.update(torch.from_numpy(preds), torch.from_numpy(target), torch.from_numpy(feats))
+        arrays.update({f"b{b}_preds": preds, f"b{b}_target": target, f"b{b}_features": feats})
+    out = m.compute()
+    arrays["num_batches"] = 3
+    arrays["keys"] = np.asarray(sorted(out))
+    arrays["values"] = np.asarray([float(out[k]) for k in sorted(out)], np.float64)
+    m2 = FeatureMonitor()
+    m2.update(torch.from_numpy(arrays["b1_preds"]), torch.zeros(37, dtype=torch.bool))  # no positives, no features
+    out2 = m2.compute()
+    arrays["nopos_values"] = np.asarray([float(out2[k]) for k in sorted(out2)], np.float64)
+    save("feature_monitor", **arrays)
+
+
 # ---- E2/E3 -------------------------------------------------------------------------------------------
 class _FakeTokenizer:
     """Whitespace tokenizer with padding=True semantics (pad id 0, mask 0 on pads)."""
@@ -573,6 +598,7 @@ def main():
     gen_build_graph()
     gen_g_agent_build()
     gen_loss()
+    gen_feature_monitor()
     # toy batch (BASELINE config 1 graph shape: 32 graphs, N_g = 64, E_g ~ 31), D = H = 32
     toy = synthetic.make_batch(32, nodes_per_graph=64, edges_per_graph=31, emb_dim=32, num_relations=16, seed=0)
     eb, eptr, near = gen_graph_utils(toy)

@@ -153,3 +153,20 @@ def test_bridge_metrics_match_reference_golden(dev, tag):
     for k in bridge_keys:
         assert got[k] == pytest.approx(ref[k], abs=2e-6), k
     assert set(got) == set(ref)
+
+
+def test_feature_monitor_matches_reference_golden(dev):
+    from evi_rag_amd.metrics import FeatureMonitor
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feature_monitor.npz"), allow_pickle=False)
+    m = FeatureMonitor()
+    for b in range(int(z["num_batches"])):
+        m.update(torch.from_numpy(z[f"b{b}_preds"]).to(dev), torch.from_numpy(z[f"b{b}_target"]).to(dev),
+                 torch.from_numpy(z[f"b{b}_features"]).to(dev))
+    out = m.compute()
+    assert sorted(out) == z["keys"].tolist()
+    np.testing.assert_allclose([float(out[k]) for k in sorted(out)], z["values"], rtol=2e-6, atol=2e-7)
+    m.reset()
+    m.update(torch.from_numpy(z["b1_preds"]).to(dev), torch.zeros(37, dtype=torch.bool, device=dev))
+    out = m.compute()
+    np.testing.assert_allclose([float(out[k]) for k in sorted(out)], z["nopos_values"], rtol=2e-6, atol=2e-7)
