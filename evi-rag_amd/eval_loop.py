@@ -23,20 +23,26 @@ DEFAULT_K_VALUES = (1, 10, 25, 50, 100, 200, 300, 400, 500)  # configs/window/de
 
 class RetrieverEvaluator:
     def __init__(self, model, *, loss: Optional[RetrieverLoss] = None, k_values: Sequence[int] = DEFAULT_K_VALUES,
-                 split: str = "test", bridge_metrics: bool = False, callbacks: Sequence[Any] = (),
-                 emit_predict_outputs: bool = False) -> None:
+                 split: str = "test", bridge_metrics: bool = False, feature_metrics: bool = False,
+                 ablate_topic: bool = False, callbacks: Sequence[Any] = (), emit_predict_outputs: bool = False) -> None:
         if split not in ("val", "test"):
             raise ValueError(f"split must be 'val' or 'test', got {split!r}")
         self.model = model
         self.loss = loss if loss is not None else RetrieverLoss()
         self.split = split
-        self.metrics = RetrieverMetricCollection(k_values, bridge_metrics=bridge_metrics, prefix=f"{split}/")
+        self.metrics = RetrieverMetricCollection(k_values, bridge_metrics=bridge_metrics, feature_metrics=feature_metrics,
+                                                 prefix=f"{split}/")
+        # evaluation_cfg.ablate_topic: a second forward with topic_one_hot zeroed, its own metric set (:118-120, :438-444)
+        self.metrics_ablate = RetrieverMetricCollection(k_values, bridge_metrics=bridge_metrics, feature_metrics=feature_metrics,
+                                                        prefix=f"{split}/ablate_topic/") if ablate_topic else None
         self.callbacks = list(callbacks)
         self.emit_predict_outputs = bool(emit_predict_outputs)
         self.reset()
 
     def reset(self) -> None:
         self.metrics.reset()
+        if self.metrics_ablate is not None:
+            self.metrics_ablate.reset()
         self._loss_sum = 0.0          # host part (batches whose loss was read eagerly)
         self._loss_dev = None         # device accumulator: sum over batches of loss * num_graphs
         self._graphs = 0
@@ -91,14 +97,17 @@ class RetrieverEvaluator:
                                     + loss_out.components["bce"] * self.loss.bce_weight) * num_graphs
         self._graphs += num_graphs
         self._batches += 1
-        scores = output.logits.detach().view(-1)
-        if scores.numel():
-            labels = batch.labels.detach().view(-1).to(dtype=torch.float32)
-            if scores.numel() != labels.numel():
-                raise ValueError(f"scores/labels shape mismatch: {scores.shape} vs {labels.shape}")
-            query_ids = output.query_ids.detach().view(-1).to(dtype=torch.long)
-            self.metrics.update(preds=scores, target=labels > 0.5, indexes=query_ids, batch=batch, query_ids=query_ids,
-                                num_graphs=num_graphs, features=output.edge_embeddings)
+        self._update_metrics(self.metrics, batch, output, num_graphs)
+        if self.metrics_ablate is not None:
+            topic = getattr(batch, "topic_one_hot", None)
+            if topic is None:
+                raise ValueError("topic_one_hot is required for ablation metrics.")
+            batch.topic_one_hot = torch.zeros_like(torch.as_tensor(topic))
+            try:
+                ablated = self.model(batch)
+            finally:
+                batch.topic_one_hot = topic
+            self._update_metrics(self.metrics_ablate, batch, ablated, num_graphs)
         for cb in self.callbacks:
             if hasattr(cb, "on_test_batch_end"):
                 cb.on_test_batch_end(None, self, output, batch, batch_idx, 0)
@@ -109,6 +118,21 @@ class RetrieverEvaluator:
             pred.edge_embeddings = None
             return pred
         return None
+
+    @staticmethod
+    def _update_metrics(metrics: RetrieverMetricCollection, batch: Any, output, num_graphs: int) -> None:
+        """`_update_metrics` (:147-176)."""
+        scores = output.logits.detach().view(-1)
+        if scores.numel() == 0:
+            return
+        labels = batch.labels.detach().view(-1).to(dtype=torch.float32)
+        if scores.numel() != labels.numel():
+            raise ValueError(f"scores/labels shape mismatch: {scores.shape} vs {labels.shape}")
+        query_ids = output.query_ids.detach().view(-1).to(dtype=torch.long)
+        if query_ids.numel() != scores.numel():
+            raise ValueError(f"query_ids/scores mismatch: {query_ids.shape} vs {scores.shape}")
+        metrics.update(preds=scores, target=labels > 0.5, indexes=query_ids, batch=batch, query_ids=query_ids,
+                       num_graphs=num_graphs, features=output.edge_embeddings)
 
     def epoch_end(self, *, sync: bool = False) -> Dict[str, float]:
         """`on_test_epoch_end` (:401-403): metric dict + the epoch loss; sync=True sums the metric states
@@ -121,8 +145,12 @@ class RetrieverEvaluator:
             from .dist import all_reduce_sum_
 
             self.metrics.sync()
+            if self.metrics_ablate is not None:
+                self.metrics_ablate.sync()
             loss_sum, graphs = all_reduce_sum_([loss_sum, graphs])
         out = {k: float(v) for k, v in self.metrics.compute().items()}
+        if self.metrics_ablate is not None:
+            out.update({k: float(v) for k, v in self.metrics_ablate.compute().items()})
         out[f"{self.split}/loss"] = loss_sum / max(graphs, 1.0)
         return out
 

@@ -99,7 +99,14 @@ def test_evaluator_epoch_matches_single_batch(dev, tmp_path):
         if k.endswith("/loss"):
             continue  # the epoch loss is a graph-weighted mean of per-batch means over VALID graphs: batching-dependent
         assert abs(res["metrics"][k] - v) < 1e-6, k
+    # topic ablation + feature metrics: a second metric set under test/ablate_topic/, features/* keys, batch left intact
+    ab = RetrieverEvaluator(model, k_values=[1, 5], ablate_topic=True, feature_metrics=True).run(pd.PackedLoader(ds, batch_size=5))
+    keys = ab["metrics"]
+    assert "test/ablate_topic/edge/recall@5" in keys and "test/features/norm_avg" in keys and keys["test/features/norm_avg"] > 0
+    assert abs(keys["test/edge/recall@5"] - one["metrics"]["test/edge/recall@5"]) < 1e-6
+    assert keys["test/ablate_topic/edge/score_margin"] != keys["test/edge/score_margin"]  # structure features matter
     batch = ds.collate(list(range(10)))
+    assert float(batch.topic_one_hot.abs().sum()) > 0
     with torch.no_grad():
         out = model(batch)
     total, _, _, _ = oloss.retriever_loss(out.logits.cpu().numpy(), batch.labels.cpu().numpy(), out.query_ids.cpu().numpy(), 10)
