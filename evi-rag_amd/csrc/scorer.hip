@@ -313,6 +313,7 @@ struct CombineArgs {
     int H, dir_fwd, dir_bwd;
     float* h1n;
     const float* v;  // [H + 1] folded head
+    const float* edge_bias;  // [E] or null
     float* logits;
     float* logits_fwd;
     float* logits_bwd;
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
         ++out_row;
     }
     if (FOLD && lane == 0) {
-        const float lf = lg[0], lb = lg[1];
+        const float eb = a.edge_bias ? a.edge_bias[e] : 0.f;
+        const float lf = lg[0] + eb, lb = lg[1] + eb;
         float out = lf;
         if (a.dir_fwd && a.dir_bwd) {
             const float m = fmaxf(lf, lb);
@@ -408,8 +410,9 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
 template <int DPL>
 __global__ __launch_bounds__(256) void k_score_combine(
     const float* __restrict__ feats, int64_t e_begin, int64_t e_count, int H, int dir_fwd, int dir_bwd,
-    const float* __restrict__ score_w, const float* __restrict__ score_b, float* __restrict__ logits,
-    float* __restrict__ logits_fwd, float* __restrict__ logits_bwd, float* __restrict__ edge_features) {
+    const float* __restrict__ score_w, const float* __restrict__ score_b, const float* __restrict__ edge_bias,
+    float* __restrict__ logits, float* __restrict__ logits_fwd, float* __restrict__ logits_bwd,
+    float* __restrict__ edge_features) {
     const int lane = threadIdx.x & 63;
     const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (le >= e_count) return;
@@ -427,8 +430,9 @@ __global__ __launch_bounds__(256) void k_score_combine(
         af = fmaf(vf[i], w, af);
         ab = fmaf(vb[i], w, ab);
     }
-    const float lf = wsum(af) + score_b[0];
-    const float lb = wsum(ab) + score_b[0];
+    const float eb = edge_bias ? edge_bias[e] : 0.f;
+    const float lf = wsum(af) + score_b[0] + eb;
+    const float lb = wsum(ab) + score_b[0] + eb;
     float wf = 1.f, wb = 0.f, lg = lf;
     if (dir_fwd && dir_bwd) {
         const float m = fmaxf(lf, lb);
@@ -727,6 +731,7 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         c.dir_bwd = dir_bwd;
         c.h1n = F32(L.h1n);
         c.v = vhead;
+        c.edge_bias = b->edge_bias;
         c.logits = out->logits;
         c.logits_fwd = out->logits_fwd;
         c.logits_bwd = out->logits_bwd;
@@ -741,7 +746,8 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         if ((rc = scorer_gemm(F32(L.h1n), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st))) return rc;
         EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_score_combine<DPL>, dim3((unsigned)((ec + 3) / 4)), dim3(256), 0, st,
                                                    F32(L.feats), e0, ec, H, dir_fwd, dir_bwd, w->score_w, w->score_b,
-                                                   out->logits, out->logits_fwd, out->logits_bwd, out->edge_features));
+                                                   b->edge_bias, out->logits, out->logits_fwd, out->logits_bwd,
+                                                   out->edge_features));
         EVI_LAUNCH_CHECK();
     }
     return EVI_OK;

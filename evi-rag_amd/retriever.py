@@ -172,10 +172,12 @@ class Retriever(nn.Module):
             prob = float(cfg.get(name, 0.0))
             if prob < 0.0 or prob > 1.0:
                 raise ValueError(f"hide_seek_cfg.{name} must be in [0, 1], got {prob}")
+            setattr(self, f"hide_seek_{name}", prob)
         for name in ("bias_near", "bias_far"):
             bias = float(cfg.get(name, 0.0))
             if bias > 0.0:
                 raise ValueError(f"hide_seek_cfg.{name} must be <= 0 (penalty), got {bias}")
+            setattr(self, f"hide_seek_{name}", bias)
 
     # ---- public API ----------------------------------------------------------------------------------
     def forward(self, batch: Any) -> RetrieverOutput:
@@ -217,14 +219,44 @@ class Retriever(nn.Module):
                               logits_bwd=empty, edge_embeddings=feats)
         return out, (feats if return_features else None)
 
+    def _compute_hide_seek_bias(self, batch: Any, *, edge_index: torch.Tensor) -> Optional[torch.Tensor]:
+        """The hide-and-seek logit penalty in eval mode (hide_seek_cfg.apply_in_eval): each edge is "hidden" with
+        probability p_near / p_far by whether it touches a seed or answer node, and a hidden edge gets bias_near /
+        bias_far added to both directional logits.  reference: _should_apply_hide_seek / _compute_hide_seek_bias,
+        src/models/components/retriever.py:307-367 (the draw is torch.rand on the device, as there)."""
+        if not (self.hide_seek_enabled and self.hide_seek_apply_in_eval):
+            return None
+        dev = edge_index.device
+        edge_is_near = getattr(batch, "edge_is_near", None)
+        if edge_is_near is None:
+            q, a = getattr(batch, "q_local_indices", None), getattr(batch, "a_local_indices", None)
+            if q is None or a is None:
+                raise ValueError("Batch missing q_local_indices/a_local_indices required for hide-and-seek.")
+            num_nodes = getattr(batch, "num_nodes", None)
+            if num_nodes is None:
+                raise ValueError("Batch missing num_nodes required for hide-and-seek.")
+            near = compute_qa_edge_mask(edge_index, num_nodes=int(num_nodes), q_local_indices=q, a_local_indices=a)
+        else:
+            near = torch.as_tensor(edge_is_near).to(device=dev, dtype=torch.bool).view(-1)
+            if near.numel() != edge_index.size(1):
+                raise ValueError(f"edge_is_near length mismatch: {near.numel()} vs edges {edge_index.size(1)}")
+        if near.numel() == 0:
+            return None
+        if self.hide_seek_p_near <= 0.0 and self.hide_seek_p_far <= 0.0:
+            return None
+        if self.hide_seek_bias_near == 0.0 and self.hide_seek_bias_far == 0.0:
+            return None
+        drop_prob = torch.where(near, torch.tensor(self.hide_seek_p_near, device=dev), torch.tensor(self.hide_seek_p_far, device=dev))
+        drop = torch.rand_like(drop_prob) < drop_prob
+        bias = torch.where(near, torch.tensor(self.hide_seek_bias_near, device=dev), torch.tensor(self.hide_seek_bias_far, device=dev))
+        return torch.where(drop, bias, torch.zeros_like(bias)).to(torch.float32).contiguous()
+
     def _forward_impl(self, batch: Any, *, return_features: bool):
         if self.training:
             raise NotImplementedError(
                 "evi_rag_amd.Retriever implements the evaluation path only; call .eval() "
                 "(training / hide-and-seek / backward are out of scope for this build)."
             )
-        if self.hide_seek_enabled and self.hide_seek_apply_in_eval:
-            raise NotImplementedError("hide_seek_cfg.apply_in_eval=true is not supported by the HIP eval path.")
         param = self.score_head.weight
         dev = param.device
         if dev.type != "cuda":
@@ -335,6 +367,8 @@ class Retriever(nn.Module):
         b.node_embedding_ids, b.edge_embeddings = node_embedding_ids.data_ptr(), edge_embeddings.data_ptr()
         b.edge_attr, b.num_relations = edge_attr.data_ptr(), num_relations
         b.topic_one_hot, b.topic_stride = topic_one_hot.data_ptr(), int(topic_one_hot.size(1))
+        edge_bias = self._compute_hide_seek_bias(batch, edge_index=edge_index)  # None unless apply_in_eval
+        b.edge_bias = edge_bias.data_ptr() if edge_bias is not None else None
         o = _lib.EviRetrieverOutput()
         o.logits = logits.data_ptr()
         o.logits_fwd = logits_fwd.data_ptr() if logits_fwd is not None else None

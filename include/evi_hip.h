@@ -508,6 +508,8 @@ typedef struct EviRetrieverBatch {
                                0 = project per edge, as the reference does */
     const float* topic_one_hot;         /* [N, topic_stride] */
     int topic_stride;
+    const float* edge_bias;             /* [E] or NULL: added to both directional logits before they are combined
+                                           (the hide-and-seek penalty, src/models/components/retriever.py:247-256) */
 } EviRetrieverBatch;
 
 /* RetrieverOutput (src/models/components/retriever.py:80-99); any pointer but logits may be NULL. */

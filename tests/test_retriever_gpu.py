@@ -283,3 +283,32 @@ def test_logits_only_forward_matches_full(dev):
             np.testing.assert_allclose(lite.logits_bwd.cpu().numpy(), full.logits_bwd.cpu().numpy(), rtol=0, atol=2e-5)
         tokens = model.extract_edge_tokens(batch)  # still available on request
         np.testing.assert_allclose(tokens.cpu().numpy(), full.edge_embeddings.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_hide_seek_bias_in_eval(dev):
+    """hide_seek_cfg.apply_in_eval: with p = 1 every edge is penalised, so the directional logits move by exactly
+    bias_near / bias_far (by the Q/A mask) and the combined logit follows; p = 0 leaves the output untouched."""
+    from evi_rag_amd.retriever import Retriever, compute_qa_edge_mask
+
+    sb = synthetic.make_batch(4, nodes_per_graph=60, edges_per_graph=150, emb_dim=32, num_relations=9, seed=23)
+    batch = synthetic.as_namespace(sb, device=dev)
+    torch.manual_seed(5)
+    plain = Retriever(emb_dim=32, hidden_dim=32).to(dev).eval()
+    ref = plain(batch)
+    cfg = dict(enabled=True, apply_in_eval=True, p_near=1.0, p_far=1.0, bias_near=-2.0, bias_far=-0.5)
+    hs = Retriever(emb_dim=32, hidden_dim=32, hide_seek_cfg=cfg).to(dev).eval()
+    hs.load_state_dict(plain.state_dict())
+    near = compute_qa_edge_mask(batch.edge_index, num_nodes=batch.num_nodes, q_local_indices=batch.q_local_indices,
+                                a_local_indices=batch.a_local_indices)
+    bias = torch.where(near, torch.tensor(-2.0, device=dev), torch.tensor(-0.5, device=dev))
+    for emit in (True, False):
+        hs.emit_edge_embeddings = emit
+        out = hs(batch)
+        np.testing.assert_allclose(out.logits_fwd.cpu().numpy(), (ref.logits_fwd + bias).cpu().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out.logits_bwd.cpu().numpy(), (ref.logits_bwd + bias).cpu().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out.logits.cpu().numpy(), (ref.logits + bias).cpu().numpy(), rtol=0, atol=3e-5)
+    off = Retriever(emb_dim=32, hidden_dim=32, hide_seek_cfg=dict(cfg, p_near=0.0, p_far=0.0)).to(dev).eval()
+    off.load_state_dict(plain.state_dict())
+    assert torch.equal(off(batch).logits, ref.logits)
+    with pytest.raises(ValueError, match="must be <= 0"):
+        Retriever(emb_dim=32, hidden_dim=32, hide_seek_cfg=dict(cfg, bias_far=0.1))
