@@ -641,3 +641,237 @@ extern "C" int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, i
     return cosine_topk_impl(q, Q, idx_fp8, 2, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
                             workspace_bytes, stream);
 }
+
+// =====================================================================================================
+// Many queries (Q in the hundreds): GEMM-shaped, still exact.
+//
+// The scan above holds 32 queries in LDS and streams the index once per 32 queries: at Q = 512 that is
+// 16 passes, bound by the f32 MFMA rate.  Here the scores of ALL queries against a slab of index rows
+// are formed as one split-bf16 GEMM (bf16 MFMA, f32 accumulate: |error| <= 2.5e-4 * |q| |x|, see
+// kApproxEps) — approximate, so they only SELECT: every query keeps its kk = k + reserve best rows by
+// approximate score, and the call succeeds only if the k-th and the kk-th approximate scores are more
+// than 2 eps apart, which proves that the true top-k (by the scan's own f32 arithmetic) is inside the
+// kk kept rows.  Those kk rows are then re-scored with exactly the scan's instruction sequence
+// (v_mfma_f32_16x16x4_f32 over d in the same order), and the final top-k is taken on those scores: ids
+// and scores are bit-identical to evi_cosine_topk.  When the gap test fails (heavy ties, adversarial
+// data) or a candidate list overflows, *status is set and the caller runs the scan instead.
+// =====================================================================================================
+namespace evi {
+
+constexpr float kApproxEps = 2.5e-4f;        // |gemm score - scan score| <= kApproxEps * |q| for unit-norm rows:
+                                             // bf16 hi/lo split 2^-16 + 2^-18, 2304 f32 accumulations x 2^-24,
+                                             // plus the scan's own 768 x 2^-24
+constexpr int kGemmTopkCap = 16384;          // candidate slots per query between two selections
+constexpr int64_t kGemmFirstRows = 4096;     // first slab: every row is a candidate (4096 <= cap)
+constexpr int64_t kGemmSlabRows = 262144;    // largest slab: 262144 x Q f32 scores (512 MiB at Q = 512)
+constexpr int kGemmGrowth = 8;
+
+static int gemm_topk_reserve(int k) {
+    int r = k / 2 > 256 ? k / 2 : 256;
+    return k + r;
+}
+
+__global__ void k_gt_init(float* tau, int32_t* cnt, int Q, int32_t* status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Q) {
+        tau[i] = -INFINITY;
+        cnt[i * kCntStride] = 0;
+    }
+    if (i == 0) *status = 0;
+}
+
+// scores [rows, Q] (row-major) of slab rows [row0, row0 + rows): append (score * row_scale, row) to the list of
+// every query whose current threshold it reaches
+__global__ __launch_bounds__(256) void k_gt_filter(const float* __restrict__ scores, int64_t rows, int Q, int64_t row0,
+                                                   const float* __restrict__ row_scale, const float* __restrict__ tau,
+                                                   float* __restrict__ cand_score, int32_t* __restrict__ cand_id,
+                                                   int32_t* __restrict__ cand_cnt, int32_t* __restrict__ status) {
+    const int64_t total = rows * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Q;
+        const int qi = (int)(i - r * Q);
+        float s = scores[i];
+        if (row_scale) s *= row_scale[row0 + r];
+        if (s >= tau[qi] || s != s) {
+            const int32_t pos = atomicAdd(&cand_cnt[qi * kCntStride], 1);
+            if (pos < kGemmTopkCap) {
+                cand_score[(int64_t)qi * kGemmTopkCap + pos] = s;
+                cand_id[(int64_t)qi * kGemmTopkCap + pos] = (int32_t)(row0 + r);
+            } else {
+                atomicOr(status, 2);  // list full: the caller falls back to the scan
+            }
+        }
+    }
+}
+
+// after an overflowing slab the cursor may exceed the capacity: clamp before the selection reads the list
+__global__ void k_gt_clamp(int32_t* cnt, int Q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Q && cnt[i * kCntStride] > kGemmTopkCap) cnt[i * kCntStride] = kGemmTopkCap;
+}
+
+// gap test: with kk rows kept, the true top-k is among them iff approx[k-1] - approx[kk-1] > 2 eps |q|
+__global__ void k_gt_gap(const float* __restrict__ q, int Q, int D, const float* __restrict__ cand_score,
+                         const int32_t* __restrict__ cand_cnt, int k, int kk, int32_t* __restrict__ status) {
+    const int qi = blockIdx.x;
+    const int lane = threadIdx.x;  // one wave
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss = fmaf(q[(int64_t)qi * D + d], q[(int64_t)qi * D + d], ss);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) {
+        const int m = cand_cnt[qi * kCntStride];
+        if (m >= kk) {
+            const float* s = cand_score + (int64_t)qi * kGemmTopkCap;
+            const float gap = s[k - 1] - s[kk - 1];
+            if (!(gap > 2.0f * kApproxEps * sqrtf(ss))) atomicOr(status, 1);
+        }  // m < kk: every row of the index is in the list
+    }
+}
+
+// Exact re-scoring of candidate rows with the scan's arithmetic: the score of (query, row) is the chain
+//   for j = 0 .. D/16 - 1, e = 0 .. 3:  acc = mfma_16x16x4(a = q[16 j + 4 g + e], b = x[16 j + 4 g + e], acc)
+// over lane groups g = 0..3 — exactly what k_cosine_score feeds for that pair (an MFMA output element depends
+// only on its own row of A and column of B), times row_scale.  One wave per (query, 16 candidates): the query
+// sits in row 0 of A, the candidates in the 16 columns of B.
+__global__ __launch_bounds__(256) void k_gt_rescore(const float* __restrict__ q, int D, const float* __restrict__ idx,
+                                                    const float* __restrict__ row_scale, const int32_t* __restrict__ cand_id,
+                                                    const int32_t* __restrict__ cand_cnt, int Q, int kk,
+                                                    float* __restrict__ exact /* [Q, kk] */) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, g = lane >> 4;
+    const int tiles = (kk + 15) / 16;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= (int64_t)Q * tiles) return;  // whole waves only: the MFMAs below run with all 64 lanes
+    const int qi = (int)(w / tiles), t = (int)(w % tiles);
+    const int m = cand_cnt[qi * kCntStride] < kk ? cand_cnt[qi * kCntStride] : kk;
+    const int c = t * 16 + n;
+    const int32_t row = c < m ? cand_id[(int64_t)qi * kGemmTopkCap + c] : -1;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(idx + (int64_t)(row >= 0 ? row : 0) * D) + g;
+    const f32x4* qp = reinterpret_cast<const f32x4*>(q + (int64_t)qi * D) + g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < D / 16; ++j) {
+        const f32x4 x = xp[j * 4];
+        const f32x4 a = n == 0 ? qp[j * 4] : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], x[e], acc, 0, 0, 0);
+    }
+    // D[row 0][col n] is register 0 of the lanes with g == 0
+    if (g == 0 && c < kk) {
+        float s = -INFINITY;
+        if (row >= 0) s = row_scale ? acc[0] * row_scale[row] : acc[0];
+        exact[(int64_t)qi * kk + c] = s;
+    }
+}
+
+// final selection on the exact scores: (score desc, row id asc), like the scan
+__global__ __launch_bounds__(kSelectThreads) void k_gt_final(const float* __restrict__ exact, const int32_t* __restrict__ cand_id,
+                                                             const int32_t* __restrict__ cand_cnt, int kk, int k,
+                                                             int64_t row_id_base, float* __restrict__ out_score,
+                                                             int64_t* __restrict__ out_index) {
+    __shared__ SelectShared sh;
+    const int qi = blockIdx.x;
+    const int m0 = cand_cnt[qi * kCntStride] < kk ? cand_cnt[qi * kCntStride] : kk;
+    const float* es = exact + (int64_t)qi * kk;
+    const int32_t* ci = cand_id + (int64_t)qi * kGemmTopkCap;
+    auto load = [&](int64_t i) -> uint64_t { return make_key(es[i], (uint32_t)ci[i]); };
+    const int m = block_topk(sh, load, m0, k);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        if (i < m) {
+            const uint64_t key = sh.keys[i];
+            out_score[(int64_t)qi * k + i] = key_score(key);
+            out_index[(int64_t)qi * k + i] = row_id_base + (int64_t)key_index(key);
+        } else {
+            out_score[(int64_t)qi * k + i] = -INFINITY;
+            out_index[(int64_t)qi * k + i] = -1;
+        }
+    }
+}
+
+struct GtLayout {
+    size_t tau, cnt, cs, ci, exact, scores, wsplit, total;
+    int64_t slab;
+};
+
+static GtLayout gt_layout(int Q, int64_t N, int D, int k) {
+    GtLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const int kk = gemm_topk_reserve(k);
+    L.slab = N < kGemmSlabRows ? (N > 0 ? N : 1) : kGemmSlabRows;
+    L.tau = take((size_t)Q * sizeof(float));
+    L.cnt = take((size_t)Q * kCntStride * sizeof(int32_t));
+    L.cs = take((size_t)Q * kGemmTopkCap * sizeof(float));
+    L.ci = take((size_t)Q * kGemmTopkCap * sizeof(int32_t));
+    L.exact = take((size_t)Q * kk * sizeof(float));
+    L.scores = take((size_t)L.slab * Q * sizeof(float));
+    L.wsplit = take(gemm_bf16x3_workspace_bytes(Q, D));
+    L.total = off;
+    return L;
+}
+
+}  // namespace evi
+
+extern "C" size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, int k) {
+    if (Q <= 0 || N < 0 || D <= 0 || k <= 0) return 0;
+    return gt_layout(Q, N, D, k).total;
+}
+
+extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
+                                    int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    EVI_REQUIRE(Q >= 1 && N >= 1 && D >= 1, "evi_cosine_topk_gemm: need Q >= 1, N >= 1, D >= 1, got Q=%d N=%lld D=%d", Q,
+                (long long)N, D);
+    EVI_REQUIRE(k >= 1, "evi_cosine_topk_gemm: k must be >= 1, got %d", k);
+    if (D % 16 != 0) return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: D must be a multiple of 16, got %d", D);
+    const int kk = gemm_topk_reserve(k);
+    if (kk > EVI_TOPK_MAX_K)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: k + reserve = %d exceeds %d (k <= %d)", kk, EVI_TOPK_MAX_K,
+                    EVI_TOPK_MAX_K * 2 / 3);
+    EVI_REQUIRE(N < (int64_t)0x7FFFFFFF, "evi_cosine_topk_gemm: N must fit int32 row ids");
+    EVI_REQUIRE(q && idx && out_score && out_index && status && workspace, "evi_cosine_topk_gemm: null pointer");
+    const GtLayout L = gt_layout(Q, N, D, k);
+    if (workspace_bytes < L.total)
+        return fail(EVI_ERR_NOMEM, "evi_cosine_topk_gemm: workspace %zu B < %zu B", workspace_bytes, L.total);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* base = static_cast<char*>(workspace);
+    float* tau = reinterpret_cast<float*>(base + L.tau);
+    int32_t* cnt = reinterpret_cast<int32_t*>(base + L.cnt);
+    float* cs = reinterpret_cast<float*>(base + L.cs);
+    int32_t* ci = reinterpret_cast<int32_t*>(base + L.ci);
+    float* exact = reinterpret_cast<float*>(base + L.exact);
+    float* scores = reinterpret_cast<float*>(base + L.scores);
+    hipLaunchKernelGGL(k_gt_init, dim3((Q + 255) / 256), dim3(256), 0, st, tau, cnt, Q, status);
+    EVI_LAUNCH_CHECK();
+    int64_t begin = 0, seg = N < kGemmFirstRows ? N : kGemmFirstRows;
+    while (begin < N) {
+        const int64_t rows = (N - begin) < seg ? (N - begin) : seg;
+        // scores[r, i] ~ idx[begin + r] . q[i]  (split-bf16 GEMM: the index slab is the row operand)
+        const int rc = launch_gemm_nt_bf16x3(idx + begin * D, rows, D, D, q, Q, D, nullptr, 0, scores, Q, base + L.wsplit, st);
+        if (rc != EVI_OK) return rc;
+        int64_t blocks = (rows * Q + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_gt_filter, dim3((unsigned)blocks), dim3(256), 0, st, scores, rows, Q, begin, row_scale, tau, cs,
+                           ci, cnt, status);
+        hipLaunchKernelGGL(k_gt_clamp, dim3((Q + 255) / 256), dim3(256), 0, st, cnt, Q);
+        hipLaunchKernelGGL(k_candidates_select, dim3(Q), dim3(kSelectThreads), 0, st, cs, ci, cnt, tau,
+                           (int64_t)kGemmTopkCap, kk, (int64_t)-1, 0, row_id_base, (float*)nullptr, (int64_t*)nullptr);
+        EVI_LAUNCH_CHECK();
+        begin += rows;
+        int64_t next = begin * kGemmGrowth;
+        seg = next < L.slab ? next : L.slab;
+    }
+    hipLaunchKernelGGL(k_gt_gap, dim3(Q), dim3(64), 0, st, q, Q, D, cs, cnt, k, kk, status);
+    const int tiles = (kk + 15) / 16;
+    const int64_t waves = (int64_t)Q * tiles;
+    hipLaunchKernelGGL(k_gt_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, idx, row_scale, ci, cnt, Q, kk, exact);
+    hipLaunchKernelGGL(k_gt_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ci, cnt, kk, k, row_id_base, out_score,
+                       out_index);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}

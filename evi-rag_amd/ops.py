@@ -195,6 +195,41 @@ def cosine_topk(
     return out_score, out_index
 
 
+def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_scale: Optional[torch.Tensor] = None,
+                     row_id_base: int = 0, fallback: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cosine_topk for many queries at once (see evi_cosine_topk_gemm): one split-bf16 GEMM pass over the index
+    selects candidates, the scan's arithmetic re-scores them; the result equals cosine_topk bit for bit.  Reads the
+    proof flag back (one synchronisation); when the proof fails (heavy score ties, adversarial row order) the scan
+    runs instead (fallback=True) or RuntimeError is raised."""
+    dev = _require_gpu(queries, index, row_scale)
+    if queries.dim() != 2 or index.dim() != 2:
+        raise ValueError("queries and index must be 2D")
+    q, x = _f32c(queries, "queries"), _f32c(index, "index")
+    Q, D = q.shape
+    N = x.shape[0]
+    if x.shape[1] != D:
+        raise ValueError(f"query dim {D} != index dim {x.shape[1]}")
+    if row_scale is not None:
+        row_scale = _f32c(row_scale, "row_scale").view(-1)
+        if row_scale.numel() != N:
+            raise ValueError(f"row_scale length {row_scale.numel()} != N {N}")
+    if Q == 0 or N == 0:
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base)
+    lib = _lib.load()
+    ws = _workspace(dev, "cosine_topk_gemm", int(lib.evi_cosine_topk_gemm_workspace_bytes(Q, N, D, int(k))))
+    out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.evi_cosine_topk_gemm(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), _ptr(out_score),
+                                        _ptr(out_index), status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+    st = int(status.item())
+    if st != 0:
+        if not fallback:
+            raise RuntimeError(f"evi_cosine_topk_gemm could not prove exactness (status {st}): run cosine_topk")
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base)
+    return out_score, out_index
+
+
 def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge per-shard top-k lists [P, Q, k] (shards in ascending row-id order) into [Q, k]."""
     dev = _require_gpu(scores, ids)

@@ -132,6 +132,19 @@ int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, int64_t N, i
                         float* out_score, int64_t* out_index,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same result as evi_cosine_topk (ids and scores bit-identical) for MANY queries (Q in the hundreds; f32
+ * index, rows of unit norm after row_scale, D % 16 == 0, k <= 1365): the scores of all queries against a
+ * slab of rows are formed as one split-bf16 MFMA GEMM and used only to SELECT k + reserve candidates per
+ * query; the candidates are re-scored with the scan's own f32 MFMA sequence and the top-k is taken on
+ * those.  *status (device int32) is written 0 when the result is proven exact; non-zero (1: the k-th and the
+ * last kept approximate scores are closer than twice the GEMM's error bound — heavy ties; 2: a candidate
+ * list overflowed — adversarial row order) means the outputs must be discarded and evi_cosine_topk run
+ * instead.  One pass over the index instead of ceil(Q / 32).  */
+size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, int k);
+int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
+                         int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.
  *   scores [P, Q, k] f32, ids [P, Q, k] i64  ->  out_score [Q, k], out_index [Q, k].

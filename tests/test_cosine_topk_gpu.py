@@ -346,3 +346,42 @@ def test_reduced_precision_index_at_shard_size(dev, storage):
         deq = rows.float()
     ref = (deq.view(Q, 50, D).double() * q.double().view(Q, 1, D)).sum(-1).float()
     assert float((ref - s[:, :50]).abs().max()) < 3e-6
+
+
+@pytest.mark.parametrize("Q,N,D,k,scaled", [(512, 400000, 768, 500, False), (130, 50000, 128, 100, True), (96, 3000, 64, 10, False),
+                                             (64, 700, 32, 500, False)])
+def test_cosine_topk_gemm_equals_scan_bit_for_bit(dev, Q, N, D, k, scaled):
+    """Many-query path: ids AND scores identical to the scan (its candidates are re-scored with the scan's own
+    MFMA sequence); duplicated rows (exact ties) and a zero row are in the index."""
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N + 3)
+    q = np.random.default_rng(Q).standard_normal((Q, D), dtype=np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    if scaled:
+        idx, scale = xd, ops.row_inv_norm(xd, EPS)
+    else:
+        idx, scale = ops.normalize_embeddings(xd, EPS), None
+    s0, i0 = ops.cosine_topk(qn, idx, k, row_scale=scale, row_id_base=11)
+    s1, i1 = ops.cosine_topk_gemm(qn, idx, k, row_scale=scale, row_id_base=11, fallback=False)
+    assert torch.equal(i1, i0)
+    assert torch.equal(s1, s0)
+
+
+def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):
+    """All rows identical: every approximate score ties, the gap test fails, fallback=False raises and the
+    default falls back to the scan."""
+    from evi_rag_amd import ops
+
+    N, D, Q, k = 5000, 64, 40, 50
+    row = torch.randn(D, device=dev)
+    idx = ops.normalize_embeddings(row.repeat(N, 1))
+    qn = ops.normalize_embeddings(torch.randn(Q, D, device=dev))
+    with pytest.raises(RuntimeError, match="could not prove"):
+        ops.cosine_topk_gemm(qn, idx, k, fallback=False)
+    s, i = ops.cosine_topk_gemm(qn, idx, k)
+    s0, i0 = ops.cosine_topk(qn, idx, k)
+    assert torch.equal(i, i0) and torch.equal(s, s0)
+    with pytest.raises(NotImplementedError):
+        ops.cosine_topk_gemm(qn, idx, 1500)  # k + reserve exceeds the selector's capacity
