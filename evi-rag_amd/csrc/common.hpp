@@ -51,6 +51,22 @@ void timing_end(int token, hipStream_t st);
 int launch_gemm_nt(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                    const float* bias, int act, float* C, int64_t ldc, hipStream_t st);
 
+// Threshold-filter epilogue of the split-bf16 GEMM (many-query top-k): instead of being stored, the element
+// (row m, column n) is appended to column n's candidate list when value * row_scale[row0 + m] >= tau[n].
+struct GemmFilter {
+    const float* tau;        // [N]
+    const float* row_scale;  // [>= row0 + M] or null
+    int64_t row0;            // global row of A's first row
+    float* cand_score;       // [N, cap]
+    int32_t* cand_id;        // [N, cap]
+    int32_t* cand_cnt;       // [N * cnt_stride]
+    int32_t* status;         // |= 2 when a list is full
+    int cap, cnt_stride;
+};
+// W [N, K] -> bf16 hi / lo planes in wsplit (once); then C = A W^T with the planes, or the filter epilogue.
+int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st);
+int launch_gemm_bf16x3_filter(const float* A, int64_t M, int K, int64_t lda, const void* wsplit, int N,
+                              const GemmFilter& flt, hipStream_t st);
 // Split-bf16 variant (gemm_bf16x3.hip); wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes.
 size_t gemm_bf16x3_workspace_bytes(int N, int K);
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,

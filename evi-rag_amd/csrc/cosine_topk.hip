@@ -663,7 +663,7 @@ constexpr float kApproxEps = 2.5e-4f;        // |gemm score - scan score| <= kAp
                                              // plus the scan's own 768 x 2^-24
 constexpr int kGemmTopkCap = 16384;          // candidate slots per query between two selections
 constexpr int64_t kGemmFirstRows = 4096;     // first slab: every row is a candidate (4096 <= cap)
-constexpr int64_t kGemmSlabRows = 262144;    // largest slab: 262144 x Q f32 scores (512 MiB at Q = 512)
+constexpr int64_t kGemmSlabRows = 1 << 21;   // rows per GEMM launch between two selections (bounds the appends)
 constexpr int kGemmGrowth = 8;
 
 static int gemm_topk_reserve(int k) {
@@ -804,12 +804,13 @@ static GtLayout gt_layout(int Q, int64_t N, int D, int k) {
     };
     const int kk = gemm_topk_reserve(k);
     L.slab = N < kGemmSlabRows ? (N > 0 ? N : 1) : kGemmSlabRows;
+    const int64_t first = N < kGemmFirstRows ? (N > 0 ? N : 1) : kGemmFirstRows;
     L.tau = take((size_t)Q * sizeof(float));
     L.cnt = take((size_t)Q * kCntStride * sizeof(int32_t));
     L.cs = take((size_t)Q * kGemmTopkCap * sizeof(float));
     L.ci = take((size_t)Q * kGemmTopkCap * sizeof(int32_t));
     L.exact = take((size_t)Q * kk * sizeof(float));
-    L.scores = take((size_t)L.slab * Q * sizeof(float));
+    L.scores = take((size_t)first * Q * sizeof(float));  // only the first slab's scores are materialised
     L.wsplit = take(gemm_bf16x3_workspace_bytes(Q, D));
     L.total = off;
     return L;
@@ -848,16 +849,26 @@ extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int
     float* scores = reinterpret_cast<float*>(base + L.scores);
     hipLaunchKernelGGL(k_gt_init, dim3((Q + 255) / 256), dim3(256), 0, st, tau, cnt, Q, status);
     EVI_LAUNCH_CHECK();
+    int rc = split_weight_bf16x3(q, Q, D, D, base + L.wsplit, st);  // the queries are the "weights": split once
+    if (rc != EVI_OK) return rc;
     int64_t begin = 0, seg = N < kGemmFirstRows ? N : kGemmFirstRows;
     while (begin < N) {
         const int64_t rows = (N - begin) < seg ? (N - begin) : seg;
-        // scores[r, i] ~ idx[begin + r] . q[i]  (split-bf16 GEMM: the index slab is the row operand)
-        const int rc = launch_gemm_nt_bf16x3(idx + begin * D, rows, D, D, q, Q, D, nullptr, 0, scores, Q, base + L.wsplit, st);
-        if (rc != EVI_OK) return rc;
-        int64_t blocks = (rows * Q + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_gt_filter, dim3((unsigned)blocks), dim3(256), 0, st, scores, rows, Q, begin, row_scale, tau, cs,
-                           ci, cnt, status);
+        if (begin == 0) {
+            // first slab: every score passes (tau = -inf), so form the scores and append them with plain stores
+            rc = launch_gemm_nt_bf16x3(idx, rows, D, D, q, Q, D, nullptr, 0, scores, Q, base + L.wsplit, st);
+            if (rc != EVI_OK) return rc;
+            int64_t blocks = (rows * Q + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(k_gt_filter, dim3((unsigned)blocks), dim3(256), 0, st, scores, rows, Q, begin, row_scale, tau,
+                               cs, ci, cnt, status);
+        } else {
+            // later slabs: scores ~ idx[begin + r] . q[i] never leave the registers of the GEMM — its epilogue
+            // compares them with tau and appends the few survivors
+            const GemmFilter flt{tau, row_scale, begin, cs, ci, cnt, status, kGemmTopkCap, kCntStride};
+            rc = launch_gemm_bf16x3_filter(idx + begin * D, rows, D, D, base + L.wsplit, Q, flt, st);
+            if (rc != EVI_OK) return rc;
+        }
         hipLaunchKernelGGL(k_gt_clamp, dim3((Q + 255) / 256), dim3(256), 0, st, cnt, Q);
         hipLaunchKernelGGL(k_candidates_select, dim3(Q), dim3(kSelectThreads), 0, st, cs, ci, cnt, tau,
                            (int64_t)kGemmTopkCap, kk, (int64_t)-1, 0, row_id_base, (float*)nullptr, (int64_t*)nullptr);

@@ -57,7 +57,7 @@ template <int ACT, int MF>
 __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
-    int64_t ldc) {
+    int64_t ldc, GemmFilter flt) {
     __shared__ uint4 sAhi[2][XM * 4], sAlo[2][XM * 4], sWhi[2][XN * 4], sWlo[2][XN * 4];  // 2 stages x 4 x 16 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -224,6 +224,33 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         __syncthreads();
     }
 
+    if (ACT == 3) {  // threshold filter instead of a store (MF = 0 layout): survivors are rare after the first slab
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fr;
+            if (n >= N) continue;
+            const float t = flt.tau[n];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (m >= M) continue;
+                    float sc = acc[MF ? 0 : i][MF ? 0 : j][r];
+                    if (flt.row_scale) sc *= flt.row_scale[flt.row0 + m];
+                    if (sc >= t || sc != sc) {
+                        const int32_t pos = atomicAdd(&flt.cand_cnt[n * flt.cnt_stride], 1);
+                        if (pos < flt.cap) {
+                            flt.cand_score[(int64_t)n * flt.cap + pos] = sc;
+                            flt.cand_id[(int64_t)n * flt.cap + pos] = (int32_t)(flt.row0 + m);
+                        } else {
+                            atomicOr(flt.status, 2);
+                        }
+                    }
+                }
+        }
+        return;
+    }
     if (MF) {  // 16x16 accumulators: col = lane & 15, row = 4 (lane >> 4) + r
         const bool interior = m0 + XM <= M && n0 + XN <= N;
 #pragma unroll
@@ -276,15 +303,39 @@ size_t gemm_bf16x3_workspace_bytes(int N, int K) {
 }
 
 // wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes of scratch for the split weight planes.
-int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
-                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
-    if (M == 0 || N == 0) return EVI_OK;
+int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st) {
     const int Kp = (K + XK - 1) / XK * XK;
     __bf16* hi = static_cast<__bf16*>(wsplit);
     __bf16* lo = reinterpret_cast<__bf16*>(static_cast<char*>(wsplit) + align_up((size_t)N * Kp * 2, 256));
     const int64_t total = (int64_t)N * Kp;
     hipLaunchKernelGGL(k_split_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, ldw, Kp, hi, lo);
     EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+int launch_gemm_bf16x3_filter(const float* A, int64_t M, int K, int64_t lda, const void* wsplit, int N,
+                              const GemmFilter& flt, hipStream_t st) {
+    if (M == 0 || N == 0) return EVI_OK;
+    const int Kp = (K + XK - 1) / XK * XK;
+    const __bf16* hi = static_cast<const __bf16*>(wsplit);
+    const __bf16* lo = reinterpret_cast<const __bf16*>(static_cast<const char*>(wsplit) + align_up((size_t)N * Kp * 2, 256));
+    const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
+    const int tok = timing_begin(kTimeGemm, st);
+    hipLaunchKernelGGL((k_gemm_nt_bf16x3<3, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp,
+                       static_cast<const float*>(nullptr), static_cast<float*>(nullptr), (int64_t)0, flt);
+    timing_end(tok, st);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
+    if (M == 0 || N == 0) return EVI_OK;
+    const int Kp = (K + XK - 1) / XK * XK;
+    __bf16* hi = static_cast<__bf16*>(wsplit);
+    __bf16* lo = reinterpret_cast<__bf16*>(static_cast<char*>(wsplit) + align_up((size_t)N * Kp * 2, 256));
+    if (int rc = split_weight_bf16x3(W, N, K, ldw, wsplit, st)) return rc;
+    const GemmFilter flt{};
     const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
     const int tok = timing_begin(kTimeGemm, st);
     // EVI_GEMM_MFMA=16 selects the 16x16x32 form (tuning knob; measured 3-10 % slower here: its stores are 64-byte
@@ -295,9 +346,9 @@ int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const f
     }();
 #define EVI_LAUNCH_X3(ACT)                                                                                              \
     if (mfma16)                                                                                                         \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc); \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt); \
     else                                                                                                                \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc);
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt);
     switch (act) {
         case 1: EVI_LAUNCH_X3(1) break;
         case 2: EVI_LAUNCH_X3(2) break;
