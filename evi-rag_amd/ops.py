@@ -146,10 +146,20 @@ def cosine_topk(
     row_id_base: int = 0,
     workspace: Optional[torch.Tensor] = None,
     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+    method: str = "scan",
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Top-k rows of `index` per query by dot product (cosine when both are L2-normalised, or when
     `index` is raw and row_scale = row_inv_norm(index)).  Returns (scores [Q,k] f32, ids [Q,k] i64),
-    ordered (score desc, id asc); slots past min(k, N) hold (-inf, -1)."""
+    ordered (score desc, id asc); slots past min(k, N) hold (-inf, -1).
+    method: "scan" (default: 32 queries per pass over the index, never synchronises), "gemm" (many queries in
+    one GEMM-shaped pass, same result, one synchronisation — see cosine_topk_gemm) or "auto" (gemm for
+    Q >= 96 on an f32 index of unit rows when its limits allow, else scan)."""
+    if method not in ("scan", "gemm", "auto"):
+        raise ValueError(f"method must be 'scan', 'gemm' or 'auto', got {method!r}")
+    if method != "scan" and out is None and index.dtype == torch.float32 and queries.dim() == 2 and index.dim() == 2:
+        eligible = index.size(1) % 16 == 0 and k + max(256, k // 2) <= 2048 and index.size(0) >= 1 and queries.size(0) >= 1
+        if method == "gemm" or (eligible and queries.size(0) >= 96):
+            return cosine_topk_gemm(queries, index, k, row_scale=row_scale, row_id_base=row_id_base)
     dev = _require_gpu(queries, index, row_scale, workspace)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")

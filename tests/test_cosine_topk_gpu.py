@@ -383,5 +383,9 @@ def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):
     s, i = ops.cosine_topk_gemm(qn, idx, k)
     s0, i0 = ops.cosine_topk(qn, idx, k)
     assert torch.equal(i, i0) and torch.equal(s, s0)
+    big_q = ops.normalize_embeddings(torch.randn(100, D, device=dev))
+    sa, ia = ops.cosine_topk(big_q, idx, k, method="auto")  # 100 queries: routed to the GEMM path, which falls back here
+    sb, ib = ops.cosine_topk(big_q, idx, k)
+    assert torch.equal(ia, ib) and torch.equal(sa, sb)
     with pytest.raises(NotImplementedError):
         ops.cosine_topk_gemm(qn, idx, 1500)  # k + reserve exceeds the selector's capacity
