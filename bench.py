@@ -48,6 +48,9 @@ def parse_args():
                     help="storage dtype of the resident index (f16 / fp8 e4m3 + per-row scale: BASELINE configs 4 / 5; "
                          "the headline is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--topk-method", choices=["scan", "gemm", "auto"], default="scan",
+                    help="local top-k kernel: the 32-queries-per-pass scan (default), the many-query GEMM-shaped pass "
+                         "(same results; pays off for --queries >= 96), or auto")
     ap.add_argument("--graph-kernels", action="store_true",
                     help="run ONLY the BASELINE config 3 leg (CWQ-shaped CSR / DDE / BFS / seed expansion kernels with their "
                          "CPU-oracle baseline) and print its JSON object")
@@ -407,7 +410,7 @@ def main():
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
     from evi_rag_amd.dist import ShardedIndex
 
-    index = ShardedIndex(shard, N, row_scale=row_scale)
+    index = ShardedIndex(shard, N, row_scale=row_scale, method=args.topk_method if args.index_dtype == "f32" else "scan")
     index.workspace = ws
 
     def step(b):
@@ -435,9 +438,9 @@ def main():
     lib.evi_timing_enable(0)
     import ctypes
 
-    ms = (ctypes.c_double * 2)()
-    launches = (ctypes.c_int32 * 2)()
-    _lib.check(lib.evi_timing_read(ms, launches, 2))
+    ms = (ctypes.c_double * 4)()
+    launches = (ctypes.c_int32 * 4)()
+    _lib.check(lib.evi_timing_read(ms, launches, 4))
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -478,6 +481,7 @@ def main():
                 "queries_per_step": Q,
                 "k": k,
                 "index_dtype": args.index_dtype,
+                "topk_method": args.topk_method,
                 "sharding": f"rows/{world}" if world > 1 else "none",
             },
             "roofline": {
@@ -496,6 +500,15 @@ def main():
             "hits_at_k": hits,
             "sorted_ok": sorted_ok,
         }
+        if ms[2] > ms[0]:
+            # the many-query path did the work: the dominant kernel is the split-bf16 GEMM (MFMA-bound), priced by the
+            # flops it executes (3 bf16 products per f32 product) against the dense bf16 peak
+            gemm_ms = ms[2] / steps
+            executed = 3.0 * 2.0 * Q * shard_rows * D / (gemm_ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s", "frac": executed / 2500.0,
+                                  "traffic": None, "kernel": "k_gemm_nt_bf16x3 (threshold-filter epilogue)",
+                                  "algorithmic_flops_per_step": 2.0 * Q * shard_rows * D, "launches_per_step": launches[2] / steps,
+                                  "kernel_ms_per_step": gemm_ms, "select_ms_per_step": ms[1] / steps}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(shard if shard_f32_sample is None else shard_f32_sample, queries, k, N,
                                                   args.cpu_rows, args.cpu_seconds)

@@ -34,10 +34,10 @@ def shard_graphs(num_graphs: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_graphs, world_size))
 
 
-def _default_local_topk(queries, shard, k, row_id_base, row_scale=None):
+def _default_local_topk(queries, shard, k, row_id_base, row_scale=None, method="scan"):
     from . import ops
 
-    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale)
+    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale, method=method)
 
 
 def _default_merge(scores, ids):
@@ -51,7 +51,7 @@ class ShardedIndex:
 
     def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
                  local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
-                 row_scale: Optional[torch.Tensor] = None) -> None:
+                 row_scale: Optional[torch.Tensor] = None, method: str = "scan") -> None:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -61,6 +61,7 @@ class ShardedIndex:
             raise ValueError(f"rank {self.rank} must hold rows [{self.row_begin}, {self.row_end}): "
                              f"{self.row_end - self.row_begin} rows, got {local_rows.size(0)}")
         self.shard = local_rows
+        self.method = method  # ops.cosine_topk method for the local top-k: "scan" | "gemm" | "auto"
         # per-row scale of the local shard: the fused normalisation of a raw index, or the
         # dequantisation scale of an fp8 index (ops.quantize_rows_fp8)
         self.row_scale = row_scale
@@ -84,7 +85,9 @@ class ShardedIndex:
         """Global top-k (scores [Q, k], global row ids [Q, k]) — identical on every rank."""
         if self._exchange and self._packed_ok and queries.is_cuda:
             return self._topk_packed(queries, k)
-        if self.row_scale is not None:
+        if self._local_topk is _default_local_topk:
+            s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale, self.method)
+        elif self.row_scale is not None:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale)
         else:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin)
@@ -110,7 +113,7 @@ def _topk_packed(self: "ShardedIndex", queries: torch.Tensor, k: int):
         self._packed_all = torch.empty(self.world * rec, dtype=torch.uint8, device=queries.device)
     s, i = ops.topk_packed_views(self._packed_local, Q, k)
     ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
-                    workspace=self.workspace, out=(s, i))
+                    workspace=self.workspace, out=(s, i), method=self.method)
     dist.all_gather_into_tensor(self._packed_all, self._packed_local, group=self.group)
     return ops.topk_merge_packed(self._packed_all, self.world, Q, k)
 
@@ -147,7 +150,7 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
         main.wait_event(p["xchg_done"][slot])  # the all-gather two batches ago has consumed this slot's record
     sv, iv = ops.topk_packed_views(p["local"][slot], Q, k)
     ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale, workspace=self.workspace,
-                    out=(sv, iv))
+                    out=(sv, iv), method=self.method)
     p["scan_done"][slot].record(main)
     side = p["side"]
     with torch.cuda.stream(side):

@@ -156,10 +156,10 @@ def cosine_topk(
     Q >= 96 on an f32 index of unit rows when its limits allow, else scan)."""
     if method not in ("scan", "gemm", "auto"):
         raise ValueError(f"method must be 'scan', 'gemm' or 'auto', got {method!r}")
-    if method != "scan" and out is None and index.dtype == torch.float32 and queries.dim() == 2 and index.dim() == 2:
+    if method != "scan" and index.dtype == torch.float32 and queries.dim() == 2 and index.dim() == 2:
         eligible = index.size(1) % 16 == 0 and k + max(256, k // 2) <= 2048 and index.size(0) >= 1 and queries.size(0) >= 1
         if method == "gemm" or (eligible and queries.size(0) >= 96):
-            return cosine_topk_gemm(queries, index, k, row_scale=row_scale, row_id_base=row_id_base)
+            return cosine_topk_gemm(queries, index, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
     dev = _require_gpu(queries, index, row_scale, workspace)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
@@ -206,7 +206,8 @@ def cosine_topk(
 
 
 def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_scale: Optional[torch.Tensor] = None,
-                     row_id_base: int = 0, fallback: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                     row_id_base: int = 0, fallback: bool = True,
+                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cosine_topk for many queries at once (see evi_cosine_topk_gemm): one split-bf16 GEMM pass over the index
     selects candidates, the scan's arithmetic re-scores them; the result equals cosine_topk bit for bit.  Reads the
     proof flag back (one synchronisation); when the proof fails (heavy score ties, adversarial row order) the scan
@@ -224,11 +225,17 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         if row_scale.numel() != N:
             raise ValueError(f"row_scale length {row_scale.numel()} != N {N}")
     if Q == 0 or N == 0:
-        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base)
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
     lib = _lib.load()
     ws = _workspace(dev, "cosine_topk_gemm", int(lib.evi_cosine_topk_gemm_workspace_bytes(Q, N, D, int(k))))
-    out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
-    out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    if out is not None:
+        out_score, out_index = out
+        if (out_score.shape != (Q, k) or out_index.shape != (Q, k) or out_score.dtype != torch.float32
+                or out_index.dtype != torch.int64 or not out_score.is_contiguous() or not out_index.is_contiguous()):
+            raise ValueError("out must be contiguous (float32 [Q, k], int64 [Q, k]) tensors")
+    else:
+        out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     status = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.check(lib.evi_cosine_topk_gemm(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), _ptr(out_score),
                                         _ptr(out_index), status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
@@ -236,7 +243,7 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
     if st != 0:
         if not fallback:
             raise RuntimeError(f"evi_cosine_topk_gemm could not prove exactness (status {st}): run cosine_topk")
-        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base)
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
     return out_score, out_index
 
 
