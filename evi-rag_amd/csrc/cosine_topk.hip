@@ -765,6 +765,48 @@ __global__ __launch_bounds__(256) void k_gt_rescore(const float* __restrict__ q,
     }
 }
 
+// The same for an f16-stored index: the scan multiplies the f16 rows with the query split hi + lo (lo scaled by
+// kLoScale) on v_mfma_f32_16x16x32_f16 into two accumulators, chunk by chunk of 32 dims, and combines them as
+// fma(acc_lo, 1 / kLoScale, acc).  Replayed here for (query in row 0, 16 candidates in the columns).
+__global__ __launch_bounds__(256) void k_gt_rescore_f16(const float* __restrict__ q, int D, const _Float16* __restrict__ idx,
+                                                        const float* __restrict__ row_scale, const int32_t* __restrict__ cand_id,
+                                                        const int32_t* __restrict__ cand_cnt, int Q, int kk,
+                                                        float* __restrict__ exact) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, g = lane >> 4;
+    const int tiles = (kk + 15) / 16;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= (int64_t)Q * tiles) return;
+    const int qi = (int)(w / tiles), t = (int)(w % tiles);
+    const int m = cand_cnt[qi * kCntStride] < kk ? cand_cnt[qi * kCntStride] : kk;
+    const int c = t * 16 + n;
+    const int32_t row = c < m ? cand_id[(int64_t)qi * kGemmTopkCap + c] : -1;
+    const f16x8* xp = reinterpret_cast<const f16x8*>(idx + (int64_t)(row >= 0 ? row : 0) * D) + g;
+    const float* qp = q + (int64_t)qi * D;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_lo = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < D / 32; ++j) {
+        const f16x8 x = xp[j * 4];
+        f16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {  // the split of k_query_fragments_f16
+            const float v = n == 0 ? qp[32 * j + 8 * g + e] : 0.f;
+            const _Float16 h = (_Float16)v;
+            ah[e] = h;
+            al[e] = (_Float16)((v - (float)h) * kLoScale);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, x, acc, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, x, acc_lo, 0, 0, 0);
+    }
+    if (g == 0 && c < kk) {
+        float s = -INFINITY;
+        if (row >= 0) {
+            const float dot = fmaf(acc_lo[0], 1.0f / kLoScale, acc[0]);
+            s = row_scale ? dot * row_scale[row] : dot;
+        }
+        exact[(int64_t)qi * kk + c] = s;
+    }
+}
+
 // final selection on the exact scores: (score desc, row id asc), like the scan
 __global__ __launch_bounds__(kSelectThreads) void k_gt_final(const float* __restrict__ exact, const int32_t* __restrict__ cand_id,
                                                              const int32_t* __restrict__ cand_cnt, int kk, int k,
@@ -823,13 +865,14 @@ extern "C" size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, 
     return gt_layout(Q, N, D, k).total;
 }
 
-extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
-                                    int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16, int64_t N, int D, const float* row_scale,
+                                 int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
     EVI_REQUIRE(Q >= 1 && N >= 1 && D >= 1, "evi_cosine_topk_gemm: need Q >= 1, N >= 1, D >= 1, got Q=%d N=%lld D=%d", Q,
                 (long long)N, D);
     EVI_REQUIRE(k >= 1, "evi_cosine_topk_gemm: k must be >= 1, got %d", k);
-    if (D % 16 != 0) return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: D must be a multiple of 16, got %d", D);
+    if (D % (f16 ? 32 : 16) != 0)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: D must be a multiple of %d, got %d", f16 ? 32 : 16, D);
     const int kk = gemm_topk_reserve(k);
     if (kk > EVI_TOPK_MAX_K)
         return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: k + reserve = %d exceeds %d (k <= %d)", kk, EVI_TOPK_MAX_K,
@@ -847,6 +890,8 @@ extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int
     int32_t* ci = reinterpret_cast<int32_t*>(base + L.ci);
     float* exact = reinterpret_cast<float*>(base + L.exact);
     float* scores = reinterpret_cast<float*>(base + L.scores);
+    const char* rows_base = static_cast<const char*>(idx);
+    const size_t row_bytes = (size_t)D * (f16 ? 2 : 4);
     hipLaunchKernelGGL(k_gt_init, dim3((Q + 255) / 256), dim3(256), 0, st, tau, cnt, Q, status);
     EVI_LAUNCH_CHECK();
     int rc = split_weight_bf16x3(q, Q, D, D, base + L.wsplit, st);  // the queries are the "weights": split once
@@ -854,9 +899,12 @@ extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int
     int64_t begin = 0, seg = N < kGemmFirstRows ? N : kGemmFirstRows;
     while (begin < N) {
         const int64_t rows = (N - begin) < seg ? (N - begin) : seg;
+        const void* slab = rows_base + begin * row_bytes;
         if (begin == 0) {
             // first slab: every score passes (tau = -inf), so form the scores and append them with plain stores
-            rc = launch_gemm_nt_bf16x3(idx, rows, D, D, q, Q, D, nullptr, 0, scores, Q, base + L.wsplit, st);
+            rc = f16 ? launch_gemm_bf16x3_f16a(slab, rows, D, D, base + L.wsplit, Q, scores, Q, st)
+                     : launch_gemm_nt_bf16x3(static_cast<const float*>(slab), rows, D, D, q, Q, D, nullptr, 0, scores, Q,
+                                             base + L.wsplit, st);
             if (rc != EVI_OK) return rc;
             int64_t blocks = (rows * Q + 255) / 256;
             if (blocks > 8192) blocks = 8192;
@@ -866,7 +914,7 @@ extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int
             // later slabs: scores ~ idx[begin + r] . q[i] never leave the registers of the GEMM — its epilogue
             // compares them with tau and appends the few survivors
             const GemmFilter flt{tau, row_scale, begin, cs, ci, cnt, status, kGemmTopkCap, kCntStride};
-            rc = launch_gemm_bf16x3_filter(idx + begin * D, rows, D, D, base + L.wsplit, Q, flt, st);
+            rc = launch_gemm_bf16x3_filter(slab, f16, rows, D, D, base + L.wsplit, Q, flt, st);
             if (rc != EVI_OK) return rc;
         }
         hipLaunchKernelGGL(k_gt_clamp, dim3((Q + 255) / 256), dim3(256), 0, st, cnt, Q);
@@ -880,9 +928,28 @@ extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int
     hipLaunchKernelGGL(k_gt_gap, dim3(Q), dim3(64), 0, st, q, Q, D, cs, cnt, k, kk, status);
     const int tiles = (kk + 15) / 16;
     const int64_t waves = (int64_t)Q * tiles;
-    hipLaunchKernelGGL(k_gt_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, idx, row_scale, ci, cnt, Q, kk, exact);
+    if (f16)
+        hipLaunchKernelGGL(k_gt_rescore_f16, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D,
+                           static_cast<const _Float16*>(idx), row_scale, ci, cnt, Q, kk, exact);
+    else
+        hipLaunchKernelGGL(k_gt_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, static_cast<const float*>(idx),
+                           row_scale, ci, cnt, Q, kk, exact);
     hipLaunchKernelGGL(k_gt_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ci, cnt, kk, k, row_id_base, out_score,
                        out_index);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
+}
+
+extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
+                                    int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return cosine_topk_gemm_impl(q, Q, idx, 0, N, D, row_scale, k, row_id_base, out_score, out_index, status, workspace,
+                                 workspace_bytes, stream);
+}
+
+extern "C" int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D, const float* row_scale,
+                                        int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    return cosine_topk_gemm_impl(q, Q, idx_f16, 1, N, D, row_scale, k, row_id_base, out_score, out_index, status, workspace,
+                                 workspace_bytes, stream);
 }

@@ -156,8 +156,8 @@ def cosine_topk(
     Q >= 96 on an f32 index of unit rows when its limits allow, else scan)."""
     if method not in ("scan", "gemm", "auto"):
         raise ValueError(f"method must be 'scan', 'gemm' or 'auto', got {method!r}")
-    if method != "scan" and index.dtype == torch.float32 and queries.dim() == 2 and index.dim() == 2:
-        eligible = index.size(1) % 16 == 0 and k + max(256, k // 2) <= 2048 and index.size(0) >= 1 and queries.size(0) >= 1
+    if method != "scan" and index.dtype in (torch.float32, torch.float16) and queries.dim() == 2 and index.dim() == 2:
+        eligible = index.size(1) % (32 if index.dtype == torch.float16 else 16) == 0 and k + max(256, k // 2) <= 2048 and index.size(0) >= 1 and queries.size(0) >= 1
         if method == "gemm" or (eligible and queries.size(0) >= 96):
             return cosine_topk_gemm(queries, index, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
     dev = _require_gpu(queries, index, row_scale, workspace)
@@ -215,7 +215,8 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
     dev = _require_gpu(queries, index, row_scale)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
-    q, x = _f32c(queries, "queries"), _f32c(index, "index")
+    q = _f32c(queries, "queries")
+    x = index.contiguous() if index.dtype == torch.float16 else _f32c(index, "index")  # f16 storage: evi_cosine_topk_gemm_f16
     Q, D = q.shape
     N = x.shape[0]
     if x.shape[1] != D:
@@ -237,8 +238,9 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     status = torch.empty(1, dtype=torch.int32, device=dev)
-    _lib.check(lib.evi_cosine_topk_gemm(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), _ptr(out_score),
-                                        _ptr(out_index), status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+    fn = lib.evi_cosine_topk_gemm_f16 if x.dtype == torch.float16 else lib.evi_cosine_topk_gemm
+    _lib.check(fn(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), _ptr(out_score), _ptr(out_index),
+                  status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
     st = int(status.item())
     if st != 0:
         if not fallback:

@@ -144,6 +144,11 @@ size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, int k);
 int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
                          int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same over an f16-stored index (D % 32 == 0): bit-identical to evi_cosine_topk_f16.  An f16 value is exactly
+ * hi + lo in bf16, so the selection GEMM loses nothing on the index side. */
+int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D, const float* row_scale,
+                             int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.

@@ -389,3 +389,19 @@ def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):
     assert torch.equal(ia, ib) and torch.equal(sa, sb)
     with pytest.raises(NotImplementedError):
         ops.cosine_topk_gemm(qn, idx, 1500)  # k + reserve exceeds the selector's capacity
+
+
+@pytest.mark.parametrize("Q,N,D,k", [(256, 300000, 768, 500), (100, 20000, 64, 40)])
+def test_cosine_topk_gemm_f16_index_equals_f16_scan(dev, Q, N, D, k):
+    """f16-stored index: the many-query path must reproduce evi_cosine_topk_f16 bit for bit."""
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N + 9)
+    q = np.random.default_rng(Q + 1).standard_normal((Q, D), dtype=np.float32)
+    x16 = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS).to(torch.float16)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    s0, i0 = ops.cosine_topk(qn, x16, k, row_id_base=3)
+    s1, i1 = ops.cosine_topk_gemm(qn, x16, k, row_id_base=3, fallback=False)
+    assert torch.equal(i1, i0) and torch.equal(s1, s0)
+    s2, i2 = ops.cosine_topk(qn, x16, k, row_id_base=3, method="auto")
+    assert torch.equal(i2, i0) and torch.equal(s2, s0)
