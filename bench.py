@@ -410,7 +410,7 @@ def main():
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
     from evi_rag_amd.dist import ShardedIndex
 
-    index = ShardedIndex(shard, N, row_scale=row_scale, method=args.topk_method if args.index_dtype == "f32" else "scan")
+    index = ShardedIndex(shard, N, row_scale=row_scale, method=args.topk_method if args.index_dtype in ("f32", "f16") else "scan")
     index.workspace = ws
 
     def step(b):
