@@ -65,11 +65,12 @@ struct GemmFilter {
 };
 // W [N, K] -> bf16 hi / lo planes in wsplit (once); then C = A W^T with the planes, or the filter epilogue.
 int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st);
-int launch_gemm_bf16x3_filter(const void* A, int a_f16, int64_t M, int K, int64_t lda, const void* wsplit, int N,
+// a_f16: A stored as f16; single: one product (hi * hi, plain bf16 accuracy) instead of three
+int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, int K, int64_t lda, const void* wsplit, int N,
                               const GemmFilter& flt, hipStream_t st);
-// C = A16 W^T with A stored as f16 and W already split (plain store epilogue)
-int launch_gemm_bf16x3_f16a(const void* A16, int64_t M, int K, int64_t lda, const void* wsplit, int N, float* C, int64_t ldc,
-                            hipStream_t st);
+// C = A W^T with W already split (plain store epilogue)
+int launch_gemm_bf16_presplit(const void* A, int a_f16, int single, int64_t M, int K, int64_t lda, const void* wsplit, int N,
+                              float* C, int64_t ldc, hipStream_t st);
 // Split-bf16 variant (gemm_bf16x3.hip); wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes.
 size_t gemm_bf16x3_workspace_bytes(int N, int K);
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,

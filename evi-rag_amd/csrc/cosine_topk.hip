@@ -661,12 +661,16 @@ namespace evi {
 constexpr float kApproxEps = 2.5e-4f;        // |gemm score - scan score| <= kApproxEps * |q| for unit-norm rows:
                                              // bf16 hi/lo split 2^-16 + 2^-18, 2304 f32 accumulations x 2^-24,
                                              // plus the scan's own 768 x 2^-24
+constexpr float kApproxEps1 = 4.2e-3f;       // single-product selection: both operands rounded to bf16 (2 x 2^-9 + 2^-18
+                                             // relative per product), 768 accumulations, plus the scan's own error
 constexpr int kGemmTopkCap = 16384;          // candidate slots per query between two selections
 constexpr int64_t kGemmFirstRows = 4096;     // first slab: every row is a candidate (4096 <= cap)
 constexpr int64_t kGemmSlabRows = 1 << 21;   // rows per GEMM launch between two selections (bounds the appends)
 constexpr int kGemmGrowth = 8;
 
-static int gemm_topk_reserve(int k) {
+// candidates kept per query: the coarser the selection scores, the more rows can hide inside 2 eps of the k-th
+static int gemm_topk_reserve(int k, int single = 0) {
+    if (single) return k + (k > 1024 ? k : 1024);
     int r = k / 2 > 256 ? k / 2 : 256;
     return k + r;
 }
@@ -712,7 +716,7 @@ __global__ void k_gt_clamp(int32_t* cnt, int Q) {
 
 // gap test: with kk rows kept, the true top-k is among them iff approx[k-1] - approx[kk-1] > 2 eps |q|
 __global__ void k_gt_gap(const float* __restrict__ q, int Q, int D, const float* __restrict__ cand_score,
-                         const int32_t* __restrict__ cand_cnt, int k, int kk, int32_t* __restrict__ status) {
+                         const int32_t* __restrict__ cand_cnt, int k, int kk, float eps, int32_t* __restrict__ status) {
     const int qi = blockIdx.x;
     const int lane = threadIdx.x;  // one wave
     float ss = 0.f;
@@ -724,7 +728,7 @@ __global__ void k_gt_gap(const float* __restrict__ q, int Q, int D, const float*
         if (m >= kk) {
             const float* s = cand_score + (int64_t)qi * kGemmTopkCap;
             const float gap = s[k - 1] - s[kk - 1];
-            if (!(gap > 2.0f * kApproxEps * sqrtf(ss))) atomicOr(status, 1);
+            if (!(gap > 2.0f * eps * sqrtf(ss))) atomicOr(status, 1);
         }  // m < kk: every row of the index is in the list
     }
 }
@@ -836,7 +840,7 @@ struct GtLayout {
     int64_t slab;
 };
 
-static GtLayout gt_layout(int Q, int64_t N, int D, int k) {
+static GtLayout gt_layout(int Q, int64_t N, int D, int k, int single = 1 /* the larger reserve */) {
     GtLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -844,7 +848,7 @@ static GtLayout gt_layout(int Q, int64_t N, int D, int k) {
         off = align_up(off + bytes, 256);
         return at;
     };
-    const int kk = gemm_topk_reserve(k);
+    const int kk = gemm_topk_reserve(k, single) <= EVI_TOPK_MAX_K ? gemm_topk_reserve(k, single) : gemm_topk_reserve(k, 0);
     L.slab = N < kGemmSlabRows ? (N > 0 ? N : 1) : kGemmSlabRows;
     const int64_t first = N < kGemmFirstRows ? (N > 0 ? N : 1) : kGemmFirstRows;
     L.tau = take((size_t)Q * sizeof(float));
@@ -865,18 +869,21 @@ extern "C" size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, 
     return gt_layout(Q, N, D, k).total;
 }
 
-static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16, int64_t N, int D, const float* row_scale,
-                                 int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16, int products, int64_t N, int D,
+                                 const float* row_scale, int k, int64_t row_id_base, float* out_score, int64_t* out_index,
+                                 int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    EVI_REQUIRE(products == 1 || products == 3, "evi_cosine_topk_gemm: products must be 3 (split-bf16) or 1 (plain bf16), got %d",
+                products);
+    const int single = products == 1;
     EVI_REQUIRE(Q >= 1 && N >= 1 && D >= 1, "evi_cosine_topk_gemm: need Q >= 1, N >= 1, D >= 1, got Q=%d N=%lld D=%d", Q,
                 (long long)N, D);
     EVI_REQUIRE(k >= 1, "evi_cosine_topk_gemm: k must be >= 1, got %d", k);
     if (D % (f16 ? 32 : 16) != 0)
         return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: D must be a multiple of %d, got %d", f16 ? 32 : 16, D);
-    const int kk = gemm_topk_reserve(k);
+    const int kk = gemm_topk_reserve(k, single);
     if (kk > EVI_TOPK_MAX_K)
-        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: k + reserve = %d exceeds %d (k <= %d)", kk, EVI_TOPK_MAX_K,
-                    EVI_TOPK_MAX_K * 2 / 3);
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_gemm: k + reserve = %d exceeds %d (k <= %d with products = %d)", kk,
+                    EVI_TOPK_MAX_K, single ? EVI_TOPK_MAX_K - 1024 : EVI_TOPK_MAX_K * 2 / 3, products);
     EVI_REQUIRE(N < (int64_t)0x7FFFFFFF, "evi_cosine_topk_gemm: N must fit int32 row ids");
     EVI_REQUIRE(q && idx && out_score && out_index && status && workspace, "evi_cosine_topk_gemm: null pointer");
     const GtLayout L = gt_layout(Q, N, D, k);
@@ -902,9 +909,7 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
         const void* slab = rows_base + begin * row_bytes;
         if (begin == 0) {
             // first slab: every score passes (tau = -inf), so form the scores and append them with plain stores
-            rc = f16 ? launch_gemm_bf16x3_f16a(slab, rows, D, D, base + L.wsplit, Q, scores, Q, st)
-                     : launch_gemm_nt_bf16x3(static_cast<const float*>(slab), rows, D, D, q, Q, D, nullptr, 0, scores, Q,
-                                             base + L.wsplit, st);
+            rc = launch_gemm_bf16_presplit(slab, f16, single, rows, D, D, base + L.wsplit, Q, scores, Q, st);
             if (rc != EVI_OK) return rc;
             int64_t blocks = (rows * Q + 255) / 256;
             if (blocks > 8192) blocks = 8192;
@@ -914,7 +919,7 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
             // later slabs: scores ~ idx[begin + r] . q[i] never leave the registers of the GEMM — its epilogue
             // compares them with tau and appends the few survivors
             const GemmFilter flt{tau, row_scale, begin, cs, ci, cnt, status, kGemmTopkCap, kCntStride};
-            rc = launch_gemm_bf16x3_filter(slab, f16, rows, D, D, base + L.wsplit, Q, flt, st);
+            rc = launch_gemm_bf16x3_filter(slab, f16, single, rows, D, D, base + L.wsplit, Q, flt, st);
             if (rc != EVI_OK) return rc;
         }
         hipLaunchKernelGGL(k_gt_clamp, dim3((Q + 255) / 256), dim3(256), 0, st, cnt, Q);
@@ -925,7 +930,7 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
         int64_t next = begin * kGemmGrowth;
         seg = next < L.slab ? next : L.slab;
     }
-    hipLaunchKernelGGL(k_gt_gap, dim3(Q), dim3(64), 0, st, q, Q, D, cs, cnt, k, kk, status);
+    hipLaunchKernelGGL(k_gt_gap, dim3(Q), dim3(64), 0, st, q, Q, D, cs, cnt, k, kk, single ? kApproxEps1 : kApproxEps, status);
     const int tiles = (kk + 15) / 16;
     const int64_t waves = (int64_t)Q * tiles;
     if (f16)
@@ -941,15 +946,15 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
 }
 
 extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
-                                    int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    return cosine_topk_gemm_impl(q, Q, idx, 0, N, D, row_scale, k, row_id_base, out_score, out_index, status, workspace,
-                                 workspace_bytes, stream);
+                                    int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
+                                    int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    return cosine_topk_gemm_impl(q, Q, idx, 0, products, N, D, row_scale, k, row_id_base, out_score, out_index, status,
+                                 workspace, workspace_bytes, stream);
 }
 
 extern "C" int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D, const float* row_scale,
-                                        int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
-    return cosine_topk_gemm_impl(q, Q, idx_f16, 1, N, D, row_scale, k, row_id_base, out_score, out_index, status, workspace,
-                                 workspace_bytes, stream);
+                                        int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
+                                        int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    return cosine_topk_gemm_impl(q, Q, idx_f16, 1, products, N, D, row_scale, k, row_id_base, out_score, out_index, status,
+                                 workspace, workspace_bytes, stream);
 }

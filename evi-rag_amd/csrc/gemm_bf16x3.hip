@@ -54,12 +54,16 @@ __global__ void k_split_weight(const float* __restrict__ W, int N, int K, int64_
 // (thirty-two 16x16 accumulators) — same LDS image, same number of fragment reads and MFMA cycles per
 // k-tile; the chip holds a higher clock on the 16x16 shape (MI355X_MICROARCH.md, DVFS item 7).
 // AH = 1: A is stored as f16 (lda in halves) — an f16 value is exactly hi + lo in bf16, so nothing is lost.
-template <int ACT, int MF, int AH = 0>
+// P1 = 1: single product hi * hi (plain bf16 GEMM: relative error 2^-8 instead of 2^-16) — only for the candidate
+// selection of the many-query top-k, whose results are re-scored exactly; the lo planes are neither loaded,
+// staged nor multiplied.
+template <int ACT, int MF, int AH = 0, int P1 = 0>
 __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
     int64_t ldc, GemmFilter flt) {
-    __shared__ uint4 sAhi[2][XM * 4], sAlo[2][XM * 4], sWhi[2][XN * 4], sWlo[2][XN * 4];  // 2 stages x 4 x 16 KiB
+    __shared__ uint4 sAhi[2][XM * 4], sWhi[2][XN * 4];                                     // 2 stages x 16 KiB each
+    __shared__ uint4 sAlo[P1 ? 1 : 2][P1 ? 1 : XM * 4], sWlo[P1 ? 1 : 2][P1 ? 1 : XN * 4];  // lo planes (absent when P1)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const bool ok = wr < N && k < Kp;
         const int64_t off = ok ? (int64_t)wr * Kp + k : 0;
         rwh[i] = *reinterpret_cast<const u32x4*>(Whi + off);
-        rwl[i] = *reinterpret_cast<const u32x4*>(Wlo + off);
+        if (!P1) rwl[i] = *reinterpret_cast<const u32x4*>(Wlo + off);
     };
     // k0 = first k of the tile the registers hold: the range check of the load is repeated here, so the
     // select sits next to the conversion and not behind the load (where it would stall on the load's latency)
@@ -118,9 +122,11 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         }
         // 8-byte halves of the 16-byte chunk c = c4 >> 1
         uint2* dh = reinterpret_cast<uint2*>(&sAhi[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
-        uint2* dl = reinterpret_cast<uint2*>(&sAlo[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
         *dh = *reinterpret_cast<uint2*>(&h);
-        *dl = *reinterpret_cast<uint2*>(&l);
+        if (!P1) {
+            uint2* dl = reinterpret_cast<uint2*>(&sAlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c4 >> 1)]) + (c4 & 1);
+            *dl = *reinterpret_cast<uint2*>(&l);
+        }
     };
     // f16-stored A: 1024 chunks of 8 halves (16 B), 4 per row
     auto load_a16 = [&](int i, int k0) {
@@ -145,14 +151,14 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             l[e] = (__bf16)(f - (float)h[e]);
         }
         *reinterpret_cast<bf16x8*>(&sAhi[buf][slot3(r, c)]) = h;
-        *reinterpret_cast<bf16x8*>(&sAlo[buf][slot3(r, c)]) = l;
+        if (!P1) *reinterpret_cast<bf16x8*>(&sAlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = l;
     };
     auto store_w = [&](int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
         const bool ok = n0 + r < N && k0 + c * 8 < Kp;
         *reinterpret_cast<u32x4*>(&sWhi[buf][slot3(r, c)]) = ok ? rwh[i] : zero16;
-        *reinterpret_cast<u32x4*>(&sWlo[buf][slot3(r, c)]) = ok ? rwl[i] : zero16;
+        if (!P1) *reinterpret_cast<u32x4*>(&sWlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = ok ? rwl[i] : zero16;
     };
 
     f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];   // MF = 0
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             const int c = MF ? q16 : ((g >> 2) << 1) + fh;  // MF = 0: chunk holding k = 16 (g >> 2) + 8 h .. + 7
             const int row = MF ? wm * 128 + g * 16 + r16 : wm * 128 + (g & 3) * 32 + fr;
             fah[g & 1] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
-            fal[g & 1] = *reinterpret_cast<const bf16x8*>(&sAlo[cur][slot3(row, c)]);
+            if (!P1) fal[g & 1] = *reinterpret_cast<const bf16x8*>(&sAlo[P1 ? 0 : cur][P1 ? 0 : slot3(row, c)]);
         };
         auto read_b = [&](int ks) {
             const int c = MF ? q16 : (ks << 1) + fh;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             for (int j = 0; j < (MF ? 4 : 2); ++j) {
                 const int row = MF ? wn * 64 + j * 16 + r16 : wn * 64 + j * 32 + fr;
                 fbh[ks][j] = *reinterpret_cast<const bf16x8*>(&sWhi[cur][slot3(row, c)]);
-                fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sWlo[cur][slot3(row, c)]);
+                if (!P1) fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sWlo[P1 ? 0 : cur][P1 ? 0 : slot3(row, c)]);
             }
         };
         read_b(0);
@@ -236,8 +242,8 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4& c = acc16[MF ? g : 0][MF ? j : 0];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[g & 1], fbh[0][MF ? j : 0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g & 1], fbl[0][MF ? j : 0], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[g & 1], fbh[0][MF ? j : 0], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g & 1], fbl[0][MF ? j : 0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g & 1], fbh[0][MF ? j : 0], c, 0, 0, 0);
                 }
             } else {
@@ -245,8 +251,8 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16& c = acc[MF ? 0 : i][MF ? 0 : j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g & 1], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbl[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g & 1], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbl[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
                 }
             }
@@ -363,8 +369,8 @@ int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit,
     return EVI_OK;
 }
 
-int launch_gemm_bf16x3_f16a(const void* A16, int64_t M, int K, int64_t lda, const void* wsplit, int N, float* C, int64_t ldc,
-                            hipStream_t st) {
+int launch_gemm_bf16_presplit(const void* A, int a_f16, int single, int64_t M, int K, int64_t lda, const void* wsplit, int N,
+                              float* C, int64_t ldc, hipStream_t st) {
     if (M == 0 || N == 0) return EVI_OK;
     const int Kp = (K + XK - 1) / XK * XK;
     const __bf16* hi = static_cast<const __bf16*>(wsplit);
@@ -372,14 +378,20 @@ int launch_gemm_bf16x3_f16a(const void* A16, int64_t M, int K, int64_t lda, cons
     const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
     const GemmFilter flt{};
     const int tok = timing_begin(kTimeGemm, st);
-    hipLaunchKernelGGL((k_gemm_nt_bf16x3<0, 0, 1>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A16), M, K, lda, hi, lo,
-                       N, Kp, static_cast<const float*>(nullptr), C, ldc, flt);
+#define EVI_LAUNCH_PS(AHV, P1V)                                                                                          \
+    hipLaunchKernelGGL((k_gemm_nt_bf16x3<0, 0, AHV, P1V>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A), M, K, lda, \
+                       hi, lo, N, Kp, static_cast<const float*>(nullptr), C, ldc, flt)
+    if (a_f16 && single) EVI_LAUNCH_PS(1, 1);
+    else if (a_f16) EVI_LAUNCH_PS(1, 0);
+    else if (single) EVI_LAUNCH_PS(0, 1);
+    else EVI_LAUNCH_PS(0, 0);
+#undef EVI_LAUNCH_PS
     timing_end(tok, st);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
 
-int launch_gemm_bf16x3_filter(const void* A, int a_f16, int64_t M, int K, int64_t lda, const void* wsplit, int N,
+int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, int K, int64_t lda, const void* wsplit, int N,
                               const GemmFilter& flt, hipStream_t st) {
     if (M == 0 || N == 0) return EVI_OK;
     const int Kp = (K + XK - 1) / XK * XK;
@@ -387,12 +399,14 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int64_t M, int K, int64_
     const __bf16* lo = reinterpret_cast<const __bf16*>(static_cast<const char*>(wsplit) + align_up((size_t)N * Kp * 2, 256));
     const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
     const int tok = timing_begin(kTimeGemm, st);
-    if (a_f16)
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<3, 0, 1>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A), M, K, lda, hi,
-                           lo, N, Kp, static_cast<const float*>(nullptr), static_cast<float*>(nullptr), (int64_t)0, flt);
-    else
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<3, 0, 0>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A), M, K, lda, hi,
-                           lo, N, Kp, static_cast<const float*>(nullptr), static_cast<float*>(nullptr), (int64_t)0, flt);
+#define EVI_LAUNCH_FL(AHV, P1V)                                                                                          \
+    hipLaunchKernelGGL((k_gemm_nt_bf16x3<3, 0, AHV, P1V>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A), M, K, lda, \
+                       hi, lo, N, Kp, static_cast<const float*>(nullptr), static_cast<float*>(nullptr), (int64_t)0, flt)
+    if (a_f16 && single) EVI_LAUNCH_FL(1, 1);
+    else if (a_f16) EVI_LAUNCH_FL(1, 0);
+    else if (single) EVI_LAUNCH_FL(0, 1);
+    else EVI_LAUNCH_FL(0, 0);
+#undef EVI_LAUNCH_FL
     timing_end(tok, st);
     EVI_LAUNCH_CHECK();
     return EVI_OK;

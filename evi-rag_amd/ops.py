@@ -207,11 +207,15 @@ def cosine_topk(
 
 def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_scale: Optional[torch.Tensor] = None,
                      row_id_base: int = 0, fallback: bool = True,
-                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                     products: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cosine_topk for many queries at once (see evi_cosine_topk_gemm): one split-bf16 GEMM pass over the index
     selects candidates, the scan's arithmetic re-scores them; the result equals cosine_topk bit for bit.  Reads the
     proof flag back (one synchronisation); when the proof fails (heavy score ties, adversarial row order) the scan
-    runs instead (fallback=True) or RuntimeError is raised."""
+    runs instead (fallback=True) or RuntimeError is raised.  products: 3 (split-bf16 selection), 1 (plain bf16 selection:
+    three times fewer MFMAs, proof fails earlier) or None = try 1 when k <= 1024, then 3, then the scan."""
+    if products not in (None, 1, 3):
+        raise ValueError(f"products must be None, 1 or 3, got {products}")
     dev = _require_gpu(queries, index, row_scale)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
@@ -239,9 +243,14 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     status = torch.empty(1, dtype=torch.int32, device=dev)
     fn = lib.evi_cosine_topk_gemm_f16 if x.dtype == torch.float16 else lib.evi_cosine_topk_gemm
-    _lib.check(fn(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), _ptr(out_score), _ptr(out_index),
-                  status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
-    st = int(status.item())
+    plan = [products] if products is not None else ([1, 3] if k <= 1024 else [3])
+    st = -1
+    for prod in plan:
+        _lib.check(fn(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), int(prod), _ptr(out_score),
+                      _ptr(out_index), status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+        st = int(status.item())
+        if st == 0:
+            break
     if st != 0:
         if not fallback:
             raise RuntimeError(f"evi_cosine_topk_gemm could not prove exactness (status {st}): run cosine_topk")

@@ -139,16 +139,19 @@ int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, int64_t N, i
  * those.  *status (device int32) is written 0 when the result is proven exact; non-zero (1: the k-th and the
  * last kept approximate scores are closer than twice the GEMM's error bound — heavy ties; 2: a candidate
  * list overflowed — adversarial row order) means the outputs must be discarded and evi_cosine_topk run
- * instead.  One pass over the index instead of ceil(Q / 32).  */
+ * instead.  One pass over the index instead of ceil(Q / 32).
+ * products = 3: split-bf16 selection scores (error 2.5e-4 |q|, reserve max(256, k/2), k <= 1365);
+ * products = 1: plain bf16 selection scores, three times fewer MFMAs (error 4.2e-3 |q|, reserve max(1024, k),
+ *               k <= 1024) — the proof fails earlier on large or clustered indexes; try 1, then 3, then the scan. */
 size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, int k);
 int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
-                         int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
+                         int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 /* The same over an f16-stored index (D % 32 == 0): bit-identical to evi_cosine_topk_f16.  An f16 value is exactly
  * hi + lo in bf16, so the selection GEMM loses nothing on the index side. */
 int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D, const float* row_scale,
-                             int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
+                             int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.

@@ -364,9 +364,10 @@ def test_cosine_topk_gemm_equals_scan_bit_for_bit(dev, Q, N, D, k, scaled):
     else:
         idx, scale = ops.normalize_embeddings(xd, EPS), None
     s0, i0 = ops.cosine_topk(qn, idx, k, row_scale=scale, row_id_base=11)
-    s1, i1 = ops.cosine_topk_gemm(qn, idx, k, row_scale=scale, row_id_base=11, fallback=False)
-    assert torch.equal(i1, i0)
-    assert torch.equal(s1, s0)
+    for products in (3, 1, None):  # split-bf16 selection, plain-bf16 selection, the automatic plan
+        s1, i1 = ops.cosine_topk_gemm(qn, idx, k, row_scale=scale, row_id_base=11, fallback=False, products=products)
+        assert torch.equal(i1, i0), products
+        assert torch.equal(s1, s0), products
 
 
 def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):
@@ -389,6 +390,8 @@ def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):
     assert torch.equal(ia, ib) and torch.equal(sa, sb)
     with pytest.raises(NotImplementedError):
         ops.cosine_topk_gemm(qn, idx, 1500)  # k + reserve exceeds the selector's capacity
+    with pytest.raises(NotImplementedError):
+        ops.cosine_topk_gemm(qn, idx, 1100, products=1)  # the coarse selection needs k + 1100 > 2048 slots
 
 
 @pytest.mark.parametrize("Q,N,D,k", [(256, 300000, 768, 500), (100, 20000, 64, 40)])
@@ -401,7 +404,8 @@ def test_cosine_topk_gemm_f16_index_equals_f16_scan(dev, Q, N, D, k):
     x16 = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS).to(torch.float16)
     qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
     s0, i0 = ops.cosine_topk(qn, x16, k, row_id_base=3)
-    s1, i1 = ops.cosine_topk_gemm(qn, x16, k, row_id_base=3, fallback=False)
-    assert torch.equal(i1, i0) and torch.equal(s1, s0)
+    for products in (3, 1):
+        s1, i1 = ops.cosine_topk_gemm(qn, x16, k, row_id_base=3, fallback=False, products=products)
+        assert torch.equal(i1, i0) and torch.equal(s1, s0), products
     s2, i2 = ops.cosine_topk(qn, x16, k, row_id_base=3, method="auto")
     assert torch.equal(i2, i0) and torch.equal(s2, s0)

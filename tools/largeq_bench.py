@@ -34,12 +34,14 @@ def main():
         return (time.perf_counter() - t0) / iters, out
 
     t_scan, (s0, i0) = timed(lambda: ops.cosine_topk(q, x, k))
-    t_gemm, (s1, i1) = timed(lambda: ops.cosine_topk_gemm(q, x, k, fallback=False))
-    same = bool(torch.equal(i0, i1) and torch.equal(s0, s1))
+    t_gemm, (s1, i1) = timed(lambda: ops.cosine_topk_gemm(q, x, k, fallback=False, products=3))
+    t_g1, (s2, i2) = timed(lambda: ops.cosine_topk_gemm(q, x, k, fallback=False, products=1))
+    same = bool(torch.equal(i0, i1) and torch.equal(s0, s1) and torch.equal(i0, i2) and torch.equal(s0, s2))
     flops = 2.0 * N * Q * D
     print(f"N={N} Q={Q} k={k} D={D}: scan {t_scan * 1e3:.1f} ms ({Q / t_scan:.0f} q/s, {flops / t_scan / 1e12:.0f} TF/s f32-MFMA), "
           f"gemm {t_gemm * 1e3:.1f} ms ({Q / t_gemm:.0f} q/s, {flops / t_gemm / 1e12:.0f} TF/s algorithmic), "
-          f"speedup {t_scan / t_gemm:.2f}x, identical results: {same}", flush=True)
+          f"speedup {t_scan / t_gemm:.2f}x; plain-bf16 selection {t_g1 * 1e3:.1f} ms ({Q / t_g1:.0f} q/s), speedup {t_scan / t_g1:.2f}x; "
+          f"identical results: {same}", flush=True)
 
 
 if __name__ == "__main__":
