@@ -504,9 +504,11 @@ def main():
             # the many-query path did the work: the dominant kernel is the split-bf16 GEMM (MFMA-bound), priced by the
             # flops it executes (3 bf16 products per f32 product) against the dense bf16 peak
             gemm_ms = ms[2] / steps
-            executed = 3.0 * 2.0 * Q * shard_rows * D / (gemm_ms * 1e-3) / 1e12
+            products = ops.cosine_topk_gemm.last_products or 3  # 1: plain bf16 selection, 3: split-bf16
+            executed = products * 2.0 * Q * shard_rows * D / (gemm_ms * 1e-3) / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s", "frac": executed / 2500.0,
-                                  "traffic": None, "kernel": "k_gemm_nt_bf16x3 (threshold-filter epilogue)",
+                                  "traffic": None, "products_per_f32_product": products,
+                                  "kernel": "k_gemm_nt_bf16x3 (threshold-filter epilogue)",
                                   "algorithmic_flops_per_step": 2.0 * Q * shard_rows * D, "launches_per_step": launches[2] / steps,
                                   "kernel_ms_per_step": gemm_ms, "select_ms_per_step": ms[1] / steps}
         if world == 1 and not args.no_cpu_baseline:

@@ -250,12 +250,17 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
                       _ptr(out_index), status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
         st = int(status.item())
         if st == 0:
+            cosine_topk_gemm.last_products = prod  # which selection precision proved the result (introspection / bench)
             break
     if st != 0:
+        cosine_topk_gemm.last_products = 0  # the scan produced the result
         if not fallback:
             raise RuntimeError(f"evi_cosine_topk_gemm could not prove exactness (status {st}): run cosine_topk")
         return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
     return out_score, out_index
+
+
+cosine_topk_gemm.last_products = None
 
 
 def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
