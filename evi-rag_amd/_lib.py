@@ -82,7 +82,8 @@ _SIGNATURES = {
     "evi_metric_accumulate": (c_int, [_P] * 9 + [c_int, c_int, _P, _P]),
     "evi_row_norms": (c_int, [_P, c_int64, c_int, _P, _P]),
     "evi_cosine_topk_gemm_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
-    "evi_cosine_topk_gemm": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "evi_cosine_topk_gemm": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "evi_index_shadow_bf16": (c_int, [_P, c_int64, c_int, _P, _P]),
     "evi_cosine_topk_gemm_f16": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "evi_topk_merge": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "evi_topk_packed_bytes": (c_size_t, [c_int, c_int]),

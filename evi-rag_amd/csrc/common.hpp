@@ -65,7 +65,8 @@ struct GemmFilter {
 };
 // W [N, K] -> bf16 hi / lo planes in wsplit (once); then C = A W^T with the planes, or the filter epilogue.
 int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st);
-// a_f16: A stored as f16; single: one product (hi * hi, plain bf16 accuracy) instead of three
+// a_f16: 0 = A is f32, 1 = A stored as f16, 2 = A is a bf16 copy (implies single);
+// single: one product (hi * hi, plain bf16 accuracy) instead of three
 int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, int K, int64_t lda, const void* wsplit, int N,
                               const GemmFilter& flt, hipStream_t st);
 // C = A W^T with W already split (plain store epilogue)

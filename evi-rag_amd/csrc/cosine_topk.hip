@@ -869,12 +869,35 @@ extern "C" size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, 
     return gt_layout(Q, N, D, k).total;
 }
 
-static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16, int products, int64_t N, int D,
-                                 const float* row_scale, int k, int64_t row_id_base, float* out_score, int64_t* out_index,
-                                 int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+__global__ void k_shadow_bf16(const float* __restrict__ x, int64_t n, __bf16* __restrict__ out) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        bf16x4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4v*>(out + i) = o;
+    }
+}
+
+extern "C" int evi_index_shadow_bf16(const float* idx, int64_t N, int D, void* out_bf16, void* stream) {
+    EVI_REQUIRE(N >= 0 && D >= 1, "evi_index_shadow_bf16: need N >= 0 and D >= 1");
+    if (D % 4 != 0) return fail(EVI_ERR_UNSUPPORTED, "evi_index_shadow_bf16: D must be a multiple of 4, got %d", D);
+    if (N == 0) return EVI_OK;
+    EVI_REQUIRE(idx && out_bf16, "evi_index_shadow_bf16: null pointer");
+    hipLaunchKernelGGL(k_shadow_bf16, dim3(4096), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), idx, N * D,
+                       static_cast<__bf16*>(out_bf16));
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16, int products, const void* shadow, int64_t N,
+                                 int D, const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                                 int64_t* out_index, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     EVI_REQUIRE(products == 1 || products == 3, "evi_cosine_topk_gemm: products must be 3 (split-bf16) or 1 (plain bf16), got %d",
                 products);
     const int single = products == 1;
+    EVI_REQUIRE(!shadow || (single && !f16), "evi_cosine_topk_gemm: a bf16 shadow goes with an f32 index and products = 1");
     EVI_REQUIRE(Q >= 1 && N >= 1 && D >= 1, "evi_cosine_topk_gemm: need Q >= 1, N >= 1, D >= 1, got Q=%d N=%lld D=%d", Q,
                 (long long)N, D);
     EVI_REQUIRE(k >= 1, "evi_cosine_topk_gemm: k must be >= 1, got %d", k);
@@ -897,8 +920,10 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
     int32_t* ci = reinterpret_cast<int32_t*>(base + L.ci);
     float* exact = reinterpret_cast<float*>(base + L.exact);
     float* scores = reinterpret_cast<float*>(base + L.scores);
-    const char* rows_base = static_cast<const char*>(idx);
-    const size_t row_bytes = (size_t)D * (f16 ? 2 : 4);
+    // selection operand: the index itself, or its bf16 shadow (same arithmetic as products = 1, no conversion work)
+    const int a_kind = shadow ? 2 : f16;
+    const char* rows_base = static_cast<const char*>(shadow ? shadow : idx);
+    const size_t row_bytes = (size_t)D * (a_kind ? 2 : 4);
     hipLaunchKernelGGL(k_gt_init, dim3((Q + 255) / 256), dim3(256), 0, st, tau, cnt, Q, status);
     EVI_LAUNCH_CHECK();
     int rc = split_weight_bf16x3(q, Q, D, D, base + L.wsplit, st);  // the queries are the "weights": split once
@@ -909,7 +934,7 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
         const void* slab = rows_base + begin * row_bytes;
         if (begin == 0) {
             // first slab: every score passes (tau = -inf), so form the scores and append them with plain stores
-            rc = launch_gemm_bf16_presplit(slab, f16, single, rows, D, D, base + L.wsplit, Q, scores, Q, st);
+            rc = launch_gemm_bf16_presplit(slab, a_kind, single, rows, D, D, base + L.wsplit, Q, scores, Q, st);
             if (rc != EVI_OK) return rc;
             int64_t blocks = (rows * Q + 255) / 256;
             if (blocks > 8192) blocks = 8192;
@@ -919,7 +944,7 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
             // later slabs: scores ~ idx[begin + r] . q[i] never leave the registers of the GEMM — its epilogue
             // compares them with tau and appends the few survivors
             const GemmFilter flt{tau, row_scale, begin, cs, ci, cnt, status, kGemmTopkCap, kCntStride};
-            rc = launch_gemm_bf16x3_filter(slab, f16, single, rows, D, D, base + L.wsplit, Q, flt, st);
+            rc = launch_gemm_bf16x3_filter(slab, a_kind, single, rows, D, D, base + L.wsplit, Q, flt, st);
             if (rc != EVI_OK) return rc;
         }
         hipLaunchKernelGGL(k_gt_clamp, dim3((Q + 255) / 256), dim3(256), 0, st, cnt, Q);
@@ -946,15 +971,16 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
 }
 
 extern "C" int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
-                                    int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
-                                    int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
-    return cosine_topk_gemm_impl(q, Q, idx, 0, products, N, D, row_scale, k, row_id_base, out_score, out_index, status,
-                                 workspace, workspace_bytes, stream);
+                                    int k, int64_t row_id_base, int products, const void* shadow_bf16, float* out_score,
+                                    int64_t* out_index, int32_t* status, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    return cosine_topk_gemm_impl(q, Q, idx, 0, products, shadow_bf16, N, D, row_scale, k, row_id_base, out_score, out_index,
+                                 status, workspace, workspace_bytes, stream);
 }
 
 extern "C" int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D, const float* row_scale,
                                         int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
                                         int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
-    return cosine_topk_gemm_impl(q, Q, idx_f16, 1, products, N, D, row_scale, k, row_id_base, out_score, out_index, status,
-                                 workspace, workspace_bytes, stream);
+    return cosine_topk_gemm_impl(q, Q, idx_f16, 1, products, nullptr, N, D, row_scale, k, row_id_base, out_score, out_index,
+                                 status, workspace, workspace_bytes, stream);
 }

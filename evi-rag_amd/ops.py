@@ -205,10 +205,23 @@ def cosine_topk(
     return out_score, out_index
 
 
+def index_shadow_bf16(index: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of an f32 index (+ 50 % memory) for cosine_topk_gemm(shadow=...): the plain-bf16 candidate selection
+    then streams half the bytes and converts nothing.  Same results as without it."""
+    dev = _require_gpu(index)
+    x = _f32c(index, "index")
+    if x.dim() != 2:
+        raise ValueError("index must be 2D")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
+    if x.numel():
+        _lib.check(_lib.load().evi_index_shadow_bf16(_ptr(x), x.size(0), x.size(1), _ptr(out), _stream(dev)))
+    return out
+
+
 def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_scale: Optional[torch.Tensor] = None,
                      row_id_base: int = 0, fallback: bool = True,
                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                     products: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     products: Optional[int] = None, shadow: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cosine_topk for many queries at once (see evi_cosine_topk_gemm): one split-bf16 GEMM pass over the index
     selects candidates, the scan's arithmetic re-scores them; the result equals cosine_topk bit for bit.  Reads the
     proof flag back (one synchronisation); when the proof fails (heavy score ties, adversarial row order) the scan
@@ -216,6 +229,9 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
     three times fewer MFMAs, proof fails earlier) or None = try 1 when k <= 1024, then 3, then the scan."""
     if products not in (None, 1, 3):
         raise ValueError(f"products must be None, 1 or 3, got {products}")
+    if shadow is not None:
+        if index.dtype != torch.float32 or shadow.dtype != torch.bfloat16 or shadow.shape != index.shape or not shadow.is_contiguous():
+            raise ValueError("shadow must be the contiguous bfloat16 copy of an f32 index (index_shadow_bf16)")
     dev = _require_gpu(queries, index, row_scale)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
@@ -246,7 +262,11 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
     plan = [products] if products is not None else ([1, 3] if k <= 1024 else [3])
     st = -1
     for prod in plan:
-        _lib.check(fn(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), int(prod), _ptr(out_score),
+        if x.dtype == torch.float16:
+            args = (int(prod),)
+        else:
+            args = (int(prod), _ptr(shadow) if (shadow is not None and prod == 1) else None)
+        _lib.check(fn(_ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base), *args, _ptr(out_score),
                       _ptr(out_index), status.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
         st = int(status.item())
         if st == 0:

@@ -142,11 +142,15 @@ int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, int64_t N, i
  * instead.  One pass over the index instead of ceil(Q / 32).
  * products = 3: split-bf16 selection scores (error 2.5e-4 |q|, reserve max(256, k/2), k <= 1365);
  * products = 1: plain bf16 selection scores, three times fewer MFMAs (error 4.2e-3 |q|, reserve max(1024, k),
- *               k <= 1024) — the proof fails earlier on large or clustered indexes; try 1, then 3, then the scan. */
+ *               k <= 1024) — the proof fails earlier on large or clustered indexes; try 1, then 3, then the scan.
+ * shadow_bf16 (nullable, products = 1 only): a bf16 copy of the f32 index made once by evi_index_shadow_bf16
+ * (+ 50 % memory).  The selection GEMM then streams half the bytes and converts nothing; the arithmetic - and
+ * so the result and the proof - is that of products = 1. */
 size_t evi_cosine_topk_gemm_workspace_bytes(int Q, int64_t N, int D, int k);
+int evi_index_shadow_bf16(const float* idx, int64_t N, int D, void* out_bf16, void* stream);
 int evi_cosine_topk_gemm(const float* q, int Q, const float* idx, int64_t N, int D, const float* row_scale,
-                         int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
-                         int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+                         int k, int64_t row_id_base, int products, const void* shadow_bf16, float* out_score,
+                         int64_t* out_index, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 /* The same over an f16-stored index (D % 32 == 0): bit-identical to evi_cosine_topk_f16.  An f16 value is exactly
  * hi + lo in bf16, so the selection GEMM loses nothing on the index side. */
 int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t N, int D, const float* row_scale,

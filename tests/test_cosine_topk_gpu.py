@@ -368,6 +368,10 @@ def test_cosine_topk_gemm_equals_scan_bit_for_bit(dev, Q, N, D, k, scaled):
         s1, i1 = ops.cosine_topk_gemm(qn, idx, k, row_scale=scale, row_id_base=11, fallback=False, products=products)
         assert torch.equal(i1, i0), products
         assert torch.equal(s1, s0), products
+    shadow = ops.index_shadow_bf16(idx)  # bf16 copy of the rows: same selection arithmetic, no conversion in the GEMM
+    assert torch.equal(shadow, idx.to(torch.bfloat16))
+    s1, i1 = ops.cosine_topk_gemm(qn, idx, k, row_scale=scale, row_id_base=11, fallback=False, products=1, shadow=shadow)
+    assert torch.equal(i1, i0) and torch.equal(s1, s0)
 
 
 def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):

@@ -36,11 +36,15 @@ def main():
     t_scan, (s0, i0) = timed(lambda: ops.cosine_topk(q, x, k))
     t_gemm, (s1, i1) = timed(lambda: ops.cosine_topk_gemm(q, x, k, fallback=False, products=3))
     t_g1, (s2, i2) = timed(lambda: ops.cosine_topk_gemm(q, x, k, fallback=False, products=1))
-    same = bool(torch.equal(i0, i1) and torch.equal(s0, s1) and torch.equal(i0, i2) and torch.equal(s0, s2))
+    shadow = ops.index_shadow_bf16(x)
+    t_sh, (s3, i3) = timed(lambda: ops.cosine_topk_gemm(q, x, k, fallback=False, products=1, shadow=shadow))
+    same = bool(torch.equal(i0, i1) and torch.equal(s0, s1) and torch.equal(i0, i2) and torch.equal(s0, s2)
+                and torch.equal(i0, i3) and torch.equal(s0, s3))
     flops = 2.0 * N * Q * D
     print(f"N={N} Q={Q} k={k} D={D}: scan {t_scan * 1e3:.1f} ms ({Q / t_scan:.0f} q/s, {flops / t_scan / 1e12:.0f} TF/s f32-MFMA), "
           f"gemm {t_gemm * 1e3:.1f} ms ({Q / t_gemm:.0f} q/s, {flops / t_gemm / 1e12:.0f} TF/s algorithmic), "
           f"speedup {t_scan / t_gemm:.2f}x; plain-bf16 selection {t_g1 * 1e3:.1f} ms ({Q / t_g1:.0f} q/s), speedup {t_scan / t_g1:.2f}x; "
+          f"with a bf16 shadow index {t_sh * 1e3:.1f} ms ({Q / t_sh:.0f} q/s), speedup {t_scan / t_sh:.2f}x; "
           f"identical results: {same}", flush=True)
 
 
