@@ -79,9 +79,13 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const int64_t m0 = (int64_t)(tile / nblocks_n) * XM;
     const int n0 = (int)(tile % nblocks_n) * XN;
 
-    f32x4 ra[4];
-    u32x4 ra16[2];  // AH = 1: two chunks of 8 halves per thread
-    u32x4 rwh[2], rwl[2];
+    // Staging registers.  NS sets: a tile is loaded NS iterations before it is written to LDS.  One set when all three
+    // products are multiplied (the register file is full); two with P1, whose k-tile takes a third of the MFMA time —
+    // with one set its loop ran at the latency of a global load per k-tile, not at the speed of its MFMAs.
+    constexpr int NS = P1 ? 2 : 1;
+    f32x4 ra[NS][4];
+    u32x4 ra16[NS][2];  // AH != 0: two chunks of 8 halves per thread
+    u32x4 rwh[NS][2], rwl[NS][2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const u32x4 zero16 = {0u, 0u, 0u, 0u};
     // The staging work of one k-tile is cut into six pieces (four A pieces of 512 float4 chunks, two W
@@ -91,31 +95,31 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     // Loads are branch-free (an out-of-range chunk reads the array's first 16 bytes and is zeroed by a
     // select), so the whole k-loop body is straight-line code and the compiler can count exactly which
     // outstanding loads each staging piece has to wait for.
-    auto load_a = [&](int i, int k0) {  // A: 2048 float4 chunks, 8 per row (128 B contiguous)
+    auto load_a = [&](int set, int i, int k0) {  // A: 2048 float4 chunks, 8 per row (128 B contiguous)
         const int s = tid + kXThreads * i;
         const int r = s >> 3, c4 = s & 7;
         const int k = k0 + c4 * 4;
         const int64_t am = m0 + r;
         const bool ok = am < M && k < K;
-        ra[i] = *reinterpret_cast<const f32x4*>(A + (ok ? am * lda + k : 0));  // zeroed where it is consumed (store_a)
+        ra[set][i] = *reinterpret_cast<const f32x4*>(A + (ok ? am * lda + k : 0));  // zeroed where it is consumed (store_a)
     };
-    auto load_w = [&](int i, int k0) {  // W planes: 1024 16-byte chunks each, 4 per row
+    auto load_w = [&](int set, int i, int k0) {  // W planes: 1024 16-byte chunks each, 4 per row
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
         const int wr = n0 + r;
         const int k = k0 + c * 8;
         const bool ok = wr < N && k < Kp;
         const int64_t off = ok ? (int64_t)wr * Kp + k : 0;
-        rwh[i] = *reinterpret_cast<const u32x4*>(Whi + off);
-        if (!P1) rwl[i] = *reinterpret_cast<const u32x4*>(Wlo + off);
+        rwh[set][i] = *reinterpret_cast<const u32x4*>(Whi + off);
+        if (!P1) rwl[set][i] = *reinterpret_cast<const u32x4*>(Wlo + off);
     };
     // k0 = first k of the tile the registers hold: the range check of the load is repeated here, so the
     // select sits next to the conversion and not behind the load (where it would stall on the load's latency)
-    auto store_a = [&](int i, int buf, int k0) {
+    auto store_a = [&](int set, int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 3, c4 = s & 7;
         const bool ok = m0 + r < M && k0 + c4 * 4 < K;
-        const f32x4 v = ok ? ra[i] : zero4;
+        const f32x4 v = ok ? ra[set][i] : zero4;
         bf16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -131,24 +135,24 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         }
     };
     // f16-stored A: 1024 chunks of 8 halves (16 B), 4 per row
-    auto load_a16 = [&](int i, int k0) {
+    auto load_a16 = [&](int set, int i, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
         const int k = k0 + c * 8;
         const int64_t am = m0 + r;
         const bool ok = am < M && k < K;
-        ra16[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(A) + (ok ? am * lda + k : 0));
+        ra16[set][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(A) + (ok ? am * lda + k : 0));
     };
-    auto store_a16 = [&](int i, int buf, int k0) {
+    auto store_a16 = [&](int set, int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
         const bool ok = m0 + r < M && k0 + c * 8 < K;
         if (AH == 2) {  // already bf16: straight to the hi plane
-            *reinterpret_cast<u32x4*>(&sAhi[buf][slot3(r, c)]) = ok ? ra16[i] : zero16;
+            *reinterpret_cast<u32x4*>(&sAhi[buf][slot3(r, c)]) = ok ? ra16[set][i] : zero16;
             return;
         }
         typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-        const f16x8v v = __builtin_bit_cast(f16x8v, ok ? ra16[i] : zero16);
+        const f16x8v v = __builtin_bit_cast(f16x8v, ok ? ra16[set][i] : zero16);
         bf16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -159,12 +163,12 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         *reinterpret_cast<bf16x8*>(&sAhi[buf][slot3(r, c)]) = h;
         if (!P1) *reinterpret_cast<bf16x8*>(&sAlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = l;
     };
-    auto store_w = [&](int i, int buf, int k0) {
+    auto store_w = [&](int set, int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
         const bool ok = n0 + r < N && k0 + c * 8 < Kp;
-        *reinterpret_cast<u32x4*>(&sWhi[buf][slot3(r, c)]) = ok ? rwh[i] : zero16;
-        if (!P1) *reinterpret_cast<u32x4*>(&sWlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = ok ? rwl[i] : zero16;
+        *reinterpret_cast<u32x4*>(&sWhi[buf][slot3(r, c)]) = ok ? rwh[set][i] : zero16;
+        if (!P1) *reinterpret_cast<u32x4*>(&sWlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = ok ? rwl[set][i] : zero16;
     };
 
     f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];   // MF = 0
@@ -188,36 +192,39 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     // Two LDS stages: stage `cur` is multiplied while the next tile (already in registers) is split and
     // written to the other stage piece by piece and the tile after it is fetched into the freed
     // registers; one barrier per k-tile.
+    auto load_tile = [&](int set, int k0) {
+        if (AH) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) load_a16(set, i, k0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_a(set, i, k0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) load_w(set, i, k0);
+    };
+    load_tile(0, 0);
     if (AH) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) load_a16(i, 0);
+        for (int i = 0; i < 2; ++i) store_a16(0, i, 0, 0);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_a(i, 0);
+        for (int i = 0; i < 4; ++i) store_a(0, i, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) load_w(i, 0);
-    if (AH) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) store_a16(i, 0, 0);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) store_a(i, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) store_w(i, 0, 0);
+    for (int i = 0; i < 2; ++i) store_w(0, i, 0, 0);
     __syncthreads();
-    if (AH) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) load_a16(i, XK);
-    } else {
+    for (int t = 1; t <= NS; ++t) load_tile(t % NS, t * XK);  // tiles 1 .. NS are in flight when the loop starts
+    // NS == 2: two k-tiles per trip so that the staging set and the LDS stage of each are compile-time constants.  A
+    // trip may run one tile past the end: that tile was staged as zeros and adds nothing.
+    int cur_rt = 0;
+    for (int kbase = 0; kbase < K; kbase += XK * NS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_a(i, XK);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) load_w(i, XK);
-    int cur = 0;
-    for (int k0 = 0; k0 < K; k0 += XK, cur ^= 1) {
+      for (int u = 0; u < NS; ++u) {
+        const int k0 = kbase + u * XK;
+        const int cur = NS == 2 ? u : cur_rt;           // LDS stage holding tile k0
+        const int set = NS == 2 ? (u ^ 1) : 0;          // staging set holding tile k0 + XK
         // Eight MFMA groups per k-tile: (MF = 0) two 16-wide k-steps x four 32-row blocks, six MFMAs each;
         // (MF = 1) eight 16-row blocks over the whole 32-wide k-tile, twelve MFMAs each.  The A fragments of
         // group g + 1 are read from LDS before group g's MFMAs are issued (ping-pong registers), so an MFMA
@@ -266,24 +273,26 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             // tile the pieces move zeros into a stage nobody reads: cheaper than a branch in this loop.
             if (AH) {
                 if (g < 2) {
-                    store_a16(g, cur ^ 1, k0 + XK);
-                    load_a16(g, k0 + 2 * XK);
+                    store_a16(set, g, cur ^ 1, k0 + XK);
+                    load_a16(set, g, k0 + (1 + NS) * XK);
                 } else if (g >= 4 && g < 6) {
-                    store_w(g - 4, cur ^ 1, k0 + XK);
-                    load_w(g - 4, k0 + 2 * XK);
+                    store_w(set, g - 4, cur ^ 1, k0 + XK);
+                    load_w(set, g - 4, k0 + (1 + NS) * XK);
                 }
             } else if (g < 4) {
-                store_a(g, cur ^ 1, k0 + XK);
-                load_a(g, k0 + 2 * XK);
+                store_a(set, g, cur ^ 1, k0 + XK);
+                load_a(set, g, k0 + (1 + NS) * XK);
             } else if (g < 6) {
-                store_w(g - 4, cur ^ 1, k0 + XK);
-                load_w(g - 4, k0 + 2 * XK);
+                store_w(set, g - 4, cur ^ 1, k0 + XK);
+                load_w(set, g - 4, k0 + (1 + NS) * XK);
             }
             // keep each piece (and the reload of its registers) in its own MFMA group: left alone, the
             // scheduler sinks all eight loads to the end of the loop, one barrier before they are needed
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        cur_rt ^= 1;
+      }
     }
 
     if (ACT == 3) {  // threshold filter instead of a store (MF = 0 layout): survivors are rare after the first slab
