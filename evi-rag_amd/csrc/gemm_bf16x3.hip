@@ -229,12 +229,15 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         // (MF = 1) eight 16-row blocks over the whole 32-wide k-tile, twelve MFMAs each.  The A fragments of
         // group g + 1 are read from LDS before group g's MFMAs are issued (ping-pong registers), so an MFMA
         // never waits on the LDS latency of its own operands.
-        bf16x8 fah[2], fal[2], fbh[MF ? 1 : 2][MF ? 4 : 2], fbl[MF ? 1 : 2][MF ? 4 : 2];
+        // A fragments are read AHEAD groups before their MFMAs: one group (six MFMAs = 192 cycles) covers the LDS
+        // latency when three products are multiplied; with one product a group is two MFMAs, so read two ahead.
+        constexpr int AHEAD = P1 ? 2 : 1, RING = AHEAD + 1;
+        bf16x8 fah[RING], fal[RING], fbh[MF ? 1 : 2][MF ? 4 : 2], fbl[MF ? 1 : 2][MF ? 4 : 2];
         auto read_a = [&](int g) {
             const int c = MF ? q16 : ((g >> 2) << 1) + fh;  // MF = 0: chunk holding k = 16 (g >> 2) + 8 h .. + 7
             const int row = MF ? wm * 128 + g * 16 + r16 : wm * 128 + (g & 3) * 32 + fr;
-            fah[g & 1] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
-            if (!P1) fal[g & 1] = *reinterpret_cast<const bf16x8*>(&sAlo[P1 ? 0 : cur][P1 ? 0 : slot3(row, c)]);
+            fah[g % RING] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
+            if (!P1) fal[g % RING] = *reinterpret_cast<const bf16x8*>(&sAlo[P1 ? 0 : cur][P1 ? 0 : slot3(row, c)]);
         };
         auto read_b = [&](int ks) {
             const int c = MF ? q16 : (ks << 1) + fh;
@@ -246,27 +249,28 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             }
         };
         read_b(0);
-        read_a(0);
+#pragma unroll
+        for (int g = 0; g < AHEAD; ++g) read_a(g);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (g + 1 < 8) read_a(g + 1);
+            if (g + AHEAD < 8) read_a(g + AHEAD);
             if (!MF && g == 2) read_b(1);
             if (MF) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4& c = acc16[MF ? g : 0][MF ? j : 0];
-                    if (!P1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[g & 1], fbh[0][MF ? j : 0], c, 0, 0, 0);
-                    if (!P1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g & 1], fbl[0][MF ? j : 0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g & 1], fbh[0][MF ? j : 0], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[g % RING], fbh[0][MF ? j : 0], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g % RING], fbl[0][MF ? j : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[g % RING], fbh[0][MF ? j : 0], c, 0, 0, 0);
                 }
             } else {
                 const int i = g & 3, ks = g >> 2;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16& c = acc[MF ? 0 : i][MF ? 0 : j];
-                    if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g & 1], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
-                    if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbl[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g % RING], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
+                    if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g % RING], fbl[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g % RING], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
                 }
             }
             // one staging piece in the shadow of this group's MFMAs (pieces 0-3: A, 4-5: W).  Past the last
