@@ -48,7 +48,9 @@ def parse_args():
                     help="storage dtype of the resident index (f16 / fp8 e4m3 + per-row scale: BASELINE configs 4 / 5; "
                          "the headline is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--topk-method", choices=["scan", "gemm", "auto"], default="scan",
+    ap.add_argument("--no-two-stage", action="store_true",
+                    help="skip the extra leg that times the two-stage exact scan (f16 shadow selection + f32 re-scoring)")
+    ap.add_argument("--topk-method", choices=["scan", "gemm", "auto", "two_stage"], default="scan",
                     help="local top-k kernel: the 32-queries-per-pass scan (default), the many-query GEMM-shaped pass "
                          "(same results; pays off for --queries >= 96), or auto")
     ap.add_argument("--graph-kernels", action="store_true",
@@ -410,14 +412,13 @@ def main():
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
     from evi_rag_amd.dist import ShardedIndex
 
-    index = ShardedIndex(shard, N, row_scale=row_scale, method=args.topk_method if args.index_dtype in ("f32", "f16") else "scan")
+    if args.topk_method == "two_stage" and args.index_dtype != "f32":
+        raise SystemExit("--topk-method two_stage goes with the f32 index (its f16 shadow is built here)")
+    method = args.topk_method if args.index_dtype in ("f32", "f16") else "scan"
+    shadow = ops.index_shadow_f16(shard) if method == "two_stage" else None
+    index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow)
     index.workspace = ws
-
-    def step(b):
-        # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge on a
-        # side stream, overlapped with the next batch's scan (every result is complete at the closing fence)
-        s, i, _ = index.topk_async(queries[b], k)
-        return s, i
+    import ctypes
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -425,27 +426,77 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for b in range(args.warmup):
-        step(b)
-    fence()
-    lib.evi_timing_enable(1)
-    t0 = time.perf_counter()
-    out = None
-    for b in range(args.warmup, n_batches):
-        out = step(b)
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.evi_timing_enable(0)
-    import ctypes
+    def timed_run(index):
+        """W untimed + K timed steps of `index`; returns (seconds — max over ranks, kernel ms per class, launches, last result)."""
+        def step(b):
+            # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge on a
+            # side stream, overlapped with the next batch's scan (every result is complete at the closing fence)
+            s, i, _ = index.topk_async(queries[b], k)
+            return s, i
 
-    ms = (ctypes.c_double * 4)()
-    launches = (ctypes.c_int32 * 4)()
-    _lib.check(lib.evi_timing_read(ms, launches, 4))
+        for b in range(args.warmup):
+            step(b)
+        fence()
+        lib.evi_timing_enable(1)
+        t0 = time.perf_counter()
+        out = None
+        for b in range(args.warmup, n_batches):
+            out = step(b)
+        fence()
+        elapsed = time.perf_counter() - t0
+        lib.evi_timing_enable(0)
+        ms = (ctypes.c_double * 4)()
+        launches = (ctypes.c_int32 * 4)()
+        _lib.check(lib.evi_timing_read(ms, launches, 4))
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, list(ms), list(launches), out
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def two_stage_bytes(shard_rows):
+        kk = k + max(256, k // 2)
+        # what the timed kernel (the shadow scan) moves: the f16 rows once, the queries, the stage-1 lists.  The kk
+        # re-scored f32 rows per query (Q * kk * D * 4 = 74 MB at the defaults) belong to the re-scoring kernel
+        return shard_rows * D * 2 + Q * D * 4 + Q * kk * 12
+
+    elapsed, ms, launches, out = timed_run(index)
+    two_stage_fallback = index.two_stage_failed() if method == "two_stage" else False
+    if world > 1 and method == "two_stage":
+        t = torch.tensor([int(two_stage_fallback)], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        two_stage_fallback = bool(t.item())
+    if two_stage_fallback:  # some batch could not be proven exact: the timed stream must be redone with the f32 scan
+        index = ShardedIndex(shard, N, method="scan")
+        index.workspace = ws
+        method = "scan"
+        elapsed, ms, launches, out = timed_run(index)
+
+    # extra leg (f32 headline run only): the same batches through the two-stage exact scan; its last result must equal
+    # the f32 scan's bit for bit
+    two_stage = None
+    if method == "scan" and args.index_dtype == "f32" and not args.no_two_stage and not two_stage_fallback:
+        shadow = ops.index_shadow_f16(shard)
+        idx2 = ShardedIndex(shard, N, method="two_stage", shadow=shadow)
+        idx2.workspace = ws
+        e2, ms2, l2, out2 = timed_run(idx2)
+        failed = idx2.two_stage_failed()
+        same = bool(torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1]))
+        b2 = two_stage_bytes(row_end - row_begin)
+        sc2 = ms2[0] / args.steps
+        two_stage = {
+            "what": "f16 shadow of the index scanned for k + max(256, k/2) candidates per query, candidates re-scored from the "
+                    "f32 rows with the scan's own MFMA chain; a per-batch gap test proves the result equals the f32 scan's",
+            "value": Q * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
+            "identical_to_f32_scan": same, "proof_failed": failed, "extra_index_memory_bytes": int(shadow.numel()) * 2,
+            "roofline": {"bound": "hbm", "achieved": b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0) / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_cosine_score<F16=1> over the shadow", "algorithmic_bytes_per_step": b2,
+                         "launches_per_step": l2[0] / args.steps, "kernel_ms_per_step": sc2,
+                         "select_and_rescore_ms_per_step": ms2[1] / args.steps},
+        }
+        del shadow, idx2, out2
+        torch.cuda.empty_cache()
 
     # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
     s_last, i_last = out
@@ -458,6 +509,8 @@ def main():
         steps = args.steps
         shard_rows = row_end - row_begin
         bytes_per_step = shard_rows * D * elem_bytes + Q * D * 4 + Q * k * 12 + (shard_rows * 4 if row_scale is not None else 0)
+        if method == "two_stage":
+            bytes_per_step = two_stage_bytes(shard_rows)
         score_ms_per_step = ms[0] / steps
         achieved = bytes_per_step / (score_ms_per_step * 1e-3) / 1e9 if score_ms_per_step > 0 else 0.0
         result = {
@@ -481,7 +534,7 @@ def main():
                 "queries_per_step": Q,
                 "k": k,
                 "index_dtype": args.index_dtype,
-                "topk_method": args.topk_method,
+                "topk_method": method,
                 "sharding": f"rows/{world}" if world > 1 else "none",
             },
             "roofline": {
@@ -490,7 +543,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step) if args.index_dtype == "f32" else None,
+                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step) if (args.index_dtype == "f32" and method == "scan") else None,
                 "kernel": "k_cosine_score",
                 "algorithmic_bytes_per_step": bytes_per_step,
                 "launches_per_step": launches[0] / steps,
@@ -500,6 +553,10 @@ def main():
             "hits_at_k": hits,
             "sorted_ok": sorted_ok,
         }
+        if two_stage is not None:
+            result["two_stage"] = two_stage
+        if args.topk_method == "two_stage":
+            result["two_stage_proof_failed"] = two_stage_fallback
         if ms[2] > ms[0]:
             # the many-query path did the work: the dominant kernel is the split-bf16 GEMM (MFMA-bound), priced by the
             # flops it executes (3 bf16 products per f32 product) against the dense bf16 peak
@@ -515,7 +572,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(shard if shard_f32_sample is None else shard_f32_sample, queries, k, N,
                                                   args.cpu_rows, args.cpu_seconds)
         if world == 1 and not args.no_graph_eval:
-            del shard, ws
+            del shard, ws, index
             torch.cuda.empty_cache()
             result["graph_eval"] = bench_graph_eval(dev, D, cpu_seconds=0.0 if args.no_cpu_baseline else 8.0)
         os.write(result_fd, (json.dumps(result) + "\n").encode())

@@ -984,3 +984,180 @@ extern "C" int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f
     return cosine_topk_gemm_impl(q, Q, idx_f16, 1, products, nullptr, N, D, row_scale, k, row_id_base, out_score, out_index,
                                  status, workspace, workspace_bytes, stream);
 }
+
+// =====================================================================================================
+// Two-stage exact scan (f16 shadow selection + f32 re-scoring): the result of evi_cosine_topk at half
+// the HBM bytes per batch.
+//
+// The f32 index is kept as it is and an f16 copy of it (the shadow, rn(x) element by element, made once
+// by evi_index_shadow_f16: + 50 % memory) is what the scan streams.  Stage 1 is evi_cosine_topk_f16
+// over the shadow with kk = k + reserve results per query.  For rows of norm <= 1 its scores differ
+// from the f32 scan's by at most kShadowEps * |q|:
+//     |q . (x - rn_f16(x))| <= 2^-11 |q| |x|                    (Cauchy-Schwarz, f16 has 11 significant bits)
+//     f32 chain of the exact scan: 768 roundings x 2^-23         (truncating adders assumed)
+//     f16-MFMA chain of the shadow scan + the hi/lo query split: < 5e-5
+// so when approx[k-1] - approx[kk-1] > 2 eps |q| every row outside the kk kept ones is beaten, in exact
+// score, by k kept rows: the true top-k is inside the list (same argument as the many-query path above).
+// Stage 2 re-scores the kk rows from the f32 index with the scan's own v_mfma_f32_16x16x4_f32 chain and
+// takes the top-k on those scores: ids and scores bit-identical to evi_cosine_topk.  A failed proof
+// ORs 1 into *status (sticky: the caller zeroes it, so a pipeline of batches can share one flag and read it
+// once) and the caller runs the f32 scan.
+// =====================================================================================================
+namespace evi {
+
+constexpr float kShadowEps = 7.0e-4f;
+
+static int two_stage_kk(int k) { return gemm_topk_reserve(k, 0); }
+
+__global__ void k_shadow_f16(const float* __restrict__ x, int64_t n, _Float16* __restrict__ out) {
+    // 4 elements per thread per step: one 16-byte load, one 8-byte store
+    const int64_t n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4* o4 = reinterpret_cast<f16x4*>(out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = x4[i];
+        f16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];  // round to nearest even
+        o4[i] = h;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (_Float16)x[i];
+}
+
+// approx / ids: [Q, kk] as evi_cosine_topk_f16 wrote them (sorted, (-inf, -1) past the end of a short index)
+__global__ void k_ts_gap(const float* __restrict__ q, int D, const float* __restrict__ approx,
+                         const int64_t* __restrict__ ids, int k, int kk, float eps, int32_t* __restrict__ status) {
+    const int qi = blockIdx.x;
+    const int lane = threadIdx.x;  // one wave
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss = fmaf(q[(int64_t)qi * D + d], q[(int64_t)qi * D + d], ss);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0 && ids[(int64_t)qi * kk + kk - 1] >= 0) {  // otherwise every row of the index is in the list
+        const float* s = approx + (int64_t)qi * kk;
+        const float gap = s[k - 1] - s[kk - 1];
+        if (!(gap > 2.0f * eps * sqrtf(ss))) atomicOr(status, 1);  // also catches NaN scores
+    }
+}
+
+// k_gt_rescore for [Q, kk] i64 candidate ids (-1 = padding): one wave per (query, 16 candidates)
+__global__ __launch_bounds__(256) void k_ts_rescore(const float* __restrict__ q, int D, const float* __restrict__ idx,
+                                                    const int64_t* __restrict__ ids, int Q, int kk,
+                                                    float* __restrict__ exact /* [Q, kk] */) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, g = lane >> 4;
+    const int tiles = (kk + 15) / 16;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= (int64_t)Q * tiles) return;  // whole waves only: the MFMAs below run with all 64 lanes
+    const int qi = (int)(w / tiles), t = (int)(w % tiles);
+    const int c = t * 16 + n;
+    const int64_t row = c < kk ? ids[(int64_t)qi * kk + c] : -1;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(idx + (row >= 0 ? row : 0) * D) + g;
+    const f32x4* qp = reinterpret_cast<const f32x4*>(q + (int64_t)qi * D) + g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < D / 16; ++j) {
+        const f32x4 x = xp[j * 4];
+        const f32x4 a = n == 0 ? qp[j * 4] : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], x[e], acc, 0, 0, 0);
+    }
+    if (g == 0 && c < kk) exact[(int64_t)qi * kk + c] = row >= 0 ? acc[0] : -INFINITY;
+}
+
+__global__ __launch_bounds__(kSelectThreads) void k_ts_final(const float* __restrict__ exact, const int64_t* __restrict__ ids,
+                                                             int kk, int k, int64_t row_id_base, float* __restrict__ out_score,
+                                                             int64_t* __restrict__ out_index) {
+    __shared__ SelectShared sh;
+    const int qi = blockIdx.x;
+    const float* es = exact + (int64_t)qi * kk;
+    const int64_t* ci = ids + (int64_t)qi * kk;
+    auto load = [&](int64_t i) -> uint64_t { return ci[i] >= 0 ? make_key(es[i], (uint32_t)ci[i]) : 0ull; };
+    const int m = block_topk(sh, load, kk, k);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint64_t key = i < m ? sh.keys[i] : 0ull;
+        if (key != 0ull) {
+            out_score[(int64_t)qi * k + i] = key_score(key);
+            out_index[(int64_t)qi * k + i] = row_id_base + (int64_t)key_index(key);
+        } else {
+            out_score[(int64_t)qi * k + i] = -INFINITY;
+            out_index[(int64_t)qi * k + i] = -1;
+        }
+    }
+}
+
+struct TsLayout {
+    size_t approx, ids, exact, scan, scan_bytes, total;
+};
+static TsLayout ts_layout(int Q, int64_t N, int D, int k) {
+    TsLayout L;
+    const int kk = two_stage_kk(k);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    L.approx = take((size_t)Q * kk * sizeof(float));
+    L.ids = take((size_t)Q * kk * sizeof(int64_t));
+    L.exact = take((size_t)Q * kk * sizeof(float));
+    L.scan_bytes = evi_cosine_topk_workspace_bytes(Q, N, D, kk);
+    L.scan = take(L.scan_bytes);
+    L.total = off;
+    return L;
+}
+
+}  // namespace evi
+
+extern "C" int evi_index_shadow_f16(const float* idx, int64_t N, int D, void* out_f16, void* stream) {
+    EVI_REQUIRE(N >= 0 && D >= 1, "evi_index_shadow_f16: need N >= 0, D >= 1");
+    if (N == 0) return EVI_OK;
+    EVI_REQUIRE(idx && out_f16, "evi_index_shadow_f16: null pointer");
+    hipLaunchKernelGGL(k_shadow_f16, dim3(4096), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), idx, N * D,
+                       static_cast<_Float16*>(out_f16));
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" size_t evi_cosine_topk_two_stage_workspace_bytes(int Q, int64_t N, int D, int k) {
+    if (Q <= 0 || N < 0 || D <= 0 || k <= 0 || two_stage_kk(k) > EVI_TOPK_MAX_K) return 0;
+    return ts_layout(Q, N, D, k).total;
+}
+
+extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx, const void* shadow_f16, int64_t N, int D,
+                                         int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    EVI_REQUIRE(Q >= 1 && N >= 1, "evi_cosine_topk_two_stage: need Q >= 1 and N >= 1, got Q=%d N=%lld", Q, (long long)N);
+    EVI_REQUIRE(k >= 1, "evi_cosine_topk_two_stage: k must be >= 1, got %d", k);
+    if (D < 32 || D % 32 != 0 || D > 1280)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_two_stage: D must be a multiple of 32 in [32, 1280], got %d", D);
+    const int kk = two_stage_kk(k);
+    if (kk > EVI_TOPK_MAX_K)
+        return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_two_stage: k + reserve = %d exceeds %d (k <= %d)", kk, EVI_TOPK_MAX_K,
+                    EVI_TOPK_MAX_K * 2 / 3);
+    EVI_REQUIRE(q && idx && shadow_f16 && out_score && out_index && status && workspace,
+                "evi_cosine_topk_two_stage: null pointer");
+    const TsLayout L = ts_layout(Q, N, D, k);
+    if (workspace_bytes < L.total)
+        return fail(EVI_ERR_NOMEM, "evi_cosine_topk_two_stage: workspace %zu B < %zu B", workspace_bytes, L.total);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* base = static_cast<char*>(workspace);
+    float* approx = reinterpret_cast<float*>(base + L.approx);
+    int64_t* ids = reinterpret_cast<int64_t*>(base + L.ids);
+    float* exact = reinterpret_cast<float*>(base + L.exact);
+    // stage 1: kk best rows per query by shadow score (local row ids)
+    const int rc = cosine_topk_impl(q, Q, shadow_f16, 1, N, D, nullptr, kk, 0, approx, ids, base + L.scan, L.scan_bytes, stream);
+    if (rc != EVI_OK) return rc;
+    // stage 2: proof, exact scores from the f32 rows, final top-k
+    hipLaunchKernelGGL(k_ts_gap, dim3(Q), dim3(64), 0, st, q, D, approx, ids, k, kk, kShadowEps, status);
+    const int tiles = (kk + 15) / 16;
+    const int64_t waves = (int64_t)Q * tiles;
+    const int tok = timing_begin(kTimeSelect, st);
+    hipLaunchKernelGGL(k_ts_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, idx, ids, Q, kk, exact);
+    hipLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ids, kk, k, row_id_base, out_score, out_index);
+    timing_end(tok, st);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}

@@ -40,6 +40,19 @@ def _default_local_topk(queries, shard, k, row_id_base, row_scale=None, method="
     return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale, method=method)
 
 
+def _local_scan(self: "ShardedIndex", queries, k, out, workspace):
+    """The shard's exact top-k into `out` on the current stream, without a read-back.  method "two_stage": the f16
+    shadow is scanned and the f32 rows re-score (ops.cosine_topk_two_stage); a failed proof is OR-ed into
+    self.two_stage_status, which the caller checks once per stream of batches (`two_stage_failed`)."""
+    from . import ops
+
+    if self.method == "two_stage":
+        return ops.cosine_topk_two_stage(queries, self.shard, self.shadow, k, row_id_base=self.row_begin, out=out,
+                                         status=self.two_stage_status, workspace=self._two_stage_workspace(queries, k))
+    return ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
+                           workspace=workspace, out=out, method=self.method)
+
+
 def _default_merge(scores, ids):
     from . import ops
 
@@ -51,7 +64,8 @@ class ShardedIndex:
 
     def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
                  local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
-                 row_scale: Optional[torch.Tensor] = None, method: str = "scan") -> None:
+                 row_scale: Optional[torch.Tensor] = None, method: str = "scan",
+                 shadow: Optional[torch.Tensor] = None) -> None:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -61,7 +75,16 @@ class ShardedIndex:
             raise ValueError(f"rank {self.rank} must hold rows [{self.row_begin}, {self.row_end}): "
                              f"{self.row_end - self.row_begin} rows, got {local_rows.size(0)}")
         self.shard = local_rows
-        self.method = method  # ops.cosine_topk method for the local top-k: "scan" | "gemm" | "auto"
+        # local top-k: ops.cosine_topk's "scan" | "gemm" | "auto", or "two_stage" (f16 shadow of the f32 shard selects,
+        # the f32 rows re-score: same result at half the bytes per batch; needs `shadow` = ops.index_shadow_f16(shard))
+        self.method = method
+        self.shadow = shadow
+        self.two_stage_status: Optional[torch.Tensor] = None
+        self._ts_ws: Optional[torch.Tensor] = None
+        if method == "two_stage":
+            if row_scale is not None or shadow is None or shadow.shape != local_rows.shape or shadow.dtype != torch.float16:
+                raise ValueError("method 'two_stage' needs an L2-normalised f32 shard (no row_scale) and its float16 shadow")
+            self.two_stage_status = torch.zeros(1, dtype=torch.int32, device=local_rows.device)
         # per-row scale of the local shard: the fused normalisation of a raw index, or the
         # dequantisation scale of an fp8 index (ops.quantize_rows_fp8)
         self.row_scale = row_scale
@@ -81,11 +104,35 @@ class ShardedIndex:
         # EVI_FORCE_EXCHANGE=1 runs the exchange even with one rank (rehearses the multi-rank path on one GPU)
         self._exchange = self.world > 1 or (os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and dist.is_initialized())
 
+    def _two_stage_workspace(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+        from . import _lib
+
+        need = int(_lib.load().evi_cosine_topk_two_stage_workspace_bytes(queries.size(0), self.shard.size(0), self.shard.size(1), int(k)))
+        if need == 0:
+            raise ValueError(f"k + max(256, k // 2) must not exceed 2048, got k = {k}")
+        if self._ts_ws is None or self._ts_ws.numel() < need:
+            self._ts_ws = torch.empty(need, dtype=torch.uint8, device=self.shard.device)
+        return self._ts_ws
+
+    def two_stage_failed(self) -> bool:
+        """True when some batch since the last call could not be proven exact (one read-back; resets the flag): the
+        results of those batches must be recomputed with method "scan"."""
+        if self.two_stage_status is None:
+            return False
+        bad = bool(self.two_stage_status.item())
+        self.two_stage_status.zero_()
+        return bad
+
     def topk(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Global top-k (scores [Q, k], global row ids [Q, k]) — identical on every rank."""
         if self._exchange and self._packed_ok and queries.is_cuda:
             return self._topk_packed(queries, k)
-        if self._local_topk is _default_local_topk:
+        if self.method == "two_stage" and self._local_topk is _default_local_topk:
+            from . import ops
+
+            s, i = ops.cosine_topk_two_stage(queries, self.shard, self.shadow, k, row_id_base=self.row_begin,
+                                             workspace=self._two_stage_workspace(queries, k))  # checked: falls back to the scan
+        elif self._local_topk is _default_local_topk:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale, self.method)
         elif self.row_scale is not None:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale)
@@ -112,8 +159,12 @@ def _topk_packed(self: "ShardedIndex", queries: torch.Tensor, k: int):
         self._packed_local = torch.empty(rec, dtype=torch.uint8, device=queries.device)
         self._packed_all = torch.empty(self.world * rec, dtype=torch.uint8, device=queries.device)
     s, i = ops.topk_packed_views(self._packed_local, Q, k)
-    ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
-                    workspace=self.workspace, out=(s, i), method=self.method)
+    _local_scan(self, queries, k, (s, i), self.workspace)
+    if self.method == "two_stage":
+        # a failed proof on ANY rank sends every rank to the f32 scan (the ranks must agree: the exchange is collective)
+        dist.all_reduce(self.two_stage_status, op=dist.ReduceOp.MAX, group=self.group)
+        if self.two_stage_failed():
+            ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, workspace=self.workspace, out=(s, i))
     dist.all_gather_into_tensor(self._packed_all, self._packed_local, group=self.group)
     return ops.topk_merge_packed(self._packed_all, self.world, Q, k)
 
@@ -131,7 +182,10 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
     dev = queries.device
     main = torch.cuda.current_stream(dev)
     if not (self._exchange and self._packed_ok and queries.is_cuda):
-        s, i = self.topk(queries, k)
+        if self.method == "two_stage" and queries.is_cuda and self._local_topk is _default_local_topk:
+            s, i = _local_scan(self, queries, k, None, None)  # no read-back: the caller checks two_stage_failed()
+        else:
+            s, i = self.topk(queries, k)
         ev = torch.cuda.Event()
         ev.record(main)
         return s, i, ev
@@ -149,8 +203,7 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
     if p["used"][slot]:
         main.wait_event(p["xchg_done"][slot])  # the all-gather two batches ago has consumed this slot's record
     sv, iv = ops.topk_packed_views(p["local"][slot], Q, k)
-    ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale, workspace=self.workspace,
-                    out=(sv, iv), method=self.method)
+    _local_scan(self, queries, k, (sv, iv), self.workspace)
     p["scan_done"][slot].record(main)
     side = p["side"]
     with torch.cuda.stream(side):

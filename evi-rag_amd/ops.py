@@ -283,6 +283,74 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
 cosine_topk_gemm.last_products = None
 
 
+def index_shadow_f16(index: torch.Tensor) -> torch.Tensor:
+    """f16 copy (round to nearest) of an f32 index of unit rows (+ 50 % memory) for cosine_topk_two_stage."""
+    dev = _require_gpu(index)
+    x = _f32c(index, "index")
+    if x.dim() != 2:
+        raise ValueError("index must be 2D")
+    out = torch.empty(x.shape, dtype=torch.float16, device=dev)
+    if x.numel():
+        _lib.check(_lib.load().evi_index_shadow_f16(_ptr(x), x.size(0), x.size(1), _ptr(out), _stream(dev)))
+    return out
+
+
+def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: torch.Tensor, k: int, *, row_id_base: int = 0,
+                          fallback: bool = True, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                          status: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
+    """cosine_topk over an L2-normalised f32 index at half the HBM bytes (see evi_cosine_topk_two_stage): the f16
+    `shadow` (index_shadow_f16(index)) is scanned to select k + max(256, k/2) candidates per query, which are re-scored
+    from the f32 rows with the scan's arithmetic; ids and scores equal cosine_topk(queries, index, k) bit for bit.
+    status=None: the proof flag is read back (one synchronisation) and a failed proof runs the f32 scan instead
+    (fallback=True) or raises RuntimeError.  status=<int32 [1] device tensor, zeroed by the caller>: nothing is read
+    back — a failed proof ORs 1 into it (sticky across calls, so a pipeline of batches shares one flag) and the caller
+    must check it (non-zero: discard the outputs, run cosine_topk) before using the results."""
+    dev = _require_gpu(queries, index, shadow, status, workspace)
+    if queries.dim() != 2 or index.dim() != 2:
+        raise ValueError("queries and index must be 2D")
+    if index.dtype != torch.float32 or shadow.dtype != torch.float16 or shadow.shape != index.shape or not shadow.is_contiguous():
+        raise ValueError("shadow must be the contiguous float16 copy of an f32 index (index_shadow_f16)")
+    q = _f32c(queries, "queries")
+    x = _f32c(index, "index")
+    Q, D = q.shape
+    N = x.shape[0]
+    if x.shape[1] != D:
+        raise ValueError(f"query dim {D} != index dim {x.shape[1]}")
+    if status is not None and (status.dtype != torch.int32 or status.numel() != 1):
+        raise ValueError("status must be an int32 tensor with one element")
+    if Q == 0 or N == 0:
+        return cosine_topk(q, x, k, row_id_base=row_id_base, out=out)
+    lib = _lib.load()
+    need = int(lib.evi_cosine_topk_two_stage_workspace_bytes(Q, N, D, int(k)))
+    if need == 0:
+        raise ValueError(f"k + max(256, k // 2) must not exceed 2048, got k = {k}")
+    ws = workspace if workspace is not None else _workspace(dev, "cosine_topk_two_stage", need)
+    if out is not None:
+        out_score, out_index = out
+        if (out_score.shape != (Q, k) or out_index.shape != (Q, k) or out_score.dtype != torch.float32
+                or out_index.dtype != torch.int64 or not out_score.is_contiguous() or not out_index.is_contiguous()):
+            raise ValueError("out must be contiguous (float32 [Q, k], int64 [Q, k]) tensors")
+    else:
+        out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    flag = status if status is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.evi_cosine_topk_two_stage(_ptr(q), Q, _ptr(x), _ptr(shadow), N, D, int(k), int(row_id_base), _ptr(out_score),
+                                             _ptr(out_index), flag.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
+                                             _stream(dev)))
+    if status is not None:
+        return out_score, out_index
+    st = int(flag.item())
+    cosine_topk_two_stage.last_status = st
+    if st != 0:
+        if not fallback:
+            raise RuntimeError(f"evi_cosine_topk_two_stage could not prove exactness (status {st}): run cosine_topk")
+        return cosine_topk(q, x, k, row_id_base=row_id_base, out=out)
+    return out_score, out_index
+
+
+cosine_topk_two_stage.last_status = None
+
+
 def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge per-shard top-k lists [P, Q, k] (shards in ascending row-id order) into [Q, k]."""
     dev = _require_gpu(scores, ids)

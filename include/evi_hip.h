@@ -157,6 +157,24 @@ int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t
                              int k, int64_t row_id_base, int products, float* out_score, int64_t* out_index,
                              int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Two-stage exact scan: the result of evi_cosine_topk (ids and scores bit-identical) at half the HBM bytes per
+ * batch, for an f32 index of rows with norm <= 1 (evi_row_normalize output; no row_scale) that is kept together
+ * with an f16 copy of itself - the shadow, rn_f16(x) element by element, made once by evi_index_shadow_f16
+ * (+ 50 % memory; D % 32 == 0).  Stage 1 streams the shadow (evi_cosine_topk_f16 arithmetic) and keeps
+ * k + max(256, k/2) rows per query; their scores are within 7e-4 |q| of the f32 scan's (f16 rounding of a row
+ * moves a dot product by at most 2^-11 |q| |x|, plus the two accumulation chains), so when the k-th and the last
+ * kept shadow scores are more than twice that apart the true top-k is among the kept rows.  Stage 2 re-scores
+ * them from the f32 rows with the scan's own v_mfma_f32_16x16x4_f32 chain and takes the top-k.
+ * *status (device int32, zeroed by the CALLER; bits are OR-ed in, so a pipeline of batches can share one flag and
+ * read it once): 0 = proven exact; bit 0 = the gap test failed for some query (heavy ties, NaN scores) - discard
+ * the outputs and run evi_cosine_topk.  The shadow must be the one evi_index_shadow_f16 made from idx: the proof
+ * is about that pair.  k <= 1365.  Never synchronises. */
+int evi_index_shadow_f16(const float* idx, int64_t N, int D, void* out_f16, void* stream);
+size_t evi_cosine_topk_two_stage_workspace_bytes(int Q, int64_t N, int D, int k);
+int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx, const void* shadow_f16, int64_t N, int D,
+                              int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.
  *   scores [P, Q, k] f32, ids [P, Q, k] i64  ->  out_score [Q, k], out_index [Q, k].

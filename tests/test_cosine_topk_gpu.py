@@ -413,3 +413,67 @@ def test_cosine_topk_gemm_f16_index_equals_f16_scan(dev, Q, N, D, k):
         assert torch.equal(i1, i0) and torch.equal(s1, s0), products
     s2, i2 = ops.cosine_topk(qn, x16, k, row_id_base=3, method="auto")
     assert torch.equal(i2, i0) and torch.equal(s2, s0)
+
+
+@pytest.mark.parametrize("Q,N,D,k", [(32, 400000, 768, 500), (33, 70000, 768, 500), (7, 3000, 64, 10), (32, 600, 32, 500),
+                                     (1, 1, 32, 1), (40, 100000, 384, 100), (16, 1 << 20, 128, 1365)])
+def test_cosine_topk_two_stage_equals_scan_bit_for_bit(dev, Q, N, D, k):
+    """f16-shadow selection + f32 re-scoring: ids AND scores identical to the f32 scan; the index holds duplicated rows
+    (exact ties), a zero row, and (N < k + reserve cases) fewer rows than the candidate list."""
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N + 5)
+    q = np.random.default_rng(Q + 7).standard_normal((Q, D), dtype=np.float32)
+    idx = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    shadow = ops.index_shadow_f16(idx)
+    assert torch.equal(shadow, idx.to(torch.float16))  # round to nearest even, element by element
+    s0, i0 = ops.cosine_topk(qn, idx, k, row_id_base=5)
+    s1, i1 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5, fallback=False)
+    assert torch.equal(i1, i0) and torch.equal(s1, s0)
+    # without a read-back: the flag lands in the caller's tensor
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    s2, i2 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5, status=flag)
+    assert int(flag.item()) == 0 and torch.equal(i2, i0) and torch.equal(s2, s0)
+
+
+def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
+    """(a) the shadow scan's scores stay inside the bound the proof uses (7e-4 |q|, measured ~1e-5); (b) a clustered
+    index (thousands of rows inside the bound of the k-th) cannot be proven: status 1, fallback=False raises, the
+    default falls back to the f32 scan and returns its result."""
+    from evi_rag_amd import ops
+
+    N, D, Q, k = 200000, 768, 32, 500
+    idx = ops.normalize_embeddings(torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+    qn = ops.normalize_embeddings(torch.randn(Q, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
+    shadow = ops.index_shadow_f16(idx)
+    s32, i32 = ops.cosine_topk(qn, idx, k)
+    s16, i16 = ops.cosine_topk(qn, shadow, N if N <= 2048 else 2048)
+    # compare row by row where both lists hold the row
+    pos = {}
+    worst = 0.0
+    s16c, i16c, s32c, i32c = s16.cpu().numpy(), i16.cpu().numpy(), s32.cpu().numpy(), i32.cpu().numpy()
+    for qi in range(Q):
+        lut = dict(zip(i16c[qi].tolist(), s16c[qi].tolist()))
+        for r, s in zip(i32c[qi].tolist(), s32c[qi].tolist()):
+            assert r in lut  # the true top-500 sits inside the shadow's top-2048
+            worst = max(worst, abs(lut[r] - s))
+    assert worst < 7e-4 / 10, worst
+
+    base = torch.randn(D, device=dev)
+    clustered = ops.normalize_embeddings(base.repeat(6000, 1) + 1e-5 * torch.randn(6000, D, device=dev))
+    sh = ops.index_shadow_f16(clustered)
+    with pytest.raises(RuntimeError, match="could not prove"):
+        ops.cosine_topk_two_stage(qn, clustered, sh, 50, fallback=False)
+    s, i = ops.cosine_topk_two_stage(qn, clustered, sh, 50)
+    assert ops.cosine_topk_two_stage.last_status == 1
+    s0, i0 = ops.cosine_topk(qn, clustered, 50)
+    assert torch.equal(i, i0) and torch.equal(s, s0)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky: a failure stays visible after a later success
+    ops.cosine_topk_two_stage(qn, clustered, sh, 50, status=flag)
+    ops.cosine_topk_two_stage(qn, idx, shadow, 50, status=flag)
+    assert int(flag.item()) == 1
+    with pytest.raises(ValueError):
+        ops.cosine_topk_two_stage(qn, clustered, sh, 1500)  # k + reserve exceeds the selector's capacity
+    with pytest.raises(ValueError):
+        ops.cosine_topk_two_stage(qn, clustered, sh.to(torch.bfloat16), 50)
