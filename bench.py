@@ -58,17 +58,20 @@ def parse_args():
                          "CPU-oracle baseline) and print its JSON object")
     ap.add_argument("--graph-batch", type=int, default=64, help="graphs per batch of the --graph-kernels leg")
     ap.add_argument("--no-graph-eval", action="store_true")
+    ap.add_argument("--no-encode", action="store_true", help="skip the text-encoding leg (random-init BERT + pooling kernel)")
     return ap.parse_args()
 
 
-def build_shard(dev, row_begin, row_end, D, seed):
+def build_shard(dev, row_begin, row_end, D, seed, dtype=torch.float32):
     """Rows [row_begin, row_end) of the global synthetic index, generated chunk-wise on the GPU so
     that the content of a global row does not depend on the number of ranks.  N(0,1) entries,
-    global row 0 all-zero (eps clamp), 1 % of each chunk's rows duplicated (exact ties)."""
+    global row 0 all-zero (eps clamp), 1 % of each chunk's rows duplicated (exact ties).  Every chunk is
+    normalised (C1) and stored in `dtype` as it is made, so a 100 M-row f16 index (154 GB, BASELINE config 4) is
+    built on one 288 GB GPU without ever holding its f32 form."""
     from evi_rag_amd import ops
 
     n = row_end - row_begin
-    shard = torch.empty((n, D), dtype=torch.float32, device=dev)
+    shard = torch.empty((n, D), dtype=dtype, device=dev)
     c0 = row_begin // CHUNK_ROWS
     c1 = (row_end + CHUNK_ROWS - 1) // CHUNK_ROWS
     gen = torch.Generator(device=dev)
@@ -81,11 +84,11 @@ def build_shard(dev, row_begin, row_end, D, seed):
         chunk[dst] = chunk[src]
         if c == 0:
             chunk[0] = 0.0
+        ops.normalize_embeddings(chunk, EPS, out=chunk)  # C1, in place: the resident index is normalised
         lo = max(row_begin, c * CHUNK_ROWS)
         hi = min(row_end, (c + 1) * CHUNK_ROWS)
         shard[lo - row_begin: hi - row_begin] = chunk[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS]
         del chunk
-    ops.normalize_embeddings(shard, EPS, out=shard)  # C1, in place: the resident index is normalised
     return shard
 
 
@@ -273,6 +276,52 @@ def bench_eval_pipeline(dev, D, model, *, graphs_total=128, batch_size=32, nodes
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def bench_encode(dev, D, *, texts=4096, batch_size=64, iters=3):
+    """E1-E4 stage: `TextEncoder.encode_to_device` over synthetic WebQSP-sized texts (8..32 tokens, batches of 64 as
+    configs/build_retrieval_pipeline.yaml) with a RANDOM-INIT BERT of the bge-base shape (12 layers, 768 wide, 12 heads,
+    3072 FFN, 30 522-word vocabulary: no weights exist offline).  The transformer forward is PyTorch-ROCm, as north_star
+    states; the pooling tail is evi_masked_mean_pool.  Token ids are drawn directly (no tokenizer vocabulary offline):
+    the stand-in tokenizer pads a batch to its longest text like the reference's `padding=True`."""
+    from transformers import BertConfig, BertModel
+
+    from evi_rag_amd.text_encode import TextEncoder
+
+    heads = {384: 12, 768: 12, 1024: 16}.get(D, 12)
+    layers = {384: 6, 768: 12, 1024: 24}.get(D, 12)
+    torch.manual_seed(0)
+    model = BertModel(BertConfig(vocab_size=30522, hidden_size=D, num_hidden_layers=layers, num_attention_heads=heads,
+                                 intermediate_size=4 * D, max_position_embeddings=512), add_pooling_layer=False).to(dev).eval()
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(8, 33, texts)
+
+    class Tok:
+        def __call__(self, batch, padding=True, truncation=True, return_tensors="pt"):
+            lens = [lengths[int(t)] for t in batch]
+            L = max(lens)
+            g = torch.Generator().manual_seed(int(batch[0]))
+            ids = torch.randint(1000, 30000, (len(batch), L), generator=g)
+            mask = (torch.arange(L).view(1, L) < torch.tensor(lens).view(-1, 1)).to(torch.int64)
+            return {"input_ids": ids * mask, "attention_mask": mask}
+
+    enc = TextEncoder.from_components(Tok(), model, str(dev), fp16=False)
+    names = [str(i) for i in range(texts)]
+    enc.encode_to_device(names[: 4 * batch_size], batch_size)
+    torch.cuda.synchronize(dev)
+    best = float("inf")
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        out = enc.encode_to_device(names, batch_size)
+        torch.cuda.synchronize(dev)
+        best = min(best, time.perf_counter() - t0)
+    tokens = int(sum(max(lengths[b: b + batch_size]) * len(lengths[b: b + batch_size]) for b in range(0, texts, batch_size)))
+    params = sum(p.numel() for n, p in model.named_parameters() if "embeddings" not in n)
+    flops = 2.0 * params * tokens
+    return {"workload": f"{texts} texts of 8..32 tokens in batches of {batch_size}; random-init BERT {layers}L/{D}H (bge-base shape), f32; "
+                        "PyTorch-ROCm forward + evi_masked_mean_pool",
+            "texts_per_s": texts / best, "ms_per_batch": best / (texts / batch_size) * 1e3, "padded_tokens": tokens,
+            "encoder_tflops": flops / best / 1e12, "out_shape": list(out.shape)}
+
+
 def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, iters=20, cpu_graphs=8, cpu=True):
     """BASELINE config 3 (CWQ-shaped 2-hop expansion): CSR build, DDE structure features, multi-source BFS levels,
     seed-incident edge selection on batches of CWQ-shaped graphs (N_g ~ 3 000, E_g ~ 10 000, DDE 2 + 2 rounds,
@@ -394,12 +443,8 @@ def main():
     N, D, Q, k = args.rows, args.dim, args.queries, args.k
     row_begin = N * rank // world
     row_end = N * (rank + 1) // world
-    shard = build_shard(dev, row_begin, row_end, D, args.seed)
-    elem_bytes = 4
-    if args.index_dtype == "f16":
-        shard = shard.to(torch.float16)
-        elem_bytes = 2
-        torch.cuda.empty_cache()
+    shard = build_shard(dev, row_begin, row_end, D, args.seed, torch.float16 if args.index_dtype == "f16" else torch.float32)
+    elem_bytes = 2 if args.index_dtype == "f16" else 4
     n_batches = args.warmup + args.steps
     queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, args.seed, world)
     row_scale = None
@@ -528,7 +573,8 @@ def main():
                       "fp8": "e4m3 index + f32 row scale x f32 queries (f16 MFMA, f32 accumulate)"}[args.index_dtype],
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k",
+                "workload": ("configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k" if N < 50_000_000 else
+                             "configs[3] shape: 100 M-triple index, brute-force cosine top-k" + (" on ONE GPU" if world == 1 else "")),
                 "index_rows": N,
                 "dim": D,
                 "queries_per_step": Q,
@@ -575,6 +621,12 @@ def main():
             del shard, ws, index
             torch.cuda.empty_cache()
             result["graph_eval"] = bench_graph_eval(dev, D, cpu_seconds=0.0 if args.no_cpu_baseline else 8.0)
+        if world == 1 and not args.no_encode:
+            torch.cuda.empty_cache()
+            try:
+                result["encode"] = bench_encode(dev, D)
+            except ImportError as exc:  # transformers missing: the leg is informational
+                result["encode"] = {"skipped": str(exc)}
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if world > 1 or rehearse:
         dist.barrier()

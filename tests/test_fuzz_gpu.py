@@ -23,7 +23,7 @@ EPS = 1e-6
 
 
 def test_fuzz_cosine_topk_paths_agree(dev):
-    """scan vs oracle (margin-aware), scan vs many-query GEMM path (bit-exact), shards vs single pass (bit-exact)."""
+    """scan vs oracle (margin-aware), scan vs many-query GEMM path and vs the two-stage scan (bit-exact), shards vs single pass (bit-exact)."""
     from evi_rag_amd import ops
 
     for case in range(CASES):
@@ -44,6 +44,10 @@ def test_fuzz_cosine_topk_paths_agree(dev):
         if k <= 1000 and D % 16 == 0:
             s2, i2 = ops.cosine_topk_gemm(qn, xn, k, row_id_base=5)  # falls back by itself when it cannot prove exactness
             assert torch.equal(i2, i) and torch.equal(s2, s), f"case {case}: gemm path differs"
+        if k <= 1000 and D % 32 == 0:
+            # two-stage exact scan (f16 shadow selects, f32 rows re-score); falls back by itself when it cannot prove exactness
+            s3, i3 = ops.cosine_topk_two_stage(qn, xn, ops.index_shadow_f16(xn), k, row_id_base=5)
+            assert torch.equal(i3, i) and torch.equal(s3, s), f"case {case}: two-stage path differs"
         if N >= 3:
             cuts = sorted(set([0, N] + rng.integers(1, N, 2).tolist()))
             parts = [ops.cosine_topk(qn, xn[a:b], k, row_id_base=5 + a) for a, b in zip(cuts[:-1], cuts[1:])]
