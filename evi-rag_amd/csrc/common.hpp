@@ -45,6 +45,11 @@ bool timing_enabled();
 // Records a start event on `st`; returns a token (or -1 when timing is off).
 int timing_begin(int cls, hipStream_t st);
 void timing_end(int token, hipStream_t st);
+// For a span that is ONE kernel: a (start, stop) event pair to hand to hipExtLaunchKernelGGL, which stamps them with
+// the dispatch's own begin / end times.  Unlike timing_begin/end this puts no event packets between the kernels of the
+// stream (each recorded event costs ~5 us of gap, ~60 us per scan step), so a timed run runs like an untimed one.
+// Returns false (and null events) when timing is off.
+bool timing_kernel_events(int cls, hipEvent_t* start, hipEvent_t* stop);
 
 // ---- shared launchers ------------------------------------------------------------------------
 // C[M,N] = act(A[M,K] W[N,K]^T + bias); act: 0 none, 1 tanh, 2 sigmoid (gemm.hip).

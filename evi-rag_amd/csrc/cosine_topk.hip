@@ -24,6 +24,8 @@
 // Bound: HBM.  Algorithmic bytes per batch = N*D*4 + N*4 (row_scale, optional) + Q*D*4 + Q*k*12.
 #include "common.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <stdlib.h>
 
 namespace evi {
@@ -408,6 +410,7 @@ struct ScoreArgs {
     int32_t* cc;
     int64_t cap;
     int dense, capq;
+    hipEvent_t ev_start, ev_stop;  // non-null: stamped with the dispatch's begin / end (bench roofline leg)
 };
 
 template <int NQB, int U, int THREADS, int NT, int F16 = 0>
@@ -418,9 +421,14 @@ static int launch_score(const ScoreArgs& a) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT, F16>), dim3(a.grid), dim3(THREADS), a.lds, a.st,
-                       a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci, a.cc, a.cap,
-                       a.dense, a.capq);
+    if (a.ev_start)
+        hipExtLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT, F16>), dim3(a.grid), dim3(THREADS), (uint32_t)a.lds, a.st,
+                              a.ev_start, a.ev_stop, 0, a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci,
+                              a.cc, a.cap, a.dense, a.capq);
+    else
+        hipLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT, F16>), dim3(a.grid), dim3(THREADS), a.lds, a.st,
+                           a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci, a.cc, a.cap,
+                           a.dense, a.capq);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
@@ -593,20 +601,23 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
             const int64_t tiles = (end - begin + 15) / 16;
             int64_t want = (tiles + waves_per_block - 1) / waves_per_block;
             const int grid = (int)(want < cus ? want : cus);
-            const ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
-                               cs, ci, cnt, w.cap, first ? 1 : 0, capq};
-            const int tok = timing_begin(kTimeCosineScore, st);
+            ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
+                         cs, ci, cnt, w.cap, first ? 1 : 0, capq, nullptr, nullptr};
+            timing_kernel_events(kTimeCosineScore, &sa.ev_start, &sa.ev_stop);
             const int rc = f16 == 2 ? (nqb == 1 ? launch_score_lowp<1, 2>(U, sa) : launch_score_lowp<2, 2>(U, sa))
                            : f16  ? (nqb == 1 ? launch_score_lowp<1, 1>(U, sa) : launch_score_lowp<2, 1>(U, sa))
                                   : (nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa));
-            timing_end(tok, st);
             if (rc != EVI_OK) return rc;
             const int final_pass = end >= N ? 1 : 0;
-            const int tok2 = timing_begin(kTimeSelect, st);
-            hipLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, cs, ci, cnt,
-                               tau, w.cap, k, first ? (end - begin) : (int64_t)-1, final_pass,
-                               row_id_base, o_score, o_index);
-            timing_end(tok2, st);
+            hipEvent_t sel_start, sel_stop;
+            if (timing_kernel_events(kTimeSelect, &sel_start, &sel_stop))
+                hipExtLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, sel_start, sel_stop, 0, cs, ci,
+                                      cnt, tau, w.cap, k, first ? (end - begin) : (int64_t)-1, final_pass, row_id_base, o_score,
+                                      o_index);
+            else
+                hipLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, cs, ci, cnt,
+                                   tau, w.cap, k, first ? (end - begin) : (int64_t)-1, final_pass,
+                                   row_id_base, o_score, o_index);
             EVI_LAUNCH_CHECK();
             begin = end;
             first = false;
@@ -1154,10 +1165,17 @@ extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx
     hipLaunchKernelGGL(k_ts_gap, dim3(Q), dim3(64), 0, st, q, D, approx, ids, k, kk, kShadowEps, status);
     const int tiles = (kk + 15) / 16;
     const int64_t waves = (int64_t)Q * tiles;
-    const int tok = timing_begin(kTimeSelect, st);
-    hipLaunchKernelGGL(k_ts_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, idx, ids, Q, kk, exact);
-    hipLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ids, kk, k, row_id_base, out_score, out_index);
-    timing_end(tok, st);
+    hipEvent_t e0, e1;
+    if (timing_kernel_events(kTimeSelect, &e0, &e1))
+        hipExtLaunchKernelGGL(k_ts_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, e0, e1, 0, q, D, idx,
+                              (const int64_t*)ids, Q, kk, exact);
+    else
+        hipLaunchKernelGGL(k_ts_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, idx, ids, Q, kk, exact);
+    if (timing_kernel_events(kTimeSelect, &e0, &e1))
+        hipExtLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, e0, e1, 0, (const float*)exact,
+                              (const int64_t*)ids, kk, k, row_id_base, out_score, out_index);
+    else
+        hipLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ids, kk, k, row_id_base, out_score, out_index);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -56,6 +56,18 @@ int timing_begin(int cls, hipStream_t st) {
     return (int)g_spans.size() - 1;
 }
 
+bool timing_kernel_events(int cls, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (!g_timing_on) return false;
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    TimedSpan span{cls, take_event(), take_event()};
+    if (!span.start || !span.stop) return false;
+    g_spans.push_back(span);
+    *start = span.start;
+    *stop = span.stop;
+    return true;
+}
+
 void timing_end(int token, hipStream_t st) {
     if (token < 0) return;
     std::lock_guard<std::mutex> lock(g_timing_mu);
