@@ -117,6 +117,7 @@ __host__ __device__ inline uint32_t key_index(uint64_t key) { return 0xFFFFFFFFu
 // ---- block-wide exact top-k -----------------------------------------------------------------
 constexpr int kSelectThreads = 1024;
 constexpr int kSortCap = 8192;  // keys a block can sort in LDS (64 KiB)
+constexpr int kRadixUnroll = 4; // keys per thread per trip of the radix-select loops (loads issued together)
 
 struct SelectShared {
     uint64_t keys[kSortCap];
@@ -254,9 +255,15 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
         const int shift = pass * 8;
         for (int i = tid; i < 256; i += nt) sh.hist[i] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < cnt; i += nt) {
-            const uint64_t key = load(i);
-            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFF], 1u);
+        // kRadixUnroll keys per thread per trip, all loads issued before the first atomic: the loop is bound by the
+        // latency of the global loads (64 trips for the 65 536 keys of a dense first segment), not by their bytes
+        for (int64_t i0 = tid; i0 < cnt; i0 += (int64_t)kRadixUnroll * nt) {
+            uint64_t key[kRadixUnroll];
+#pragma unroll
+            for (int u = 0; u < kRadixUnroll; ++u) key[u] = i0 + (int64_t)u * nt < cnt ? load(i0 + (int64_t)u * nt) : 0ull;
+#pragma unroll
+            for (int u = 0; u < kRadixUnroll; ++u)
+                if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) == prefix) atomicAdd(&sh.hist[(key[u] >> shift) & 0xFF], 1u);
         }
         __syncthreads();
         radix_pick_digit(sh, (uint32_t)k - above);
@@ -271,12 +278,16 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
         if (above + in_bucket <= limit || pass == 0) {
             if (tid == 0) sh.scalar[0] = 0;
             __syncthreads();
-            for (int64_t i = tid; i < cnt; i += nt) {
-                const uint64_t key = load(i);
-                if ((key & mask) >= prefix) {
-                    const uint32_t pos = atomicAdd(&sh.scalar[0], 1u);
-                    if (pos < (uint32_t)kSortCap) sh.keys[pos] = key;
-                }
+            for (int64_t i0 = tid; i0 < cnt; i0 += (int64_t)kRadixUnroll * nt) {
+                uint64_t key[kRadixUnroll];
+#pragma unroll
+                for (int u = 0; u < kRadixUnroll; ++u) key[u] = i0 + (int64_t)u * nt < cnt ? load(i0 + (int64_t)u * nt) : 0ull;
+#pragma unroll
+                for (int u = 0; u < kRadixUnroll; ++u)
+                    if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) >= prefix) {
+                        const uint32_t pos = atomicAdd(&sh.scalar[0], 1u);
+                        if (pos < (uint32_t)kSortCap) sh.keys[pos] = key[u];
+                    }
             }
             __syncthreads();
             got = (int)sh.scalar[0];
@@ -310,9 +321,13 @@ __device__ inline uint64_t block_kth_largest(SelectShared& sh, Load load, int64_
         const int shift = pass * 8;
         for (int i = tid; i < 256; i += nt) sh.hist[i] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < cnt; i += nt) {
-            const uint64_t key = load(i);
-            if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFF], 1u);
+        for (int64_t i0 = tid; i0 < cnt; i0 += (int64_t)kRadixUnroll * nt) {
+            uint64_t key[kRadixUnroll];
+#pragma unroll
+            for (int u = 0; u < kRadixUnroll; ++u) key[u] = i0 + (int64_t)u * nt < cnt ? load(i0 + (int64_t)u * nt) : 0ull;
+#pragma unroll
+            for (int u = 0; u < kRadixUnroll; ++u)
+                if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) == prefix) atomicAdd(&sh.hist[(key[u] >> shift) & 0xFF], 1u);
         }
         __syncthreads();
         if (tid == 0) {
