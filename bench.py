@@ -130,7 +130,7 @@ def cpu_baseline(shard, queries, k, n_total, cpu_rows, budget_s):
     return ob.time_cosine_topk(q, x, k, n_total=n_total, budget_s=budget_s)
 
 
-def pmc_traffic_gbs(N, D, Q, k, world, kernel_ms_per_step):
+def pmc_traffic_gbs(N, D, Q, k, world, kernel_ms_per_step, method="scan"):
     """HBM traffic of the scan kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), as GB/s at this run's kernel time;
     null when no profile exists for this configuration (counters cannot be read inside the bench)."""
@@ -143,7 +143,7 @@ def pmc_traffic_gbs(N, D, Q, k, world, kernel_ms_per_step):
             with open(os.path.join(prof_dir, name)) as fh:
                 p = json.load(fh)
             c = p.get("config", {})
-            if (c.get("index_rows"), c.get("dim"), c.get("queries_per_step"), c.get("k")) == (N, D, Q, k):
+            if (c.get("index_rows"), c.get("dim"), c.get("queries_per_step"), c.get("k"), c.get("method", "scan")) == (N, D, Q, k, method):
                 best = p  # the latest round's file wins
     if best is None:
         return None
@@ -535,7 +535,8 @@ def main():
             "value": Q * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
             "identical_to_f32_scan": same, "proof_failed": failed, "extra_index_memory_bytes": int(shadow.numel()) * 2,
             "roofline": {"bound": "hbm", "achieved": b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0) / HBM_PEAK_GBS, "traffic": None,
+                         "frac": (b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0) / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_gbs(N, D, Q, k, world, sc2, "two_stage"),
                          "kernel": "k_cosine_score<F16=1> over the shadow", "algorithmic_bytes_per_step": b2,
                          "launches_per_step": l2[0] / args.steps, "kernel_ms_per_step": sc2,
                          "select_and_rescore_ms_per_step": ms2[1] / args.steps},
@@ -589,7 +590,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step) if (args.index_dtype == "f32" and method == "scan") else None,
+                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step, method) if args.index_dtype == "f32" else None,
                 "kernel": "k_cosine_score",
                 "algorithmic_bytes_per_step": bytes_per_step,
                 "launches_per_step": launches[0] / steps,

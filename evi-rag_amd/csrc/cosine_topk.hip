@@ -766,11 +766,24 @@ __global__ __launch_bounds__(256) void k_gt_rescore(const float* __restrict__ q,
     const f32x4* qp = reinterpret_cast<const f32x4*>(q + (int64_t)qi * D) + g;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < D / 16; ++j) {
-        const f32x4 x = xp[j * 4];
-        const f32x4 a = n == 0 ? qp[j * 4] : zero;
+    // eight 64-byte pieces of the row in flight per lane group: the rows are scattered over the index, so a loop that
+    // waits for each piece is bound by the HBM latency (48 round trips at D = 768); the MFMA order is unchanged
+    constexpr int PF = 8;
+    const int J = D / 16;
+    for (int j0 = 0; j0 < J; j0 += PF) {
+        f32x4 x[PF], a[PF];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], x[e], acc, 0, 0, 0);
+        for (int u = 0; u < PF; ++u)
+            if (j0 + u < J) {
+                x[u] = xp[(j0 + u) * 4];
+                a[u] = n == 0 ? qp[(j0 + u) * 4] : zero;
+            }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (j0 + u < J) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], x[u][e], acc, 0, 0, 0);
+            }
     }
     // D[row 0][col n] is register 0 of the lanes with g == 0
     if (g == 0 && c < kk) {
@@ -1037,22 +1050,6 @@ __global__ void k_shadow_f16(const float* __restrict__ x, int64_t n, _Float16* _
         out[i] = (_Float16)x[i];
 }
 
-// approx / ids: [Q, kk] as evi_cosine_topk_f16 wrote them (sorted, (-inf, -1) past the end of a short index)
-__global__ void k_ts_gap(const float* __restrict__ q, int D, const float* __restrict__ approx,
-                         const int64_t* __restrict__ ids, int k, int kk, float eps, int32_t* __restrict__ status) {
-    const int qi = blockIdx.x;
-    const int lane = threadIdx.x;  // one wave
-    float ss = 0.f;
-    for (int d = lane; d < D; d += 64) ss = fmaf(q[(int64_t)qi * D + d], q[(int64_t)qi * D + d], ss);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    if (lane == 0 && ids[(int64_t)qi * kk + kk - 1] >= 0) {  // otherwise every row of the index is in the list
-        const float* s = approx + (int64_t)qi * kk;
-        const float gap = s[k - 1] - s[kk - 1];
-        if (!(gap > 2.0f * eps * sqrtf(ss))) atomicOr(status, 1);  // also catches NaN scores
-    }
-}
-
 // k_gt_rescore for [Q, kk] i64 candidate ids (-1 = padding): one wave per (query, 16 candidates)
 __global__ __launch_bounds__(256) void k_ts_rescore(const float* __restrict__ q, int D, const float* __restrict__ idx,
                                                     const int64_t* __restrict__ ids, int Q, int kk,
@@ -1069,22 +1066,51 @@ __global__ __launch_bounds__(256) void k_ts_rescore(const float* __restrict__ q,
     const f32x4* qp = reinterpret_cast<const f32x4*>(q + (int64_t)qi * D) + g;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < D / 16; ++j) {
-        const f32x4 x = xp[j * 4];
-        const f32x4 a = n == 0 ? qp[j * 4] : zero;
+    // eight 64-byte pieces of the row in flight per lane group: the rows are scattered over the index, so a loop that
+    // waits for each piece is bound by the HBM latency (48 round trips at D = 768); the MFMA order is unchanged
+    constexpr int PF = 8;
+    const int J = D / 16;
+    for (int j0 = 0; j0 < J; j0 += PF) {
+        f32x4 x[PF], a[PF];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], x[e], acc, 0, 0, 0);
+        for (int u = 0; u < PF; ++u)
+            if (j0 + u < J) {
+                x[u] = xp[(j0 + u) * 4];
+                a[u] = n == 0 ? qp[(j0 + u) * 4] : zero;
+            }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (j0 + u < J) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], x[u][e], acc, 0, 0, 0);
+            }
     }
     if (g == 0 && c < kk) exact[(int64_t)qi * kk + c] = row >= 0 ? acc[0] : -INFINITY;
 }
 
+// Final top-k on the exact scores, and the proof: approx / ids are the [Q, kk] lists evi_cosine_topk_f16 wrote (sorted,
+// (-inf, -1) past the end of a short index); the true top-k is among them when approx[k-1] - approx[kk-1] > 2 eps |q|.
 __global__ __launch_bounds__(kSelectThreads) void k_ts_final(const float* __restrict__ exact, const int64_t* __restrict__ ids,
                                                              int kk, int k, int64_t row_id_base, float* __restrict__ out_score,
-                                                             int64_t* __restrict__ out_index) {
+                                                             int64_t* __restrict__ out_index, const float* __restrict__ q, int D,
+                                                             const float* __restrict__ approx, float eps,
+                                                             int32_t* __restrict__ status) {
     __shared__ SelectShared sh;
     const int qi = blockIdx.x;
     const float* es = exact + (int64_t)qi * kk;
     const int64_t* ci = ids + (int64_t)qi * kk;
+    if (threadIdx.x < 64) {  // wave 0: |q|^2 in a fixed order, then the gap test
+        const int lane = threadIdx.x;
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) ss = fmaf(q[(int64_t)qi * D + d], q[(int64_t)qi * D + d], ss);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (lane == 0 && ci[kk - 1] >= 0) {  // otherwise every row of the index is in the list
+            const float* s = approx + (int64_t)qi * kk;
+            const float gap = s[k - 1] - s[kk - 1];
+            if (!(gap > 2.0f * eps * sqrtf(ss))) atomicOr(status, 1);  // also catches NaN scores
+        }
+    }
     auto load = [&](int64_t i) -> uint64_t { return ci[i] >= 0 ? make_key(es[i], (uint32_t)ci[i]) : 0ull; };
     const int m = block_topk(sh, load, kk, k);
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
@@ -1161,8 +1187,7 @@ extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx
     // stage 1: kk best rows per query by shadow score (local row ids)
     const int rc = cosine_topk_impl(q, Q, shadow_f16, 1, N, D, nullptr, kk, 0, approx, ids, base + L.scan, L.scan_bytes, stream);
     if (rc != EVI_OK) return rc;
-    // stage 2: proof, exact scores from the f32 rows, final top-k
-    hipLaunchKernelGGL(k_ts_gap, dim3(Q), dim3(64), 0, st, q, D, approx, ids, k, kk, kShadowEps, status);
+    // stage 2: exact scores from the f32 rows, final top-k + proof
     const int tiles = (kk + 15) / 16;
     const int64_t waves = (int64_t)Q * tiles;
     hipEvent_t e0, e1;
@@ -1173,9 +1198,11 @@ extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx
         hipLaunchKernelGGL(k_ts_rescore, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, D, idx, ids, Q, kk, exact);
     if (timing_kernel_events(kTimeSelect, &e0, &e1))
         hipExtLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, e0, e1, 0, (const float*)exact,
-                              (const int64_t*)ids, kk, k, row_id_base, out_score, out_index);
+                              (const int64_t*)ids, kk, k, row_id_base, out_score, out_index, q, D, (const float*)approx,
+                              kShadowEps, status);
     else
-        hipLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ids, kk, k, row_id_base, out_score, out_index);
+        hipLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ids, kk, k, row_id_base, out_score, out_index,
+                           q, D, approx, kShadowEps, status);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -283,12 +283,19 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
 cosine_topk_gemm.last_products = None
 
 
-def index_shadow_f16(index: torch.Tensor) -> torch.Tensor:
-    """f16 copy (round to nearest) of an f32 index of unit rows (+ 50 % memory) for cosine_topk_two_stage."""
+def index_shadow_f16(index: torch.Tensor, *, check_norms: bool = True) -> torch.Tensor:
+    """f16 copy (round to nearest) of an f32 index of unit rows (+ 50 % memory) for cosine_topk_two_stage.
+    The exactness proof of the two-stage scan bounds the f16 rounding of a row by 2^-11 of its norm and assumes
+    norm <= 1 (normalize_embeddings output): check_norms verifies that once here (one pass + one read-back)."""
     dev = _require_gpu(index)
     x = _f32c(index, "index")
     if x.dim() != 2:
         raise ValueError("index must be 2D")
+    if check_norms and x.numel():
+        worst = float(row_norms(x).max().item())
+        if not worst <= 1.0 + 1e-4:
+            raise ValueError(f"index_shadow_f16 needs L2-normalised rows (largest row norm {worst:.6g}): "
+                             "run normalize_embeddings first")
     out = torch.empty(x.shape, dtype=torch.float16, device=dev)
     if x.numel():
         _lib.check(_lib.load().evi_index_shadow_f16(_ptr(x), x.size(0), x.size(1), _ptr(out), _stream(dev)))

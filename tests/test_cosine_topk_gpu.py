@@ -477,3 +477,5 @@ def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
         ops.cosine_topk_two_stage(qn, clustered, sh, 1500)  # k + reserve exceeds the selector's capacity
     with pytest.raises(ValueError):
         ops.cosine_topk_two_stage(qn, clustered, sh.to(torch.bfloat16), 50)
+    with pytest.raises(ValueError, match="L2-normalised"):
+        ops.index_shadow_f16(2.0 * clustered)  # the proof's bound assumes rows of norm <= 1
