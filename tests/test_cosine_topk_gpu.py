@@ -479,3 +479,38 @@ def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
         ops.cosine_topk_two_stage(qn, clustered, sh.to(torch.bfloat16), 50)
     with pytest.raises(ValueError, match="L2-normalised"):
         ops.index_shadow_f16(2.0 * clustered)  # the proof's bound assumes rows of norm <= 1
+
+
+@pytest.mark.parametrize("k", [1, 500, 1500])
+def test_segment_topk_long_lists_every_score_shape(dev, k):
+    """Lists long enough for the selector's linear pre-partition (>= 16 384 keys), with the score shapes that could
+    upset it: a narrow cluster plus a far outlier, heavy ties, all-equal scores, +-inf, NaN, denormals, a constant
+    list with one larger value.  The result must be the stable descending order, whatever the bucket spread."""
+    from evi_rag_amd import ops
+
+    rng = np.random.default_rng(100 + k)
+    n = 50000
+    lists = []
+    lists.append(rng.standard_normal(n).astype(np.float32) * 0.036)                     # cosine-like
+    a = rng.standard_normal(n).astype(np.float32) * 1e-3 + 5.0
+    a[123] = 1e30                                                                        # far outlier: everything else in one bucket
+    lists.append(a)
+    lists.append(rng.integers(0, 4, n).astype(np.float32))                               # four distinct values
+    lists.append(np.full(n, 0.5, np.float32))                                            # all equal
+    b = rng.standard_normal(n).astype(np.float32)
+    b[:700] = np.inf
+    b[700:1400] = -np.inf
+    b[1400:1500] = np.nan
+    lists.append(b)
+    lists.append((rng.standard_normal(n) * 1e-41).astype(np.float32))                    # denormals
+    c = np.zeros(n, np.float32)
+    c[n - 1] = 1.0
+    lists.append(c)
+    lists.append(-np.abs(rng.standard_normal(n).astype(np.float32)) * 1e20)             # huge negatives
+    scores = np.concatenate(lists)
+    ptr = (np.arange(len(lists) + 1) * n).astype(np.int64)
+    idx, val, cnt = ops.segment_topk(torch.from_numpy(scores).to(dev), torch.from_numpy(ptr).to(dev), k)
+    ridx, rval, rcnt = orank.segment_topk(scores, ptr, k)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(val.cpu().numpy(), rval, equal_nan=True)
