@@ -109,3 +109,21 @@ def test_shard_helpers():
     assert idx.world == 1 and (idx.row_begin, idx.row_end) == (0, 4)
     with pytest.raises(ValueError, match="must hold rows"):
         edist.ShardedIndex(torch.zeros(3, 8), 4)
+
+
+def test_sharded_index_two_stage_needs_its_shadow():
+    """Host-side contract of method="two_stage" (no GPU needed to refuse bad arguments)."""
+    import pytest
+    import torch
+
+    from evi_rag_amd.dist import ShardedIndex
+
+    rows = torch.zeros((8, 32))
+    with pytest.raises(ValueError, match="float16 shadow"):
+        ShardedIndex(rows, 8, method="two_stage")
+    with pytest.raises(ValueError, match="float16 shadow"):
+        ShardedIndex(rows, 8, method="two_stage", shadow=rows.to(torch.bfloat16))
+    with pytest.raises(ValueError, match="float16 shadow"):
+        ShardedIndex(rows, 8, method="two_stage", shadow=rows.to(torch.float16), row_scale=torch.ones(8))
+    idx = ShardedIndex(rows, 8, method="two_stage", shadow=rows.to(torch.float16))
+    assert idx.two_stage_status is not None and idx.two_stage_status.dtype == torch.int32 and not idx.two_stage_failed()
