@@ -1,5 +1,4 @@
 """CPU: composition of a reference-shaped config tree (hydra_lite) and the pure checks of the eval entry point."""
-import os
 from pathlib import Path
 
 import pytest
