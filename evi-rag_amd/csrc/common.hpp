@@ -117,7 +117,12 @@ __host__ __device__ inline uint32_t key_index(uint64_t key) { return 0xFFFFFFFFu
 // ---- block-wide exact top-k -----------------------------------------------------------------
 constexpr int kSelectThreads = 1024;
 constexpr int kSortCap = 8192;  // keys a block can sort in LDS (64 KiB)
-constexpr int kRadixUnroll = 4; // keys per thread per trip of the radix-select loops (loads issued together)
+// Keys per thread per trip of the radix-select loops.  The loads of a trip are UNCONDITIONAL (an index past the end is
+// clamped to the last entry and the key ignored afterwards): behind a per-key bounds branch the compiler waits for
+// every load before it issues the next, and the loop runs at one memory latency per key (~75 us for the three passes
+// over the 65 536 candidates of a dense first segment).
+constexpr int kRadixUnroll = 8;
+__device__ inline int64_t radix_clamp(int64_t i, int64_t cnt) { return i < cnt ? i : cnt - 1; }
 
 struct SelectShared {
     uint64_t keys[kSortCap];
@@ -260,7 +265,7 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
         for (int64_t i0 = tid; i0 < cnt; i0 += (int64_t)kRadixUnroll * nt) {
             uint64_t key[kRadixUnroll];
 #pragma unroll
-            for (int u = 0; u < kRadixUnroll; ++u) key[u] = i0 + (int64_t)u * nt < cnt ? load(i0 + (int64_t)u * nt) : 0ull;
+            for (int u = 0; u < kRadixUnroll; ++u) key[u] = load(radix_clamp(i0 + (int64_t)u * nt, cnt));
 #pragma unroll
             for (int u = 0; u < kRadixUnroll; ++u)
                 if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) == prefix) atomicAdd(&sh.hist[(key[u] >> shift) & 0xFF], 1u);
@@ -281,7 +286,7 @@ __device__ inline int block_topk(SelectShared& sh, Load load, int64_t cnt, int k
             for (int64_t i0 = tid; i0 < cnt; i0 += (int64_t)kRadixUnroll * nt) {
                 uint64_t key[kRadixUnroll];
 #pragma unroll
-                for (int u = 0; u < kRadixUnroll; ++u) key[u] = i0 + (int64_t)u * nt < cnt ? load(i0 + (int64_t)u * nt) : 0ull;
+                for (int u = 0; u < kRadixUnroll; ++u) key[u] = load(radix_clamp(i0 + (int64_t)u * nt, cnt));
 #pragma unroll
                 for (int u = 0; u < kRadixUnroll; ++u)
                     if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) >= prefix) {
@@ -324,7 +329,7 @@ __device__ inline uint64_t block_kth_largest(SelectShared& sh, Load load, int64_
         for (int64_t i0 = tid; i0 < cnt; i0 += (int64_t)kRadixUnroll * nt) {
             uint64_t key[kRadixUnroll];
 #pragma unroll
-            for (int u = 0; u < kRadixUnroll; ++u) key[u] = i0 + (int64_t)u * nt < cnt ? load(i0 + (int64_t)u * nt) : 0ull;
+            for (int u = 0; u < kRadixUnroll; ++u) key[u] = load(radix_clamp(i0 + (int64_t)u * nt, cnt));
 #pragma unroll
             for (int u = 0; u < kRadixUnroll; ++u)
                 if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) == prefix) atomicAdd(&sh.hist[(key[u] >> shift) & 0xFF], 1u);
