@@ -776,11 +776,11 @@ __global__ __launch_bounds__(256) void k_gt_rescore(const float* __restrict__ q,
     for (int j0 = 0; j0 < J; j0 += PF) {
         f32x4 x[PF], a[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (j0 + u < J) {
-                x[u] = xp[(j0 + u) * 4];
-                a[u] = n == 0 ? qp[(j0 + u) * 4] : zero;
-            }
+        for (int u = 0; u < PF; ++u) {  // unconditional loads (a piece past the end re-reads the last one): a bounds
+            const int j = j0 + u < J ? j0 + u : J - 1;  // branch here would make the compiler wait for each load in turn
+            x[u] = xp[j * 4];
+            a[u] = n == 0 ? qp[j * 4] : zero;
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if (j0 + u < J) {
@@ -1076,11 +1076,11 @@ __global__ __launch_bounds__(256) void k_ts_rescore(const float* __restrict__ q,
     for (int j0 = 0; j0 < J; j0 += PF) {
         f32x4 x[PF], a[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (j0 + u < J) {
-                x[u] = xp[(j0 + u) * 4];
-                a[u] = n == 0 ? qp[(j0 + u) * 4] : zero;
-            }
+        for (int u = 0; u < PF; ++u) {  // unconditional loads (a piece past the end re-reads the last one): a bounds
+            const int j = j0 + u < J ? j0 + u : J - 1;  // branch here would make the compiler wait for each load in turn
+            x[u] = xp[j * 4];
+            a[u] = n == 0 ? qp[j * 4] : zero;
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if (j0 + u < J) {
