@@ -38,9 +38,20 @@ constexpr int kCntStride = 64;                // one append cursor per 256 B: no
 constexpr int64_t kSegmentGrowth = 16;
 constexpr int64_t kMaxSegmentDefault = 1 << 24;  // recommended workspace: 8 B x 32 x (min(N, 2^24) + k)
 
+// every query-fragment kernel also resets the batch's selection state (thresholds and append cursors): one launch
+// fewer per batch than a separate reset kernel
+__device__ inline void reset_query_state(float* tau, int32_t* cnt) {
+    if (blockIdx.x == 0 && threadIdx.x < kQueryBlock) {
+        tau[threadIdx.x] = -INFINITY;
+        cnt[threadIdx.x * kCntStride] = 0;
+    }
+}
+
 // q [Q, D] -> qfrag[((j*4 + g) * (NQB*16) + i) * 4 + t] = q[i][16 j + 4 g + t], zero for i >= Q.
 __global__ void k_query_fragments(const float* __restrict__ q, int Q, int D, int nq_pad,
-                                  float* __restrict__ qfrag) {
+                                  float* __restrict__ qfrag, float* __restrict__ tau,
+                                  int32_t* __restrict__ cnt) {
+    reset_query_state(tau, cnt);
     const int total = (D / 16) * 4 * nq_pad;  // float4 slots
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
         const int i = s % nq_pad;
@@ -58,7 +69,9 @@ __global__ void k_query_fragments(const float* __restrict__ q, int Q, int D, int
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kLoScale = 2048.0f;
 __global__ void k_query_fragments_f16(const float* __restrict__ q, int Q, int D, int nq_pad,
-                                      f16x8* __restrict__ qfrag) {
+                                      f16x8* __restrict__ qfrag, float* __restrict__ tau,
+                                  int32_t* __restrict__ cnt) {
+    reset_query_state(tau, cnt);
     const int total = (D / 32) * 4 * nq_pad;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
         const int i = s % nq_pad;
@@ -80,7 +93,9 @@ __global__ void k_query_fragments_f16(const float* __restrict__ q, int Q, int D,
 // 16 g .. 16 g + 15 and feeds them to two f16 MFMA K-steps (m = 0: bytes 0-7, m = 1: bytes 8-15).
 //   qfrag8[(((J*2 + m)*4 + g)*2 + part) * nq_pad + i] = 8 halves of q[i][64 J + 16 g + 8 m .. + 7]
 __global__ void k_query_fragments_fp8(const float* __restrict__ q, int Q, int D, int nq_pad,
-                                      f16x8* __restrict__ qfrag) {
+                                      f16x8* __restrict__ qfrag, float* __restrict__ tau,
+                                  int32_t* __restrict__ cnt) {
+    reset_query_state(tau, cnt);
     const int total = (D / 64) * 8 * nq_pad;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
         const int i = s % nq_pad;
@@ -106,13 +121,6 @@ __device__ inline uint32_t fp8x2_to_f16x2_scaled(uint32_t w, uint32_t sel) {
     return (p & 0x80008000u) | ((p >> 1) & 0x3F803F80u);
 }
 
-__global__ void k_init_state(float* tau, int32_t* cnt, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        tau[i] = -INFINITY;
-        cnt[i * kCntStride] = 0;
-    }
-}
 
 // One pass over rows [seg_begin, seg_end) of the shard.
 //   NQB: query blocks of 16 (1 or 2).  U: float4 loads in flight per lane per prefetch group
@@ -570,17 +578,15 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
         float* o_score = out_score + (int64_t)q0 * k;
         int64_t* o_index = out_index + (int64_t)q0 * k;
 
-        hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, st, tau, cnt, kQueryBlock);
-        EVI_LAUNCH_CHECK();
         if (f16 == 2)
             hipLaunchKernelGGL(k_query_fragments_fp8, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
-                               reinterpret_cast<f16x8*>(qfrag));
+                               reinterpret_cast<f16x8*>(qfrag), tau, cnt);
         else if (f16)
             hipLaunchKernelGGL(k_query_fragments_f16, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
-                               reinterpret_cast<f16x8*>(qfrag));
+                               reinterpret_cast<f16x8*>(qfrag), tau, cnt);
         else
             hipLaunchKernelGGL(k_query_fragments, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D,
-                               nq_pad, qfrag);
+                               nq_pad, qfrag, tau, cnt);
         EVI_LAUNCH_CHECK();
 
         if (N == 0) {
