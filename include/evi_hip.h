@@ -53,9 +53,12 @@ int evi_version(void);
  * number of bytes the full message needs (excluding the NUL). */
 size_t evi_last_error(char* buf, size_t buf_bytes);
 
-/* Optional per-kernel timing for the bench's roofline leg.  While enabled, each call brackets its
+/* Optional per-kernel timing for the bench's roofline leg.  While enabled, each call times its
  * dominant kernels with hipEvents on the call's stream (class 0: the cosine scan kernel,
- * class 1: top-k selection kernels, class 2: scorer GEMMs, class 3: edge-feature kernel).  evi_timing_read synchronises those events, writes the summed
+ * class 1: top-k selection / re-scoring kernels, class 2: scorer GEMMs, class 3: edge-feature kernel).  The scan and
+ * selection kernels are launched with hipExtLaunchKernelGGL start / stop events, which carry the dispatch's own begin
+ * and end times and put nothing between the kernels of the stream; the scorer classes bracket groups of kernels with
+ * recorded events.  evi_timing_read synchronises those events, writes the summed
  * milliseconds and launch counts per class into HOST arrays of n_classes entries, and clears the
  * log.  Calls made while timing is enabled must not be captured into a hipGraph. */
 int evi_timing_enable(int on);
