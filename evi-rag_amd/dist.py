@@ -40,7 +40,7 @@ def _default_local_topk(queries, shard, k, row_id_base, row_scale=None, method="
     return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale, method=method)
 
 
-def _local_scan(self: "ShardedIndex", queries, k, out, workspace):
+def _local_scan(self: "ShardedIndex", queries, k, out, workspace, lane: int = 0):
     """The shard's exact top-k into `out` on the current stream, without a read-back.  method "two_stage": the f16
     shadow is scanned and the f32 rows re-score (ops.cosine_topk_two_stage); a failed proof is OR-ed into
     self.two_stage_status, which the caller checks once per stream of batches (`two_stage_failed`)."""
@@ -48,7 +48,7 @@ def _local_scan(self: "ShardedIndex", queries, k, out, workspace):
 
     if self.method == "two_stage":
         return ops.cosine_topk_two_stage(queries, self.shard, self.shadow, k, row_id_base=self.row_begin, out=out,
-                                         status=self.two_stage_status, workspace=self._two_stage_workspace(queries, k))
+                                         status=self.two_stage_status, workspace=self._two_stage_workspace(queries, k, lane))
     return ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
                            workspace=workspace, out=out, method=self.method)
 
@@ -80,7 +80,7 @@ class ShardedIndex:
         self.method = method
         self.shadow = shadow
         self.two_stage_status: Optional[torch.Tensor] = None
-        self._ts_ws: Optional[torch.Tensor] = None
+        self._ts_ws: List[Optional[torch.Tensor]] = [None, None]  # one per pipeline lane
         if method == "two_stage":
             if row_scale is not None or shadow is None or shadow.shape != local_rows.shape or shadow.dtype != torch.float16:
                 raise ValueError("method 'two_stage' needs an L2-normalised f32 shard (no row_scale) and its float16 shadow")
@@ -101,18 +101,21 @@ class ShardedIndex:
         self._packed_all: Optional[torch.Tensor] = None
         self.workspace: Optional[torch.Tensor] = None
         self._pipe = None
+        self._lanes = None
+        # topk_async with an exchange: two pipeline lanes (see _topk_async) or, when False, one main stream + a side stream
+        self.two_lanes = os.environ.get("EVI_TWO_LANES", "1") != "0"
         # EVI_FORCE_EXCHANGE=1 runs the exchange even with one rank (rehearses the multi-rank path on one GPU)
         self._exchange = self.world > 1 or (os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and dist.is_initialized())
 
-    def _two_stage_workspace(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+    def _two_stage_workspace(self, queries: torch.Tensor, k: int, lane: int = 0) -> torch.Tensor:
         from . import _lib
 
         need = int(_lib.load().evi_cosine_topk_two_stage_workspace_bytes(queries.size(0), self.shard.size(0), self.shard.size(1), int(k)))
         if need == 0:
             raise ValueError(f"k + max(256, k // 2) must not exceed 2048, got k = {k}")
-        if self._ts_ws is None or self._ts_ws.numel() < need:
-            self._ts_ws = torch.empty(need, dtype=torch.uint8, device=self.shard.device)
-        return self._ts_ws
+        if self._ts_ws[lane] is None or self._ts_ws[lane].numel() < need:
+            self._ts_ws[lane] = torch.empty(need, dtype=torch.uint8, device=self.shard.device)
+        return self._ts_ws[lane]
 
     def two_stage_failed(self) -> bool:
         """True when some batch since the last call could not be proven exact (one read-back; resets the flag): the
@@ -190,6 +193,8 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
         ev.record(main)
         return s, i, ev
     Q = queries.size(0)
+    if self.two_lanes:
+        return _topk_async_lanes(self, queries, k, main)
     p = self._pipe
     # The side stream is a HIGH-PRIORITY stream: that gives it a hardware queue of its own.  As a normal-priority stream it
     # shared the main stream's queue (rocprofv3 kernel trace: same Queue_Id, the next batch's first kernel starting only
@@ -216,6 +221,43 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
         p["xchg_done"][slot].record(side)
     p["used"][slot] = True
     return p["out_s"][slot], p["out_i"][slot], p["xchg_done"][slot]
+
+
+def _topk_async_lanes(self: "ShardedIndex", queries: torch.Tensor, k: int, main):
+    """Two pipeline lanes: batches alternate between two streams on two hardware queues (one normal-, one high-priority
+    stream), each lane with its own scan workspace, packed record and outputs, and each batch runs ENTIRELY on its lane —
+    scan, selections, all-gather, merge.  While one lane is in a selection (32 of 256 CUs busy) or in the exchange, the
+    other lane's scan has the machine: measured on a 1/8 shard (2^20 rows), 0.61 ms per batch against 0.66 ms on one stream
+    (0.37 against 0.43 ms for the two-stage scan); results are unchanged.  Per-kernel event times taken while two lanes
+    run include the time a kernel waits for CUs, so the bench times its kernels in single-lane warm-up steps."""
+    from . import _lib, ops
+
+    dev = queries.device
+    Q = queries.size(0)
+    p = self._lanes
+    if p is None or p["shape"] != (Q, k) or p["dev"] != dev:
+        rec = int(_lib.load().evi_topk_packed_bytes(Q, k))
+        mk = lambda n, dt: [torch.empty(n, dtype=dt, device=dev) for _ in range(2)]  # noqa: E731
+        need = ops.cosine_topk_workspace_bytes(Q, self.shard.size(0), self.shard.size(1), k)
+        ws0 = self.workspace if (self.workspace is not None and self.workspace.numel() >= need) else torch.empty(need, dtype=torch.uint8, device=dev)
+        p = self._lanes = {"shape": (Q, k), "dev": dev, "slot": 0,
+                           "streams": [torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1)],
+                           "ws": [ws0, torch.empty(need, dtype=torch.uint8, device=dev)],
+                           "local": mk(rec, torch.uint8), "all": mk(self.world * rec, torch.uint8),
+                           "out_s": mk((Q, k), torch.float32), "out_i": mk((Q, k), torch.int64),
+                           "done": [torch.cuda.Event() for _ in range(2)]}
+    slot = p["slot"]
+    p["slot"] = slot ^ 1
+    lane = p["streams"][slot]
+    lane.wait_stream(main)  # the queries (and whatever else the caller enqueued) are ready
+    queries.record_stream(lane)
+    with torch.cuda.stream(lane):
+        sv, iv = ops.topk_packed_views(p["local"][slot], Q, k)
+        _local_scan(self, queries, k, (sv, iv), p["ws"][slot], lane=slot)
+        dist.all_gather_into_tensor(p["all"][slot], p["local"][slot], group=self.group)
+        ops.topk_merge_packed(p["all"][slot], self.world, Q, k, out=(p["out_s"][slot], p["out_i"][slot]))
+        p["done"][slot].record(lane)
+    return p["out_s"][slot], p["out_i"][slot], p["done"][slot]
 
 
 ShardedIndex._topk_packed = _topk_packed

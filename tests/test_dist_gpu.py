@@ -44,6 +44,14 @@ def test_pipelined_exchange_one_rank_group(dev, monkeypatch):
         for b in (steps - 2, steps - 1):
             assert torch.equal(outs[b][1], want[b][1]) and torch.equal(outs[b][0], want[b][0]), b
         assert outs[steps - 1][0].data_ptr() == outs[steps - 3][0].data_ptr()  # two alternating slots
+        # the same with one main stream + a side stream for the exchange instead of two pipeline lanes
+        assert idx.two_lanes
+        idx.two_lanes = False
+        outs = [idx.topk_async(qs[b], k) for b in range(steps)]
+        torch.cuda.synchronize(dev)
+        for b in (steps - 2, steps - 1):
+            assert torch.equal(outs[b][1], want[b][1]) and torch.equal(outs[b][0], want[b][0]), b
+        idx.two_lanes = True
         # the same through the two-stage exact scan (f16 shadow selects, f32 rows re-score): identical results, the
         # proof flag is sticky across the stream of batches and read once
         idx2 = ShardedIndex(xn, N, method="two_stage", shadow=ops.index_shadow_f16(xn))
