@@ -6,9 +6,11 @@ top-k", concrete shapes from SURVEY.md §8(d) config 2): a synthetic L2-normalis
 N = 2^23 rows x D = 768 f32 (25.8 GB) resident in HBM; one step = one batch of Q = 32 question
 embeddings -> exact cosine top-500 row ids + scores.  With --gpus P > 1 the SAME index is
 row-sharded over the ranks (strong scaling): per-shard top-k, one RCCL all-gather of the packed
-[Q, k] lists, merge on every rank.
+[Q, k] lists, merge on every rank, batches alternating between two pipeline lanes.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: `value` / `roofline` / `cpu_baseline` for the f32 scan, plus extra objects that are
+not part of `value`: `two_stage` (the same batches through the f16-shadow + f32 re-scoring scan, checked bit for bit
+against the f32 scan), `graph_eval` (scorer + metrics + evaluation loop), `encode` (text-encoding stage).
 """
 from __future__ import annotations
 
