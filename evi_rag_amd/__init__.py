@@ -1,14 +1,8 @@
-"""Importable alias of the `evi-rag_amd/` package directory (a hyphen is not a valid module name).
+"""evi_rag_amd — MI355X-native retriever hot path for EVI-RAG (C-ABI HIP library + host mirror).
 
-`import evi_rag_amd` executes evi-rag_amd/__init__.py with this package's __path__ pointing at
-that directory, so `evi_rag_amd.ops`, `evi_rag_amd._lib`, ... resolve to the files there.
+The repository also carries the name `evi-rag_amd/` as a symlink to this directory (a hyphen is not importable).
 """
-import os as _os
+from . import _lib  # noqa: F401
+from . import ops  # noqa: F401
 
-_real = _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), _os.pardir, "evi-rag_amd"))
-if not _os.path.isdir(_real):
-    raise ImportError(f"package directory {_real} is missing")
-__path__ = [_real]
-__file__ = _os.path.join(_real, "__init__.py")
-with open(__file__, "r", encoding="utf-8") as _fh:
-    exec(compile(_fh.read(), __file__, "exec"), globals())
+__all__ = ["_lib", "ops"]

@@ -142,7 +142,7 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise EviLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C evi-rag_amd/csrc` (there is no CPU fallback)."
+            "or `make -C evi_rag_amd/csrc` (there is no CPU fallback)."
         )
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in _SIGNATURES.items():
