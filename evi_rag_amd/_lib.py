@@ -86,7 +86,7 @@ _SIGNATURES = {
     "evi_index_shadow_bf16": (c_int, [_P, c_int64, c_int, _P, _P]),
     "evi_index_shadow_f16": (c_int, [_P, c_int64, c_int, _P, _P]),
     "evi_cosine_topk_two_stage_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
-    "evi_cosine_topk_two_stage": (c_int, [_P, c_int, _P, _P, c_int64, c_int, c_int, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+    "evi_cosine_topk_two_stage": (c_int, [_P, c_int, _P, _P, c_int64, c_int, c_int, c_int64, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "evi_cosine_topk_gemm_f16": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "evi_topk_merge": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "evi_topk_packed_bytes": (c_size_t, [c_int, c_int]),

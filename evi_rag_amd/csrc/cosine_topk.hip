@@ -38,6 +38,14 @@ constexpr int kCntStride = 64;                // one append cursor per 256 B: no
 constexpr int64_t kSegmentGrowth = 16;
 constexpr int64_t kMaxSegmentDefault = 1 << 24;  // recommended workspace: 8 B x 32 x (min(N, 2^24) + k)
 
+// Device-side gate: a scan enqueued as the FALLBACK of a proof-carrying fast path (two-stage scan) takes a pointer to that
+// path's per-call status word; while the word is 0 (proof held) every kernel of the fallback returns at once, so the
+// fallback costs a few empty launches and no read-back, and a failed proof is repaired on the device before anyone can
+// consume the unproven result.  gate == nullptr: an ordinary, unconditional scan.
+__device__ inline bool gate_closed(const int32_t* gate) {
+    return gate != nullptr && *gate == 0;  // written by an earlier kernel of the same stream
+}
+
 // every query-fragment kernel also resets the batch's selection state (thresholds and append cursors): one launch
 // fewer per batch than a separate reset kernel
 __device__ inline void reset_query_state(float* tau, int32_t* cnt) {
@@ -50,7 +58,8 @@ __device__ inline void reset_query_state(float* tau, int32_t* cnt) {
 // q [Q, D] -> qfrag[((j*4 + g) * (NQB*16) + i) * 4 + t] = q[i][16 j + 4 g + t], zero for i >= Q.
 __global__ void k_query_fragments(const float* __restrict__ q, int Q, int D, int nq_pad,
                                   float* __restrict__ qfrag, float* __restrict__ tau,
-                                  int32_t* __restrict__ cnt) {
+                                  int32_t* __restrict__ cnt, const int32_t* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     reset_query_state(tau, cnt);
     const int total = (D / 16) * 4 * nq_pad;  // float4 slots
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
@@ -70,7 +79,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kLoScale = 2048.0f;
 __global__ void k_query_fragments_f16(const float* __restrict__ q, int Q, int D, int nq_pad,
                                       f16x8* __restrict__ qfrag, float* __restrict__ tau,
-                                  int32_t* __restrict__ cnt) {
+                                      int32_t* __restrict__ cnt, const int32_t* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     reset_query_state(tau, cnt);
     const int total = (D / 32) * 4 * nq_pad;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
@@ -94,7 +104,8 @@ __global__ void k_query_fragments_f16(const float* __restrict__ q, int Q, int D,
 //   qfrag8[(((J*2 + m)*4 + g)*2 + part) * nq_pad + i] = 8 halves of q[i][64 J + 16 g + 8 m .. + 7]
 __global__ void k_query_fragments_fp8(const float* __restrict__ q, int Q, int D, int nq_pad,
                                       f16x8* __restrict__ qfrag, float* __restrict__ tau,
-                                  int32_t* __restrict__ cnt) {
+                                      int32_t* __restrict__ cnt, const int32_t* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     reset_query_state(tau, cnt);
     const int total = (D / 64) * 8 * nq_pad;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
@@ -137,7 +148,8 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     const float* __restrict__ qfrag, const void* __restrict__ idx, int64_t seg_begin,
     int64_t seg_end, int D, int Q, const float* __restrict__ row_scale,
     const float* __restrict__ tau, float* __restrict__ cand_score, int32_t* __restrict__ cand_id,
-    int32_t* __restrict__ cand_cnt, int64_t cap, int dense, int capq) {
+    int32_t* __restrict__ cand_cnt, int64_t cap, int dense, int capq, const int32_t* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     extern __shared__ float4 lds_q[];  // [(D/16)*4][NQB*16] float4, then the append staging area
     constexpr int NQ = NQB * 16;
     constexpr int WAVES = THREADS / 64;
@@ -323,7 +335,9 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
 __global__ __launch_bounds__(kSelectThreads) void k_candidates_select(
     float* __restrict__ cand_score, int32_t* __restrict__ cand_id, int32_t* __restrict__ cand_cnt,
     float* __restrict__ tau, int64_t cap, int k, int64_t dense_count, int final_pass,
-    int64_t row_id_base, float* __restrict__ out_score, int64_t* __restrict__ out_index) {
+    int64_t row_id_base, float* __restrict__ out_score, int64_t* __restrict__ out_index,
+    const int32_t* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     __shared__ SelectShared sh;
     const int qi = blockIdx.x;
     const float* cs = cand_score + qi * cap;
@@ -421,6 +435,7 @@ struct ScoreArgs {
     int32_t* cc;
     int64_t cap;
     int dense, capq;
+    const int32_t* gate;
     hipEvent_t ev_start, ev_stop;  // non-null: stamped with the dispatch's begin / end (bench roofline leg)
 };
 
@@ -435,11 +450,11 @@ static int launch_score(const ScoreArgs& a) {
     if (a.ev_start)
         hipExtLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT, F16>), dim3(a.grid), dim3(THREADS), (uint32_t)a.lds, a.st,
                               a.ev_start, a.ev_stop, 0, a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci,
-                              a.cc, a.cap, a.dense, a.capq);
+                              a.cc, a.cap, a.dense, a.capq, a.gate);
     else
         hipLaunchKernelGGL((k_cosine_score<NQB, U, THREADS, NT, F16>), dim3(a.grid), dim3(THREADS), a.lds, a.st,
                            a.qfrag, a.idx, a.b, a.e, a.D, a.Q, a.row_scale, a.tau, a.cs, a.ci, a.cc, a.cap,
-                           a.dense, a.capq);
+                           a.dense, a.capq, a.gate);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
@@ -521,7 +536,8 @@ extern "C" size_t evi_cosine_topk_min_workspace_bytes(int Q, int64_t N, int D, i
 
 static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int64_t N, int D,
                             const float* row_scale, int k, int64_t row_id_base, float* out_score,
-                            int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream) {
+                            int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream,
+                            const int32_t* gate = nullptr) {
     EVI_REQUIRE(Q >= 1, "evi_cosine_topk: Q must be >= 1, got %d", Q);
     EVI_REQUIRE(N >= 0, "evi_cosine_topk: N must be >= 0, got %lld", (long long)N);
     EVI_REQUIRE(N < (int64_t)0x7FFFFFFF, "evi_cosine_topk: a shard holds at most 2^31-1 rows, got %lld",
@@ -580,18 +596,18 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
 
         if (f16 == 2)
             hipLaunchKernelGGL(k_query_fragments_fp8, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
-                               reinterpret_cast<f16x8*>(qfrag), tau, cnt);
+                               reinterpret_cast<f16x8*>(qfrag), tau, cnt, gate);
         else if (f16)
             hipLaunchKernelGGL(k_query_fragments_f16, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
-                               reinterpret_cast<f16x8*>(qfrag), tau, cnt);
+                               reinterpret_cast<f16x8*>(qfrag), tau, cnt, gate);
         else
             hipLaunchKernelGGL(k_query_fragments, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D,
-                               nq_pad, qfrag, tau, cnt);
+                               nq_pad, qfrag, tau, cnt, gate);
         EVI_LAUNCH_CHECK();
 
         if (N == 0) {
             hipLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, cs, ci, cnt,
-                               tau, w.cap, k, (int64_t)0, 1, row_id_base, o_score, o_index);
+                               tau, w.cap, k, (int64_t)0, 1, row_id_base, o_score, o_index, gate);
             EVI_LAUNCH_CHECK();
             continue;
         }
@@ -611,22 +627,22 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
             int64_t want = (tiles + waves_per_block - 1) / waves_per_block;
             const int grid = (int)(want < cus ? want : cus);
             ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
-                         cs, ci, cnt, w.cap, first ? 1 : 0, capq, nullptr, nullptr};
-            timing_kernel_events(kTimeCosineScore, &sa.ev_start, &sa.ev_stop);
+                         cs, ci, cnt, w.cap, first ? 1 : 0, capq, gate, nullptr, nullptr};
+            if (!gate) timing_kernel_events(kTimeCosineScore, &sa.ev_start, &sa.ev_stop);  // gated launches stay out of the accounts
             const int rc = f16 == 2 ? (nqb == 1 ? launch_score_lowp<1, 2>(U, sa) : launch_score_lowp<2, 2>(U, sa))
                            : f16  ? (nqb == 1 ? launch_score_lowp<1, 1>(U, sa) : launch_score_lowp<2, 1>(U, sa))
                                   : (nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa));
             if (rc != EVI_OK) return rc;
             const int final_pass = end >= N ? 1 : 0;
             hipEvent_t sel_start, sel_stop;
-            if (timing_kernel_events(kTimeSelect, &sel_start, &sel_stop))
+            if (!gate && timing_kernel_events(kTimeSelect, &sel_start, &sel_stop))
                 hipExtLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, sel_start, sel_stop, 0, cs, ci,
                                       cnt, tau, w.cap, k, first ? (end - begin) : (int64_t)-1, final_pass, row_id_base, o_score,
-                                      o_index);
+                                      o_index, gate);
             else
                 hipLaunchKernelGGL(k_candidates_select, dim3(qn), dim3(kSelectThreads), 0, st, cs, ci, cnt,
                                    tau, w.cap, k, first ? (end - begin) : (int64_t)-1, final_pass,
-                                   row_id_base, o_score, o_index);
+                                   row_id_base, o_score, o_index, gate);
             EVI_LAUNCH_CHECK();
             begin = end;
             first = false;
@@ -982,7 +998,8 @@ static int cosine_topk_gemm_impl(const float* q, int Q, const void* idx, int f16
         }
         hipLaunchKernelGGL(k_gt_clamp, dim3((Q + 255) / 256), dim3(256), 0, st, cnt, Q);
         hipLaunchKernelGGL(k_candidates_select, dim3(Q), dim3(kSelectThreads), 0, st, cs, ci, cnt, tau,
-                           (int64_t)kGemmTopkCap, kk, (int64_t)-1, 0, row_id_base, (float*)nullptr, (int64_t*)nullptr);
+                           (int64_t)kGemmTopkCap, kk, (int64_t)-1, 0, row_id_base, (float*)nullptr, (int64_t*)nullptr,
+                           (const int32_t*)nullptr);
         EVI_LAUNCH_CHECK();
         begin += rows;
         int64_t next = begin * kGemmGrowth;
@@ -1103,7 +1120,7 @@ __global__ __launch_bounds__(kSelectThreads) void k_ts_final(const float* __rest
                                                              int kk, int k, int64_t row_id_base, float* __restrict__ out_score,
                                                              int64_t* __restrict__ out_index, const float* __restrict__ q, int D,
                                                              const float* __restrict__ approx, float eps,
-                                                             int32_t* __restrict__ status) {
+                                                             int32_t* __restrict__ status, int32_t* __restrict__ call_flag) {
     __shared__ SelectShared sh;
     const int qi = blockIdx.x;
     const float* es = exact + (int64_t)qi * kk;
@@ -1117,7 +1134,10 @@ __global__ __launch_bounds__(kSelectThreads) void k_ts_final(const float* __rest
         if (lane == 0 && ci[kk - 1] >= 0) {  // otherwise every row of the index is in the list
             const float* s = approx + (int64_t)qi * kk;
             const float gap = s[k - 1] - s[kk - 1];
-            if (!(gap > 2.0f * eps * sqrtf(ss))) atomicOr(status, 1);  // also catches NaN scores
+            if (!(gap > 2.0f * eps * sqrtf(ss))) {  // also catches NaN scores
+                if (status) atomicOr(status, 1);  // the caller's sticky flag (a pipeline of batches shares it)
+                atomicOr(call_flag, 1);           // this call's own flag: opens the gate of the fallback scan
+            }
         }
     }
     auto load = [&](int64_t i) -> uint64_t { return ci[i] >= 0 ? make_key(es[i], (uint32_t)ci[i]) : 0ull; };
@@ -1135,7 +1155,7 @@ __global__ __launch_bounds__(kSelectThreads) void k_ts_final(const float* __rest
 }
 
 struct TsLayout {
-    size_t approx, ids, exact, scan, scan_bytes, total;
+    size_t flag, approx, ids, exact, scan, scan_bytes, total;
 };
 static TsLayout ts_layout(int Q, int64_t N, int D, int k) {
     TsLayout L;
@@ -1146,6 +1166,7 @@ static TsLayout ts_layout(int Q, int64_t N, int D, int k) {
         off = align_up(off + bytes, 256);
         return at;
     };
+    L.flag = take(sizeof(int32_t));  // this call's proof flag (gate of the device-side fallback)
     L.approx = take((size_t)Q * kk * sizeof(float));
     L.ids = take((size_t)Q * kk * sizeof(int64_t));
     L.exact = take((size_t)Q * kk * sizeof(float));
@@ -1174,7 +1195,7 @@ extern "C" size_t evi_cosine_topk_two_stage_workspace_bytes(int Q, int64_t N, in
 
 extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx, const void* shadow_f16, int64_t N, int D,
                                          int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+                                         int device_fallback, void* workspace, size_t workspace_bytes, void* stream) {
     EVI_REQUIRE(Q >= 1 && N >= 1, "evi_cosine_topk_two_stage: need Q >= 1 and N >= 1, got Q=%d N=%lld", Q, (long long)N);
     EVI_REQUIRE(k >= 1, "evi_cosine_topk_two_stage: k must be >= 1, got %d", k);
     if (D < 32 || D % 32 != 0 || D > 1280)
@@ -1183,8 +1204,9 @@ extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx
     if (kk > EVI_TOPK_MAX_K)
         return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_two_stage: k + reserve = %d exceeds %d (k <= %d)", kk, EVI_TOPK_MAX_K,
                     EVI_TOPK_MAX_K * 2 / 3);
-    EVI_REQUIRE(q && idx && shadow_f16 && out_score && out_index && status && workspace,
-                "evi_cosine_topk_two_stage: null pointer");
+    EVI_REQUIRE(q && idx && shadow_f16 && out_score && out_index && workspace, "evi_cosine_topk_two_stage: null pointer");
+    EVI_REQUIRE(status || device_fallback,
+                "evi_cosine_topk_two_stage: without the device-side fallback the caller must pass a status word and check it");
     const TsLayout L = ts_layout(Q, N, D, k);
     if (workspace_bytes < L.total)
         return fail(EVI_ERR_NOMEM, "evi_cosine_topk_two_stage: workspace %zu B < %zu B", workspace_bytes, L.total);
@@ -1193,6 +1215,8 @@ extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx
     float* approx = reinterpret_cast<float*>(base + L.approx);
     int64_t* ids = reinterpret_cast<int64_t*>(base + L.ids);
     float* exact = reinterpret_cast<float*>(base + L.exact);
+    int32_t* call_flag = reinterpret_cast<int32_t*>(base + L.flag);
+    EVI_HIP_CHECK(hipMemsetAsync(call_flag, 0, sizeof(int32_t), st));
     // stage 1: kk best rows per query by shadow score (local row ids)
     const int rc = cosine_topk_impl(q, Q, shadow_f16, 1, N, D, nullptr, kk, 0, approx, ids, base + L.scan, L.scan_bytes, stream);
     if (rc != EVI_OK) return rc;
@@ -1208,10 +1232,19 @@ extern "C" int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx
     if (timing_kernel_events(kTimeSelect, &e0, &e1))
         hipExtLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, e0, e1, 0, (const float*)exact,
                               (const int64_t*)ids, kk, k, row_id_base, out_score, out_index, q, D, (const float*)approx,
-                              kShadowEps, status);
+                              kShadowEps, status, call_flag);
     else
         hipLaunchKernelGGL(k_ts_final, dim3(Q), dim3(kSelectThreads), 0, st, exact, ids, kk, k, row_id_base, out_score, out_index,
-                           q, D, approx, kShadowEps, status);
+                           q, D, approx, kShadowEps, status, call_flag);
     EVI_LAUNCH_CHECK();
+    if (device_fallback) {
+        // The f32 scan of the same batch into the same outputs, gated on this call's flag: while the proof held every
+        // kernel returns at once (a few empty launches); when it failed the scan overwrites the unproven result before any
+        // later work of the stream can read it.  No read-back, no agreement between ranks needed: each shard's record is
+        // exact when it leaves the device.  The stage-1 scan workspace is free again and large enough (kk >= k).
+        const int rc2 = cosine_topk_impl(q, Q, idx, 0, N, D, nullptr, k, row_id_base, out_score, out_index, base + L.scan,
+                                         L.scan_bytes, stream, call_flag);
+        if (rc2 != EVI_OK) return rc2;
+    }
     return EVI_OK;
 }

@@ -42,13 +42,16 @@ def _default_local_topk(queries, shard, k, row_id_base, row_scale=None, method="
 
 def _local_scan(self: "ShardedIndex", queries, k, out, workspace, lane: int = 0):
     """The shard's exact top-k into `out` on the current stream, without a read-back.  method "two_stage": the f16
-    shadow is scanned and the f32 rows re-score (ops.cosine_topk_two_stage); a failed proof is OR-ed into
-    self.two_stage_status, which the caller checks once per stream of batches (`two_stage_failed`)."""
+    shadow is scanned and the f32 rows re-score (ops.cosine_topk_two_stage) with the DEVICE-SIDE fallback: a batch whose
+    exactness proof fails is re-done by the gated f32 scan before the record leaves the device, so what a rank
+    contributes to the exchange is always exact and the ranks need no agreement.  self.two_stage_status only records
+    that a fallback ran somewhere in the stream of batches (`two_stage_failed`, informational)."""
     from . import ops
 
     if self.method == "two_stage":
         return ops.cosine_topk_two_stage(queries, self.shard, self.shadow, k, row_id_base=self.row_begin, out=out,
-                                         status=self.two_stage_status, workspace=self._two_stage_workspace(queries, k, lane))
+                                         status=self.two_stage_status, fallback="device",
+                                         workspace=self._two_stage_workspace(queries, k, lane))
     return ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
                            workspace=workspace, out=out, method=self.method)
 
@@ -65,7 +68,10 @@ class ShardedIndex:
     def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
                  local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
                  row_scale: Optional[torch.Tensor] = None, method: str = "scan",
-                 shadow: Optional[torch.Tensor] = None) -> None:
+                 shadow: Optional[torch.Tensor] = None, exchange: Optional[Callable] = None) -> None:
+        """exchange(all_records, local_record): fills `all_records` (world x record bytes, uint8, rank order) from every
+        rank's `local_record`, ordered on the CURRENT stream.  Default: one `dist.all_gather_into_tensor` over `group`
+        (RCCL).  Injected by the tests that run two ranks on ONE GPU, where RCCL refuses two ranks per device."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -92,6 +98,7 @@ class ShardedIndex:
             raise ValueError(f"row_scale must have one entry per local row ({local_rows.size(0)}), got {row_scale.numel()}")
         self._local_topk = local_topk or _default_local_topk
         self._merge = merge or _default_merge
+        self._exchange_fn = exchange or self._rccl_all_gather
         self._gather_s: Optional[torch.Tensor] = None
         self._gather_i: Optional[torch.Tensor] = None
         # device fast path: the kernel writes scores and ids into ONE packed record, so a step costs a
@@ -107,6 +114,9 @@ class ShardedIndex:
         # EVI_FORCE_EXCHANGE=1 runs the exchange even with one rank (rehearses the multi-rank path on one GPU)
         self._exchange = self.world > 1 or (os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and dist.is_initialized())
 
+    def _rccl_all_gather(self, all_records: torch.Tensor, local_record: torch.Tensor) -> None:
+        dist.all_gather_into_tensor(all_records, local_record, group=self.group)
+
     def _two_stage_workspace(self, queries: torch.Tensor, k: int, lane: int = 0) -> torch.Tensor:
         from . import _lib
 
@@ -118,12 +128,25 @@ class ShardedIndex:
         return self._ts_ws[lane]
 
     def two_stage_failed(self) -> bool:
-        """True when some batch since the last call could not be proven exact (one read-back; resets the flag): the
-        results of those batches must be recomputed with method "scan"."""
+        """True when, on ANY rank, some batch since the last call could not be proven exact and was re-done by the gated
+        f32 scan (one read-back; resets the flag).  The results are exact either way (device-side fallback); a True here
+        says the two-stage scan is the wrong method for this index (clustered rows, heavy ties): every failed batch
+        cost a full f32 scan on top.  With more than one rank this is a COLLECTIVE (max over ranks): every rank must
+        call it, and every rank gets the same answer."""
         if self.two_stage_status is None:
             return False
-        bad = bool(self.two_stage_status.item())
-        self.two_stage_status.zero_()
+        flag = self.two_stage_status
+        if self.world > 1 and dist.is_initialized():
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                bad = bool(flag.item())
+            else:  # host-staged (gloo in the tests)
+                host = flag.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+                bad = bool(host.item())
+        else:
+            bad = bool(flag.item())
+        flag.zero_()
         return bad
 
     def topk(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -134,7 +157,8 @@ class ShardedIndex:
             from . import ops
 
             s, i = ops.cosine_topk_two_stage(queries, self.shard, self.shadow, k, row_id_base=self.row_begin,
-                                             workspace=self._two_stage_workspace(queries, k))  # checked: falls back to the scan
+                                             status=self.two_stage_status,
+                                             workspace=self._two_stage_workspace(queries, k))  # device-side fallback: always exact
         elif self._local_topk is _default_local_topk:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale, self.method)
         elif self.row_scale is not None:
@@ -162,13 +186,8 @@ def _topk_packed(self: "ShardedIndex", queries: torch.Tensor, k: int):
         self._packed_local = torch.empty(rec, dtype=torch.uint8, device=queries.device)
         self._packed_all = torch.empty(self.world * rec, dtype=torch.uint8, device=queries.device)
     s, i = ops.topk_packed_views(self._packed_local, Q, k)
-    _local_scan(self, queries, k, (s, i), self.workspace)
-    if self.method == "two_stage":
-        # a failed proof on ANY rank sends every rank to the f32 scan (the ranks must agree: the exchange is collective)
-        dist.all_reduce(self.two_stage_status, op=dist.ReduceOp.MAX, group=self.group)
-        if self.two_stage_failed():
-            ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, workspace=self.workspace, out=(s, i))
-    dist.all_gather_into_tensor(self._packed_all, self._packed_local, group=self.group)
+    _local_scan(self, queries, k, (s, i), self.workspace)  # two_stage: exact on the device, whatever the proof said
+    self._exchange_fn(self._packed_all, self._packed_local)
     return ops.topk_merge_packed(self._packed_all, self.world, Q, k)
 
 
@@ -186,7 +205,7 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
     main = torch.cuda.current_stream(dev)
     if not (self._exchange and self._packed_ok and queries.is_cuda):
         if self.method == "two_stage" and queries.is_cuda and self._local_topk is _default_local_topk:
-            s, i = _local_scan(self, queries, k, None, None)  # no read-back: the caller checks two_stage_failed()
+            s, i = _local_scan(self, queries, k, None, None)  # no read-back; exact either way (device-side fallback)
         else:
             s, i = self.topk(queries, k)
         ev = torch.cuda.Event()
@@ -216,7 +235,7 @@ def _topk_async(self: "ShardedIndex", queries: torch.Tensor, k: int):
     side = p["side"]
     with torch.cuda.stream(side):
         side.wait_event(p["scan_done"][slot])
-        dist.all_gather_into_tensor(p["all"][slot], p["local"][slot], group=self.group)
+        self._exchange_fn(p["all"][slot], p["local"][slot])
         ops.topk_merge_packed(p["all"][slot], self.world, Q, k, out=(p["out_s"][slot], p["out_i"][slot]))
         p["xchg_done"][slot].record(side)
     p["used"][slot] = True
@@ -254,7 +273,7 @@ def _topk_async_lanes(self: "ShardedIndex", queries: torch.Tensor, k: int, main)
     with torch.cuda.stream(lane):
         sv, iv = ops.topk_packed_views(p["local"][slot], Q, k)
         _local_scan(self, queries, k, (sv, iv), p["ws"][slot], lane=slot)
-        dist.all_gather_into_tensor(p["all"][slot], p["local"][slot], group=self.group)
+        self._exchange_fn(p["all"][slot], p["local"][slot])
         ops.topk_merge_packed(p["all"][slot], self.world, Q, k, out=(p["out_s"][slot], p["out_i"][slot]))
         p["done"][slot].record(lane)
     return p["out_s"][slot], p["out_i"][slot], p["done"][slot]

@@ -303,15 +303,25 @@ def index_shadow_f16(index: torch.Tensor, *, check_norms: bool = True) -> torch.
 
 
 def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: torch.Tensor, k: int, *, row_id_base: int = 0,
-                          fallback: bool = True, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                          fallback="device", out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                           status: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
     """cosine_topk over an L2-normalised f32 index at half the HBM bytes (see evi_cosine_topk_two_stage): the f16
     `shadow` (index_shadow_f16(index)) is scanned to select k + max(256, k/2) candidates per query, which are re-scored
     from the f32 rows with the scan's arithmetic; ids and scores equal cosine_topk(queries, index, k) bit for bit.
-    status=None: the proof flag is read back (one synchronisation) and a failed proof runs the f32 scan instead
-    (fallback=True) or raises RuntimeError.  status=<int32 [1] device tensor, zeroed by the caller>: nothing is read
-    back — a failed proof ORs 1 into it (sticky across calls, so a pipeline of batches shares one flag) and the caller
-    must check it (non-zero: discard the outputs, run cosine_topk) before using the results."""
+    What happens when the per-batch exactness proof fails (heavy ties, clustered rows, NaN):
+      fallback="device" (default; True means the same): the f32 scan of the batch is enqueued behind the two-stage scan,
+        gated on the proof flag ON THE DEVICE — the outputs are always cosine_topk's, nothing is read back, ranks of a
+        sharded index need no agreement.  `status` (optional int32 [1] device tensor, zeroed by the caller, sticky) only
+        records that a fallback ran.
+      fallback="host": the flag is read back (one synchronisation) and the scan is run from the host if needed.
+      fallback=False: with status=None the flag is read back and RuntimeError raised on failure; with a `status` tensor
+        nothing is read back and the CALLER must check it before using the outputs (the raw C-ABI contract)."""
+    if fallback is True:
+        fallback = "device"
+    if fallback not in ("device", "host", False):
+        raise ValueError(f"fallback must be 'device', 'host' or False, got {fallback!r}")
+    if fallback == "host" and status is not None:
+        raise ValueError("fallback='host' reads the flag back itself: do not pass status")
     dev = _require_gpu(queries, index, shadow, status, workspace)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
@@ -340,16 +350,19 @@ def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: to
     else:
         out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
-    flag = status if status is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+    on_device = fallback == "device"
+    flag = status
+    if flag is None and not on_device:
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(lib.evi_cosine_topk_two_stage(_ptr(q), Q, _ptr(x), _ptr(shadow), N, D, int(k), int(row_id_base), _ptr(out_score),
-                                             _ptr(out_index), flag.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
-                                             _stream(dev)))
-    if status is not None:
+                                             _ptr(out_index), _ptr(flag), 1 if on_device else 0, ws.data_ptr(),
+                                             ws.numel() * ws.element_size(), _stream(dev)))
+    if on_device or status is not None:
         return out_score, out_index
     st = int(flag.item())
     cosine_topk_two_stage.last_status = st
     if st != 0:
-        if not fallback:
+        if fallback is False:
             raise RuntimeError(f"evi_cosine_topk_two_stage could not prove exactness (status {st}): run cosine_topk")
         return cosine_topk(q, x, k, row_id_base=row_id_base, out=out)
     return out_score, out_index

@@ -169,14 +169,19 @@ int evi_cosine_topk_gemm_f16(const float* q, int Q, const void* idx_f16, int64_t
  * kept shadow scores are more than twice that apart the true top-k is among the kept rows.  Stage 2 re-scores
  * them from the f32 rows with the scan's own v_mfma_f32_16x16x4_f32 chain and takes the top-k.
  * *status (device int32, zeroed by the CALLER; bits are OR-ed in, so a pipeline of batches can share one flag and
- * read it once): 0 = proven exact; bit 0 = the gap test failed for some query (heavy ties, NaN scores) - discard
- * the outputs and run evi_cosine_topk.  The shadow must be the one evi_index_shadow_f16 made from idx: the proof
- * is about that pair.  k <= 1365.  Never synchronises. */
+ * read it once): 0 = proven exact; bit 0 = the gap test failed for some query (heavy ties, NaN scores).
+ * device_fallback != 0 (what the host mirrors use): the f32 scan of the same batch is enqueued behind stage 2 into
+ * the same outputs, every kernel of it gated on this call's own proof flag - while the proof held they return at
+ * once (a few empty launches), when it failed they overwrite the unproven result on the device, so the outputs are
+ * ALWAYS those of evi_cosine_topk, with no read-back and no agreement between ranks; status may then be NULL and is
+ * only a record that a fallback ran.  device_fallback == 0: a non-zero status means discard the outputs and run
+ * evi_cosine_topk (status required).  The shadow must be the one evi_index_shadow_f16 made from idx: the proof is
+ * about that pair.  k <= 1365.  Never synchronises. */
 int evi_index_shadow_f16(const float* idx, int64_t N, int D, void* out_f16, void* stream);
 size_t evi_cosine_topk_two_stage_workspace_bytes(int Q, int64_t N, int D, int k);
 int evi_cosine_topk_two_stage(const float* q, int Q, const float* idx, const void* shadow_f16, int64_t N, int D,
                               int k, int64_t row_id_base, float* out_score, int64_t* out_index, int32_t* status,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              int device_fallback, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge P per-shard top-k lists (the all-gathered outputs of evi_cosine_topk on P ranks) into
  * the global top-k, same (score desc, id asc) order; ids < 0 are padding and never win.

@@ -431,10 +431,13 @@ def test_cosine_topk_two_stage_equals_scan_bit_for_bit(dev, Q, N, D, k):
     s0, i0 = ops.cosine_topk(qn, idx, k, row_id_base=5)
     s1, i1 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5, fallback=False)
     assert torch.equal(i1, i0) and torch.equal(s1, s0)
-    # without a read-back: the flag lands in the caller's tensor
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
-    s2, i2 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5, status=flag)
-    assert int(flag.item()) == 0 and torch.equal(i2, i0) and torch.equal(s2, s0)
+    # without a read-back: the flag lands in the caller's tensor (default: device-side fallback; raw contract: fallback=False)
+    for fb in ("device", False):
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        s2, i2 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5, status=flag, fallback=fb)
+        assert int(flag.item()) == 0 and torch.equal(i2, i0) and torch.equal(s2, s0)
+    s3, i3 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5)  # default: no status, no read-back
+    assert torch.equal(i3, i0) and torch.equal(s3, s0)
 
 
 def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
@@ -465,14 +468,27 @@ def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
     sh = ops.index_shadow_f16(clustered)
     with pytest.raises(RuntimeError, match="could not prove"):
         ops.cosine_topk_two_stage(qn, clustered, sh, 50, fallback=False)
-    s, i = ops.cosine_topk_two_stage(qn, clustered, sh, 50)
+    s, i = ops.cosine_topk_two_stage(qn, clustered, sh, 50, fallback="host")
     assert ops.cosine_topk_two_stage.last_status == 1
     s0, i0 = ops.cosine_topk(qn, clustered, 50)
     assert torch.equal(i, i0) and torch.equal(s, s0)
+    # raw contract (fallback=False + status): the unproven result is handed out, the flag says so
     flag = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky: a failure stays visible after a later success
-    ops.cosine_topk_two_stage(qn, clustered, sh, 50, status=flag)
-    ops.cosine_topk_two_stage(qn, idx, shadow, 50, status=flag)
+    ops.cosine_topk_two_stage(qn, clustered, sh, 50, status=flag, fallback=False)
+    ops.cosine_topk_two_stage(qn, idx, shadow, 50, status=flag, fallback=False)
     assert int(flag.item()) == 1
+    # default = device-side fallback: the gated f32 scan repairs the failed batch on the device (no read-back), the
+    # outputs are the scan's bit for bit, with and without a status word, also into caller-owned outputs
+    sd, idd = ops.cosine_topk_two_stage(qn, clustered, sh, 50)
+    assert torch.equal(idd, i0) and torch.equal(sd, s0)
+    flag.zero_()
+    out = (torch.full((Q, 50), 7.0, device=dev), torch.full((Q, 50), 7, dtype=torch.int64, device=dev))
+    ops.cosine_topk_two_stage(qn, clustered, sh, 50, status=flag, out=out, row_id_base=11)
+    assert int(flag.item()) == 1 and torch.equal(out[1], i0 + 11) and torch.equal(out[0], s0)
+    # ... and a batch whose proof holds right after a repaired one is untouched by the (closed) gate
+    s_ok, i_ok = ops.cosine_topk_two_stage(qn, idx, shadow, 50)
+    s_ref, i_ref = ops.cosine_topk(qn, idx, 50)
+    assert torch.equal(i_ok, i_ref) and torch.equal(s_ok, s_ref)
     with pytest.raises(ValueError):
         ops.cosine_topk_two_stage(qn, clustered, sh, 1500)  # k + reserve exceeds the selector's capacity
     with pytest.raises(ValueError):

@@ -1,0 +1,102 @@
+"""GPU: the sharded top-k with TWO ranks and the real kernels (replaces the gather at
+src/callbacks/retriever_topk_edge_writer.py:450-462).
+
+Two processes share the one GPU of the test box, each owning half the rows: per-shard evi_cosine_topk (or the two-stage
+scan) into the packed record, ONE exchange of the [Q, k] records per batch, evi_topk_merge_packed on every rank.  RCCL
+refuses two ranks per device, so the exchange is injected as a `gloo` all-gather of host-staged buffers
+(tests/two_rank_worker.py); the rest is the code path of `bench.py --gpus N`.  Required: merged ids AND scores equal the
+one-rank result bit for bit, on both ranks, for `topk`, the two-lane and the side-stream form of `topk_async`, the scan and
+the two-stage method — also when one rank's two-stage proof fails (its shard holds a cluster of near-identical rows): the
+device-side fallback repairs that rank's record before the exchange and `two_stage_failed()` reports it on EVERY rank.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_real_kernels_equal_one_rank_bit_for_bit(dev, tmp_path):
+    world = 2
+    port = _free_port()
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(world), str(port), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=800)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-4000:]}"
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for tag in ("plain", "clustered"):
+        want_s, want_i = z[0][f"{tag}_want_s"], z[0][f"{tag}_want_i"]
+        assert np.array_equal(want_i, z[1][f"{tag}_want_i"]) and np.array_equal(want_s, z[1][f"{tag}_want_s"])
+        for r in range(world):
+            for name in ("scan_lanes", "scan_side", "ts_lanes", "ts_side"):
+                assert np.array_equal(z[r][f"{tag}_{name}_sync_i"], want_i[0]), (tag, name, r)
+                assert np.array_equal(z[r][f"{tag}_{name}_sync_s"], want_s[0]), (tag, name, r)
+                assert np.array_equal(z[r][f"{tag}_{name}_async_i"], want_i), (tag, name, r)
+                assert np.array_equal(z[r][f"{tag}_{name}_async_s"], want_s), (tag, name, r)
+    # the tie across the shard boundary resolves by global row id (row 17 on rank 0 before its copy on rank 1)
+    wi = z[0]["plain_want_i"]
+    assert wi[0, 0, 0] == 17 and wi[0, 0, 1] == 300_001 - 5
+    # proof flags: nothing failed on the plain index; on the clustered one only the upper shard's proof fails, and the
+    # collective read reports it on both ranks
+    assert [int(z[r]["plain_ts_failed"]) for r in range(world)] == [0, 0]
+    assert [int(z[r]["clustered_ts_local_flag"]) for r in range(world)] == [0, 1]
+    assert [int(z[r]["clustered_ts_failed"]) for r in range(world)] == [1, 1]
+
+
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks(dev):
+    """`python bench.py --gpus 1` through the launcher path and `--gpus 2` without one: the second must start its own
+    ranks (the parent stays GPU-free) — on a one-GPU box the two ranks cannot both get a device, so what is checked there
+    is that the parent relays a rank failure as a non-zero exit instead of dying at argument parsing."""
+    import json
+
+    import torch
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    root = os.path.dirname(HERE)
+    small = ["--steps", "3", "--warmup", "1", "--rows", "200000", "--dim", "128", "--k", "50", "--no-cpu-baseline",
+             "--no-graph-eval", "--no-encode", "--no-extra-legs"]
+    # one rank under torch.distributed.run: world 1, no exchange — the same path as the plain run
+    r1 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                         "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1"] + small,
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    line = json.loads([ln for ln in r1.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["hits_at_k"]["hits@50"] == 1.0 and line["sorted_ok"]
+    if torch.cuda.device_count() >= 2:
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r2.returncode == 0, r2.stderr.decode()[-3000:]
+        line = json.loads([ln for ln in r2.stdout.decode().splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["hits_at_k"]["hits@50"] == 1.0
+    else:
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r2.returncode != 0  # rank 1 has no device: reported, not hung
+        assert b"launch multi-GPU runs with torch.distributed.run" not in r2.stderr
