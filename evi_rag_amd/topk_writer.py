@@ -14,6 +14,7 @@ It is a plain class with the Lightning hook names (no Lightning import is needed
 from __future__ import annotations
 
 import json
+import logging
 from datetime import datetime, timezone
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Sequence
@@ -21,8 +22,15 @@ from typing import Any, Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .metrics import normalize_k_values, rank_batch
+from collections import namedtuple
+
+from . import ops
+from .metrics import normalize_k_values
 from .retriever import RetrieverOutput
+
+RankedLists = namedtuple("RankedLists", "topk_score topk_count")
+
+logger = logging.getLogger(__name__)
 
 _DEFAULT_TOPK_VALUES = (1, 5, 10)
 
@@ -149,14 +157,37 @@ class RetrieverTopKEdgeWriter:
             raise ValueError("Batch missing answer_entity_ids_ptr required for persistence.")
         answer_ptr = torch.as_tensor(answer_ptr, dtype=torch.long).view(-1).tolist()
         num_graphs = len(answer_ptr) - 1
-        rb = rank_batch(scores, None, batch, [self._max_topk], num_graphs=num_graphs, indexes=output.query_ids,
-                        want_topk=True)
         dev = scores.device
-        pos = rb.topk_index.long().clamp(min=0) + rb.edge_ptr[:-1].view(-1, 1)  # global edge positions [B, kmax]
+        query_ids = output.query_ids.detach().view(-1).to(dev)
+        # graph boundaries like the reference (:212-215, :415-422): the collate's edge ptr when the batch carries one of the
+        # right length, else the edges of graph g are those with query_ids == g, in their stored order (:269-281)
+        edge_ptr = None
+        cand = slice_dict.get("edge_index")
+        if cand is not None:
+            cand = torch.as_tensor(cand, dtype=torch.long).view(-1)
+            if cand.numel() == num_graphs + 1:
+                edge_ptr = cand.to(dev)
+        perm = None
+        if edge_ptr is None:
+            if query_ids.numel() != scores.numel():
+                raise ValueError(f"query_ids/scores mismatch: {query_ids.shape} vs {scores.shape}")
+            if bool((query_ids[1:] < query_ids[:-1]).any()):  # unsorted edge->graph ids: group them, order kept inside a graph
+                perm = torch.argsort(query_ids, stable=True)
+                query_ids = query_ids[perm]
+            counts = torch.bincount(query_ids.clamp(min=0), minlength=num_graphs)[:num_graphs]
+            edge_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+        ranked = scores if perm is None else scores[perm]
+        # one segmented top-k launch for the whole batch (evi_segment_topk: (score desc, position asc) — the reference's
+        # torch.topk leaves the order of equal scores unspecified), replacing the per-graph torch.topk loop (:294-302)
+        topk_index, topk_score, topk_count = ops.segment_topk(ranked, edge_ptr, self._max_topk)
+        pos = topk_index.long().clamp(min=0) + edge_ptr[:-1].view(-1, 1)  # positions in the (grouped) edge order [B, kmax]
+        pos = pos.clamp(max=max(scores.numel() - 1, 0))  # padding slots (count < k_max) are never read back
+        if perm is not None:
+            pos = perm[pos]
+        rb = RankedLists(topk_score=topk_score, topk_count=topk_count)
         ei = torch.as_tensor(_attr(batch, "edge_index")).to(dev)
         gids = torch.as_tensor(_attr(batch, "node_global_ids")).to(dev).view(-1)
         rel = torch.as_tensor(_attr(batch, "edge_attr")).to(dev).view(-1)
-        pos = pos.clamp(max=scores.numel() - 1)  # padding slots (count < k_max) are never read back
         gather = lambda t: t[pos]  # noqa: E731
         chunk = {"count": rb.topk_count.cpu(), "score": rb.topk_score.cpu(), "head": gather(gids[ei[0]]).cpu(),
                  "tail": gather(gids[ei[1]]).cpu(), "rel": gather(rel).cpu(), "label": gather(labels).cpu()}
@@ -164,11 +195,36 @@ class RetrieverTopKEdgeWriter:
             chunk[key] = gather(src.detach().view(-1).float()).cpu() if src is not None else None
         ans = torch.as_tensor(_attr(batch, "answer_entity_ids")).view(-1).cpu().tolist()
         chunk["answers"] = [[int(x) for x in ans[answer_ptr[g]: answer_ptr[g + 1]]] for g in range(num_graphs)]
-        sample_ids = _attr(batch, "sample_id")
-        chunk["sample_ids"] = [str(s) for s in sample_ids] if isinstance(sample_ids, (list, tuple)) else [str(g) for g in range(num_graphs)]
-        q = _attr(batch, "question")
-        chunk["questions"] = [str(x) for x in q] if isinstance(q, (list, tuple)) else ["" for _ in range(num_graphs)]
+        chunk["sample_ids"] = self._extract_sample_ids(batch, num_graphs)
+        chunk["questions"] = self._extract_questions(batch, num_graphs)
         self._chunks.append(chunk)
+
+    @staticmethod
+    def _extract_sample_ids(batch: Any, num_graphs: int) -> List[str]:
+        """src/utils/metrics.py:46-55 (`extract_sample_ids`): list -> strings, tensor -> str(item), scalar -> one entry,
+        absent -> graph numbers; a graph beyond the list gets its number (:386-389)."""
+        raw = _attr(batch, "sample_id")
+        if raw is None:
+            return [str(i) for i in range(num_graphs)]
+        if isinstance(raw, (list, tuple)):
+            return [str(s) for s in raw]
+        if torch.is_tensor(raw):
+            return [str(s.item()) for s in raw]
+        return [str(raw)]
+
+    @staticmethod
+    def _extract_questions(batch: Any, num_graphs: int) -> List[str]:
+        """retriever_topk_edge_writer.py:403-414."""
+        raw = _attr(batch, "question")
+        if raw is None:
+            return ["" for _ in range(num_graphs)]
+        if isinstance(raw, (list, tuple)):
+            return [str(q) for q in raw]
+        if torch.is_tensor(raw):
+            if raw.numel() == num_graphs:
+                return [str(v.item()) for v in raw]
+            return [str(raw.cpu().tolist()) for _ in range(num_graphs)]
+        return [str(raw) for _ in range(num_graphs)]
 
     def _records_from_chunk(self, c: Dict[str, Any]) -> List[Dict[str, Any]]:
         records = []
@@ -234,14 +290,20 @@ class RetrieverTopKEdgeWriter:
             raise FileNotFoundError(f"entity_vocab_path not found: {entity_path}")
         if not relation_path.exists():
             raise FileNotFoundError(f"relation_vocab_path not found: {relation_path}")
-        import pyarrow.parquet as pq
+        ent_map: Optional[Dict[int, str]] = None
+        rel_map: Optional[Dict[int, str]] = None
+        try:  # like the reference (:430-446): an unreadable vocabulary is a warning on rank 0, the texts stay None
+            import pyarrow.parquet as pq
 
-        ent = pq.read_table(entity_path, columns=["entity_id", "label"])
-        rel = pq.read_table(relation_path, columns=["relation_id", "label"])
-        ent_map = {int(i): str(l) for i, l in zip(ent.column("entity_id").to_pylist(), ent.column("label").to_pylist())
-                   if i is not None and l is not None}
-        rel_map = {int(i): str(l) for i, l in zip(rel.column("relation_id").to_pylist(), rel.column("label").to_pylist())
-                   if i is not None and l is not None}
+            ent = pq.read_table(entity_path, columns=["entity_id", "label"])
+            ent_map = {int(i): str(l) for i, l in zip(ent.column("entity_id").to_pylist(), ent.column("label").to_pylist())
+                       if i is not None and l is not None}
+            rel = pq.read_table(relation_path, columns=["relation_id", "label"])
+            rel_map = {int(i): str(l) for i, l in zip(rel.column("relation_id").to_pylist(), rel.column("label").to_pylist())
+                       if i is not None and l is not None}
+        except Exception as exc:
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+                logger.warning("Failed to load vocab for textualize: %s", exc)
         return ent_map, rel_map
 
     @staticmethod

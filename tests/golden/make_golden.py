@@ -30,7 +30,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, REF)
 
 # ---- inert stubs for absent third-party packages -----------------------------------------------
-_STUB_ROOTS = ("lmdb", "torch_geometric", "torchmetrics", "lightning", "wandb", "openai", "ollama", "tiktoken", "vllm")
+_STUB_ROOTS = ("lmdb", "torch_geometric", "torchmetrics", "lightning", "lightning_utilities", "wandb", "openai", "ollama", "tiktoken", "vllm")
 
 
 class _StubModule(types.ModuleType):
@@ -590,6 +590,93 @@ def gen_encode(tmpdir):
     save("encode", **arrays)
 
 
+# ---- T3: eval_retriever/<split>.pt payload of the reference's writer callback -----------------------------
+def gen_topk_writer(cases, tmpdir):
+    """Drives the reference's RetrieverTopKEdgeWriter (src/callbacks/retriever_topk_edge_writer.py: on_test_start ->
+    on_test_batch_end -> on_test_end, i.e. _build_context / _slice_graph / _select_topk_edges / _build_record) on the
+    committed batches with the reference Retriever's own outputs and stores the payload it saved.  Lightning's
+    BasePredictionWriter is an inert stub; everything else is the reference's code."""
+    import json
+    import types as _types
+
+    # src/utils/logging_utils.py imports omegaconf at module level; stubbed only from here on (the earlier imports keep
+    # seeing it as absent, which is what scripts/build_retrieval_pipeline.py's own guards expect)
+    global _STUB_ROOTS
+    _STUB_ROOTS = _STUB_ROOTS + ("omegaconf", "hydra", "rich")
+    from src.callbacks.retriever_topk_edge_writer import RetrieverTopKEdgeWriter
+    from src.models.components.retriever import RetrieverOutput
+
+    out_cases = []
+    for case in cases:
+        ns = case["batch"]
+        wdir = os.path.join(tmpdir, case["name"])
+        w = RetrieverTopKEdgeWriter(output_dir=wdir, split=case.get("split", "test"), topk_values=case["topk_values"])
+        trainer = _types.SimpleNamespace(global_rank=0)
+        w.on_test_start(trainer, None)
+        w.on_test_batch_end(trainer, None, case["output"], ns, 0)
+        w.on_test_end(trainer, None)
+        path = os.path.join(wdir, f"{case.get('split', 'test')}.pt")
+        payload = torch.load(path, weights_only=False) if os.path.exists(path) else None  # our own file, written above
+        manifest = json.load(open(os.path.join(wdir, f"{case.get('split', 'test')}.manifest.json"))) if payload is not None else None
+        if manifest is not None:
+            manifest.pop("created_at")
+        if payload is not None:  # JSON keys are strings: triplets_by_k's int keys are restored by the test
+            for smp in payload["samples"]:
+                smp["triplets_by_k"] = {str(k): v for k, v in smp["triplets_by_k"].items()}
+        out_cases.append({"name": case["name"], "source": case["source"], "topk_values": list(case["topk_values"]) if case["topk_values"] is not None else None,
+                          "split": case.get("split", "test"), "batch_extras": case["extras"], "inline": case.get("inline"),
+                          "payload": payload, "manifest": manifest})
+    import gzip
+
+    path = os.path.join(HERE, "topk_writer.json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as fh:  # mtime=0: byte-reproducible
+        fh.write(json.dumps({"cases": out_cases}).encode())
+    print(f"wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
+
+
+def _writer_cases(toy, out_toy, mid, out_mid):
+    import types as _types
+
+    cases = []
+    # (1) toy batch: edge ptr from _slice_dict, sample ids and questions as lists, k window beyond E_g (31 edges)
+    ns = synthetic.as_namespace(toy)
+    ns.num_graphs = toy.num_graphs
+    ns._slice_dict = {"edge_index": torch.from_numpy(toy.edge_ptr)}
+    ns.answer_entity_ids_ptr = torch.from_numpy(toy.answer_ptr)
+    ns.sample_id = [f"WebQTest-{g}" for g in range(toy.num_graphs)]
+    ns.question = [f"question number {g}?" for g in range(toy.num_graphs)]
+    cases.append({"name": "toy_ptr", "source": "retriever_toy", "batch": ns, "output": out_toy, "topk_values": [1, 5, 10, 100],
+                  "extras": {"slice_dict": True, "sample_id": "list", "question": "list"}})
+    # (2) mid batch: no _slice_dict -> per-graph boolean masks over query_ids; sample ids as a tensor; no questions;
+    #     answer ptr from _slice_dict["answer_entity_ids"]; split name "validation"
+    ns = synthetic.as_namespace(mid)
+    ns.num_graphs = mid.num_graphs
+    ns._slice_dict = {"answer_entity_ids": torch.from_numpy(mid.answer_ptr)}
+    ns.sample_id = torch.arange(100, 100 + mid.num_graphs)
+    cases.append({"name": "mid_mask", "source": "retriever_mid", "batch": ns, "output": out_mid, "topk_values": [3, 50, 500],
+                  "split": "validation", "extras": {"slice_dict": False, "sample_id": "tensor", "question": None}})
+    # (3) hand-made: graph 1 has no edges (no record), forward-only output (no logit_bwd), default topk_values
+    g = torch.Generator().manual_seed(9)
+    E = 9
+    ei = torch.tensor([[0, 1, 2, 0, 3, 5, 6, 5, 6], [1, 2, 0, 2, 1, 6, 5, 5, 6]])
+    logits = torch.randn(E, generator=g)
+    inline = {"edge_index": ei.tolist(), "edge_ptr": [0, 5, 5, 9], "edge_attr": [4, 2, 7, 7, 1, 3, 3, 0, 9],
+              "labels": [1, 0, 0, 1, 0, 0, 1, 0, 0], "node_global_ids": [10, 11, 12, 13, 20, 30, 31],
+              "answer_entity_ids": [12, 99, 31], "answer_ptr": [0, 2, 2, 3], "logits": logits.tolist(),
+              "logits_fwd": (logits + 0.25).tolist(), "query_ids": [0, 0, 0, 0, 0, 2, 2, 2, 2]}
+    ns = _types.SimpleNamespace(
+        num_graphs=3, edge_index=ei, edge_attr=torch.tensor(inline["edge_attr"]), labels=torch.tensor(inline["labels"]).float(),
+        node_global_ids=torch.tensor(inline["node_global_ids"]), answer_entity_ids=torch.tensor(inline["answer_entity_ids"]),
+        answer_entity_ids_ptr=torch.tensor(inline["answer_ptr"]), _slice_dict={"edge_index": torch.tensor(inline["edge_ptr"])})
+    from src.models.components.retriever import RetrieverOutput
+
+    out = RetrieverOutput(logits=logits, query_ids=torch.tensor(inline["query_ids"]), relation_ids=ns.edge_attr,
+                          logits_fwd=logits + 0.25, logits_bwd=None)
+    cases.append({"name": "empty_graph_forward_only", "source": None, "batch": ns, "output": out, "topk_values": None,
+                  "extras": {"slice_dict": True, "sample_id": None, "question": None}, "inline": inline})
+    return cases
+
+
 def main():
     import tempfile
 
@@ -615,6 +702,8 @@ def main():
     gen_retriever("retriever_bwd", 16, 16, fwd, seed=2, rounds=(0, 4), direction="backward")
     with tempfile.TemporaryDirectory() as tmp:
         gen_encode(tmp)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_topk_writer(_writer_cases(toy, out, mid, out_mid), tmp)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,109 @@
+"""GPU: "Hits@k unchanged" through the DEFAULT scorer (north_star: retrieved index sets bit-exact, scores within 1e-3).
+
+The chain the evaluation runs — HIP Retriever.forward with the default split-bf16 GEMM (~1e-5 relative, the precision class
+of the TF32 the reference uses on CUDA) -> HIP fused ranking metrics — is compared with the values the REFERENCE's metric
+classes computed on the REFERENCE's logits for the same batch and weights (tests/golden/retriever_{toy,mid}.npz +
+metrics_{toy,mid}.npz, both written by running the reference, tests/golden/make_golden.py).  A near-tie flipped by the
+GEMM's rounding inside some graph's top-k would show up here as a changed set or a changed metric.
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.ranking import segment_topk as oracle_segment_topk
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+K_VALUES = [1, 10, 25, 50, 100, 200, 300, 400, 500]
+# metrics that are integer functions of the per-graph top-k index sets: must be EQUAL (f32 rounding of a mean aside)
+SET_METRICS = ("edge/recall@", "answer/reachability@", "answer_hit@", "answer_recall@", "bridge/recall@",
+               "bridge/pos_edge_frac", "bridge/pos_graph_frac")
+
+
+def _batch_from(z, dev, prefix="b_"):
+    b = types.SimpleNamespace()
+    for k in z.files:
+        if k.startswith(prefix):
+            setattr(b, k[len(prefix):], torch.from_numpy(z[k]).to(dev))
+    b.num_graphs = int(b.ptr.numel() - 1)
+    b.num_nodes = int(b.ptr[-1].item())
+    b._slice_dict = {"edge_index": b.edge_ptr, "q_local_indices": b.q_ptr, "a_local_indices": b.a_ptr}
+    b.answer_entity_ids_ptr = b.answer_ptr
+    return b
+
+
+def _model_from(z, dev):
+    from evi_rag_amd.retriever import Retriever
+
+    rounds = z["rounds"].tolist()
+    m = Retriever(emb_dim=int(z["D"]), hidden_dim=int(z["H"]),
+                  dde_cfg={"num_rounds": rounds[0], "num_reverse_rounds": rounds[1]}, direction_mode=str(z["direction"]))
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")}, strict=True)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag", ["toy", "mid"])
+@pytest.mark.parametrize("gemm", ["default", "f32"])
+def test_hip_forward_then_hip_metrics_equal_the_reference_values(dev, tag, gemm, monkeypatch):
+    from evi_rag_amd import metrics as M
+
+    if gemm == "f32":
+        monkeypatch.setenv("EVI_SCORER_GEMM", "f32")  # the exact-f32 MFMA path, for comparison
+    else:
+        monkeypatch.delenv("EVI_SCORER_GEMM", raising=False)  # default: split-bf16
+    zr = np.load(os.path.join(GOLD, f"retriever_{tag}.npz"), allow_pickle=False)
+    zm = np.load(os.path.join(GOLD, f"metrics_{tag}.npz"), allow_pickle=False)
+    assert np.array_equal(zr["logits"], zm["scores"])  # metrics_* were computed by the reference on these very logits
+    ref = dict(zip(zm["keys"].tolist(), zm["values"].tolist()))
+    model = _model_from(zr, dev)
+    batch = _batch_from(zm, dev)
+    with torch.no_grad():
+        out = model(batch)
+    logits = out.logits
+    np.testing.assert_allclose(logits.cpu().numpy(), zr["logits"], rtol=0, atol=2e-4)
+
+    # (1) per-graph top-k index SETS (k_max = 500) from the HIP logits vs from the reference's logits
+    target = batch.labels > 0.5
+    rb = M.rank_batch(logits, target, batch, K_VALUES, want_topk=True)
+    eptr = zm["b_edge_ptr"]
+    ridx, _, rcnt = oracle_segment_topk(zr["logits"], eptr, K_VALUES[-1])  # (score desc, position asc) on the reference's logits
+    got_idx, got_cnt = rb.topk_index.cpu().numpy(), rb.topk_count.cpu().numpy()
+    assert np.array_equal(got_cnt, rcnt)
+    graphs_with_changed_set = 0
+    graphs_with_changed_order = 0
+    worst_swap = 0.0
+    for g in range(len(eptr) - 1):
+        m = int(rcnt[g])
+        a, b = got_idx[g, :m], ridx[g, :m]
+        if not np.array_equal(a, b):
+            graphs_with_changed_order += 1
+            d = np.nonzero(a != b)[0]
+            s = zr["logits"][int(eptr[g]): int(eptr[g + 1])]
+            worst_swap = max(worst_swap, float(np.max(np.abs(s[a[d]] - s[b[d]]))))
+        for k in K_VALUES:
+            kk = min(k, m)
+            if set(a[:kk].tolist()) != set(b[:kk].tolist()):
+                graphs_with_changed_set += 1
+                break
+    # bound: no top-k set at any k of the window changes on these batches; an order change may only swap reference scores
+    # that differ by less than the logit tolerance
+    assert graphs_with_changed_set == 0, f"{graphs_with_changed_set} graphs changed a top-k set (worst swapped gap {worst_swap})"
+    assert graphs_with_changed_order == 0 or worst_swap < 4e-4, (graphs_with_changed_order, worst_swap)
+
+    # (2) every metric value of the HIP chain vs the reference's metric classes on the reference's logits
+    coll = M.RetrieverMetricCollection(K_VALUES, bridge_metrics=True)
+    coll.update(preds=logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=batch.num_graphs)
+    got = {k: float(v) for k, v in coll.compute().items()}
+    assert got, "the collection computed nothing"
+    checked_sets = 0
+    for name, v in got.items():
+        assert name in ref, name
+        if name.startswith(SET_METRICS):
+            assert v == pytest.approx(ref[name], abs=2e-6), name  # set functions: identical up to the f32 mean
+            checked_sets += 1
+        else:
+            assert v == pytest.approx(ref[name], abs=5e-4), name   # float functions of the scores (margins, probabilities)
+    assert checked_sets >= 5 * len(K_VALUES)

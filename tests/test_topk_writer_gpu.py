@@ -59,3 +59,96 @@ def test_topk_writer_payload_matches_oracle(dev, tmp_path):
         w2.on_predict_start()
     with pytest.raises(ValueError, match="non-empty"):
         RetrieverTopKEdgeWriter(output_dir=tmp_path, artifact_name=" ")
+
+
+def _load_reference_payloads():
+    import gzip
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "topk_writer.json.gz")
+    with gzip.open(path, "rb") as fh:
+        return json.loads(fh.read().decode())["cases"]
+
+
+def _case_inputs(case, dev):
+    """Rebuilds the batch + RetrieverOutput the reference's writer was driven with (tests/golden/make_golden.py:
+    `_writer_cases`): the committed retriever_{toy,mid}.npz batches with the reference Retriever's own outputs, or the
+    inline hand-made batch."""
+    import os
+    import types
+
+    from evi_rag_amd.retriever import RetrieverOutput
+
+    t = lambda a, dt=None: torch.as_tensor(np.asarray(a), dtype=dt).to(dev)  # noqa: E731
+    ex = case["batch_extras"]
+    if case["source"] is not None:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case["source"] + ".npz"), allow_pickle=False)
+        b = types.SimpleNamespace(**{k[2:]: t(z[k]) for k in z.files if k.startswith("b_")})
+        B = int(z["b_ptr"].shape[0] - 1)
+        b.num_graphs = B
+        out = RetrieverOutput(logits=t(z["logits"]), query_ids=t(z["query_ids"]), relation_ids=t(z["relation_ids"]),
+                              logits_fwd=t(z["logits_fwd"]), logits_bwd=t(z["logits_bwd"]))
+        if ex["slice_dict"]:
+            b._slice_dict = {"edge_index": b.edge_ptr}
+            b.answer_entity_ids_ptr = b.answer_ptr
+        else:
+            b._slice_dict = {"answer_entity_ids": b.answer_ptr}
+            del b.edge_ptr  # the reference had no edge ptr here: graphs are cut by query_ids
+        if ex["sample_id"] == "list":
+            b.sample_id = [f"WebQTest-{g}" for g in range(B)]
+        elif ex["sample_id"] == "tensor":
+            b.sample_id = torch.arange(100, 100 + B)
+        if ex["question"] == "list":
+            b.question = [f"question number {g}?" for g in range(B)]
+        return b, out
+    d = case["inline"]
+    b = types.SimpleNamespace(
+        num_graphs=len(d["edge_ptr"]) - 1, edge_index=t(d["edge_index"]), edge_attr=t(d["edge_attr"]),
+        labels=t(d["labels"], torch.float32), node_global_ids=t(d["node_global_ids"]),
+        answer_entity_ids=t(d["answer_entity_ids"]), answer_entity_ids_ptr=t(d["answer_ptr"]),
+        _slice_dict={"edge_index": t(d["edge_ptr"])})  # no ptr / seeds / answers' local indices: the writer needs none
+    out = RetrieverOutput(logits=t(d["logits"], torch.float32), query_ids=t(d["query_ids"]), relation_ids=b.edge_attr,
+                          logits_fwd=t(d["logits_fwd"], torch.float32), logits_bwd=None)
+    return b, out
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_topk_writer_payload_equals_the_reference_writers(dev, tmp_path, idx):
+    """T3 pinned: the payload the REFERENCE's RetrieverTopKEdgeWriter saved for these batches (its _build_context /
+    _select_topk_edges / _build_record, run by tests/golden/make_golden.py) vs the mirror's, record by record: same
+    samples in the same order, same keys, identical ids / ranks / labels / directional logits, sigmoid scores to 1e-6
+    (torch-CPU vs torch-ROCm sigmoid), same settings and manifest."""
+    from evi_rag_amd.topk_writer import RetrieverTopKEdgeWriter
+
+    case = _load_reference_payloads()[idx]
+    batch, out = _case_inputs(case, dev)
+    kw = {} if case["topk_values"] is None else {"topk_values": case["topk_values"]}
+    w = RetrieverTopKEdgeWriter(output_dir=tmp_path / "w", split=case["split"], **kw)
+    w.on_test_start()
+    w.on_test_batch_end(None, None, out, batch, 0)
+    w.on_test_end()
+    got = torch.load(tmp_path / "w" / f"{case['split']}.pt", weights_only=False)
+    want = case["payload"]
+    assert got["settings"] == want["settings"]
+    manifest = json.loads((tmp_path / "w" / f"{case['split']}.manifest.json").read_text())
+    assert manifest.pop("created_at").endswith("Z") and manifest == case["manifest"]
+    assert len(got["samples"]) == len(want["samples"])
+    n_rows = 0
+    for gs, ws in zip(got["samples"], want["samples"]):
+        assert list(gs.keys()) == list(ws.keys())
+        assert gs["sample_id"] == ws["sample_id"] and gs["question"] == ws["question"]
+        assert gs["answer_entity_ids"] == ws["answer_entity_ids"]
+        assert [str(k) for k in gs["triplets_by_k"].keys()] == list(ws["triplets_by_k"].keys())  # int keys, same order
+        for k, rows in gs["triplets_by_k"].items():
+            assert isinstance(k, int)
+            wrows = ws["triplets_by_k"][str(k)]
+            assert len(rows) == len(wrows)
+            for r, wr in zip(rows, wrows):
+                assert list(r.keys()) == list(wr.keys())
+                for key in r:
+                    if key == "score":
+                        assert r[key] == pytest.approx(wr[key], abs=1e-6)
+                    else:
+                        assert r[key] == wr[key], (key, r, wr)
+                n_rows += 1
+    assert n_rows > 0
