@@ -134,21 +134,33 @@ def test_topk_writer_payload_equals_the_reference_writers(dev, tmp_path, idx):
     assert manifest.pop("created_at").endswith("Z") and manifest == case["manifest"]
     assert len(got["samples"]) == len(want["samples"])
     n_rows = 0
+    ties_seen = [0]
     for gs, ws in zip(got["samples"], want["samples"]):
         assert list(gs.keys()) == list(ws.keys())
         assert gs["sample_id"] == ws["sample_id"] and gs["question"] == ws["question"]
         assert gs["answer_entity_ids"] == ws["answer_entity_ids"]
         assert [str(k) for k in gs["triplets_by_k"].keys()] == list(ws["triplets_by_k"].keys())  # int keys, same order
+        # torch.topk leaves the order of EXACTLY equal scores unspecified and the toy batches do hold such
+        # edges (two tails that share an embedding row give bit-identical logits): rows are compared position by position
+        # except inside a group of equal reference scores, where the mirror's row must be one of the group's rows (its own
+        # order there is (score desc, edge position asc), tested against the oracle above)
+        kmax = max(int(k) for k in ws["triplets_by_k"])
+        strip = lambda row: tuple((kk, vv) for kk, vv in row.items() if kk not in ("rank", "score"))  # noqa: E731
+        groups = {}
+        for wr in ws["triplets_by_k"][str(kmax)]:
+            groups.setdefault(wr["score"], []).append(strip(wr))
         for k, rows in gs["triplets_by_k"].items():
             assert isinstance(k, int)
             wrows = ws["triplets_by_k"][str(k)]
             assert len(rows) == len(wrows)
+            seen = set()
             for r, wr in zip(rows, wrows):
                 assert list(r.keys()) == list(wr.keys())
-                for key in r:
-                    if key == "score":
-                        assert r[key] == pytest.approx(wr[key], abs=1e-6)
-                    else:
-                        assert r[key] == wr[key], (key, r, wr)
+                assert r["rank"] == wr["rank"] and r["score"] == pytest.approx(wr["score"], abs=1e-6)
+                if strip(r) != strip(wr):
+                    assert len(groups[wr["score"]]) > 1 and strip(r) in groups[wr["score"]], (k, r, wr)
+                    ties_seen[0] += 1
+                assert strip(r) not in seen
+                seen.add(strip(r))
                 n_rows += 1
-    assert n_rows > 0
+    assert n_rows > 0 and ties_seen[0] <= n_rows // 20
