@@ -52,7 +52,7 @@ class EviRetrieverOutput(Structure):
     """Mirror of `EviRetrieverOutput` in include/evi_hip.h."""
 
     _fields_ = [("logits", c_void_p), ("logits_fwd", c_void_p), ("logits_bwd", c_void_p),
-                ("edge_features", c_void_p), ("node_struct", c_void_p)]
+                ("edge_features", c_void_p), ("node_struct", c_void_p), ("status", c_void_p)]
 
 
 # name -> (restype, argtypes)

@@ -98,6 +98,7 @@ struct EdgeFeatArgs {
     const int64_t* edge_batch;  // [E]
     const int64_t* edge_attr;   // [E]
     int rel_by_edge;            // 1: rel_repr row = edge; 0: rel_repr row = edge_attr
+    int64_t R;                  // rows of rel_repr when rel_by_edge == 0
     const float* node_repr;     // [N, D]
     const float* rel_repr;
     const float* gate_q;        // [B, D]
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
         const int64_t hv = __builtin_amdgcn_readfirstlane((int)a.edge_index[e]);
         const int64_t tv = __builtin_amdgcn_readfirstlane((int)a.edge_index[a.E + e]);
         const int64_t g = __builtin_amdgcn_readfirstlane((int)a.edge_batch[e]);
-        const int64_t rrow = a.rel_by_edge ? e : (int64_t)__builtin_amdgcn_readfirstlane((int)a.edge_attr[e]);
+        // a relation id outside [0, R) was flagged by k_first_edge_of_relation (status word -> IndexError on the host, like
+        // the reference's index_select); here it is clamped so that the read below stays inside rel_repr
+        int64_t rrow = a.rel_by_edge ? e : (int64_t)__builtin_amdgcn_readfirstlane((int)a.edge_attr[e]);
+        if (!a.rel_by_edge) rrow = rrow < 0 ? 0 : (rrow >= a.R ? a.R - 1 : rrow);
         const float* hp = a.node_repr + hv * D;
         const float* tp = a.node_repr + tv * D;
         const float* rp = a.rel_repr + rrow * D;
@@ -627,8 +631,10 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     if (L.dedupe) {
         const int64_t R = b->num_relations;
         int32_t* first = I32(L.rel_first);
-        int32_t* status = I32(L.status);
-        EVI_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
+        // out-of-range relation ids: OR-ed into the caller's sticky status word when it gave one (read once per epoch by the
+        // host mirror: Retriever.check_deferred), else into a scratch word nobody reads
+        int32_t* status = out->status ? out->status : I32(L.status);
+        if (!out->status) EVI_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
         hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, first, R, 0x7FFFFFFF);
         hipLaunchKernelGGL(k_first_edge_of_relation, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr,
                            E, R, first, status);
@@ -674,6 +680,7 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         a.edge_batch = b->edge_batch;
         a.edge_attr = b->edge_attr;
         a.rel_by_edge = L.dedupe ? 0 : 1;
+        a.R = b->num_relations;
         a.node_repr = node_repr;
         a.rel_repr = rel_repr;
         a.gate_q = gate_q;

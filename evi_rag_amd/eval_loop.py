@@ -168,6 +168,9 @@ class RetrieverEvaluator:
         check = getattr(getattr(loader, "dataset", None), "check_deferred", None)
         if check is not None:
             check()  # deferred embedding-id range checks of the collated batches
+        check = getattr(self.model, "check_deferred", None)
+        if check is not None:
+            check()  # relation ids outside batch.num_relations seen by a forward (scored clamped, reported here)
         metrics = self.epoch_end(sync=sync)
         torch.cuda.synchronize()
         seconds = time.perf_counter() - t0

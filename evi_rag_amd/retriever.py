@@ -375,6 +375,11 @@ class Retriever(nn.Module):
         o.logits_bwd = logits_bwd.data_ptr() if logits_bwd is not None else None
         o.edge_features = features.data_ptr() if features is not None else None
         o.node_struct = None
+        # sticky flag for relation ids outside the stated num_relations (no read-back here: check_deferred())
+        st = getattr(self, "_deferred_status", None)
+        if st is None or st.device != dev:
+            st = self._deferred_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        o.status = st.data_ptr()
         need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,
                                                              self.dde.num_reverse_rounds, num_relations))
         ws = ops._workspace(dev, "retriever_forward", need)
@@ -387,6 +392,19 @@ class Retriever(nn.Module):
         output = RetrieverOutput(logits=logits, query_ids=edge_batch, relation_ids=getattr(batch, "edge_attr", None),
                                  logits_fwd=logits_fwd, logits_bwd=logits_bwd, edge_embeddings=features)
         return output, (features if return_features else None)
+
+
+def _check_deferred(self) -> None:
+    """Raises the IndexError the reference raises at its embedding gather (embedding_store.py:139-150) when a forward
+    since the last call met an `edge_attr` outside [0, batch.num_relations) on the relation-dedupe path.  Such edges were
+    scored with a clamped relation row (never an out-of-bounds read).  One read-back: call once per epoch."""
+    st = getattr(self, "_deferred_status", None)
+    if st is not None and int(st.item()) != 0:
+        st.zero_()
+        raise IndexError("edge_attr out of range: a relation id exceeds batch.num_relations")
+
+
+Retriever.check_deferred = _check_deferred
 
 
 __all__ = ["Retriever", "RetrieverOutput", "EmbeddingProjector", "DDE", "compute_edge_batch", "compute_qa_edge_mask"]

@@ -571,6 +571,10 @@ typedef struct EviRetrieverOutput {
     float* edge_features;  /* [E, H]  (RetrieverOutput.edge_embeddings / extract_edge_tokens); NULL = logits
                             * only: score_head is folded into state_net.4 and the [2E, H] features are never formed */
     float* node_struct;    /* [N, 2*(1+rounds+rev)] */
+    int32_t* status;       /* device int32, caller-zeroed, sticky, may be NULL: bit 0 = an edge_attr outside
+                            * [0, batch.num_relations) was seen on the relation-dedupe path (the edge is scored with a
+                            * clamped relation row; the reference raises IndexError at the embedding gather,
+                            * src/data/components/embedding_store.py:139-150) */
 } EviRetrieverOutput;
 
 /* Eval-mode Retriever._forward_impl (src/models/components/retriever.py:195-289): dropout is the

@@ -312,3 +312,32 @@ def test_hide_seek_bias_in_eval(dev):
     assert torch.equal(off(batch).logits, ref.logits)
     with pytest.raises(ValueError, match="must be <= 0"):
         Retriever(emb_dim=32, hidden_dim=32, hide_seek_cfg=dict(cfg, bias_far=0.1))
+
+
+def test_out_of_range_relation_id_on_the_hint_path_is_reported_not_read_out_of_bounds(dev):
+    """A packed split states batch.num_relations (embedding_store.attach) and the forward trusts it without a read-back;
+    a relation id beyond it must not index past rel_repr: the edge is scored with a clamped row, every other logit is
+    untouched, and Retriever.check_deferred() raises the IndexError the reference raises at its embedding gather."""
+    from evi_rag_amd.retriever import Retriever
+
+    D = H = 64
+    sb = synthetic.make_batch(3, nodes_per_graph=50, edges_per_graph=120, emb_dim=D, num_relations=16, seed=4)
+    torch.manual_seed(0)
+    model = Retriever(emb_dim=D, hidden_dim=H).to(dev).eval()
+    good = synthetic.as_namespace(sb, device=dev)
+    good.num_relations = 16
+    ref = model(good).logits.clone()
+    model.check_deferred()  # nothing to report
+    bad = synthetic.as_namespace(sb, device=dev)
+    bad.num_relations = 16
+    bad.edge_attr = bad.edge_attr.clone()
+    bad.edge_attr[7] = 10_000_000  # far outside the relation table
+    bad.edge_attr[11] = -3
+    out = model(bad).logits
+    torch.cuda.synchronize()
+    keep = torch.ones_like(ref, dtype=torch.bool)
+    keep[7] = keep[11] = False
+    assert torch.equal(out[keep], ref[keep]) and bool(torch.isfinite(out).all())
+    with pytest.raises(IndexError, match="edge_attr out of range"):
+        model.check_deferred()
+    model.check_deferred()  # the flag was reset
