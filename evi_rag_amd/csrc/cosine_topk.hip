@@ -1134,7 +1134,11 @@ __global__ __launch_bounds__(kSelectThreads) void k_ts_final(const float* __rest
         if (lane == 0 && ci[kk - 1] >= 0) {  // otherwise every row of the index is in the list
             const float* s = approx + (int64_t)qi * kk;
             const float gap = s[k - 1] - s[kk - 1];
-            if (!(gap > 2.0f * eps * sqrtf(ss))) {  // also catches NaN scores
+            // the bound is relative to |q| and assumes the f16 hi / lo split of the query keeps its 22 bits: far from unit
+            // norm (elements near the f16 subnormal range, or the 2048 x lo part near overflow) it does not hold, and the
+            // proof is refused — the f32 scan then does the batch
+            const bool norm_ok = ss >= 0.0625f && ss <= 16.0f;
+            if (!(gap > 2.0f * eps * sqrtf(ss)) || !norm_ok) {  // also catches NaN scores
                 if (status) atomicOr(status, 1);  // the caller's sticky flag (a pipeline of batches shares it)
                 atomicOr(call_flag, 1);           // this call's own flag: opens the gate of the fallback scan
             }

@@ -218,10 +218,39 @@ def index_shadow_bf16(index: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_UNIT_ROWS_VERIFIED: dict = {}
+
+
+def rows_are_unit_norm(index: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> bool:
+    """True when every (scaled) row of `index` has norm <= 1 + 1e-4 — what the exactness proofs of the GEMM-shaped and
+    two-stage paths assume (their error bounds are kEps * |q| * |x| with |x| <= 1).  One pass over the index and one
+    read-back, cached per (storage, shape, version): in-place edits of the tensor are seen."""
+    key = (index.data_ptr(), tuple(index.shape), index.dtype, index._version,
+           None if row_scale is None else (row_scale.data_ptr(), row_scale._version))
+    hit = _UNIT_ROWS_VERIFIED.get(key)
+    if hit is None:
+        if index.numel() == 0:
+            hit = True
+        else:
+            x = index if index.dtype == torch.float32 else None
+            if x is not None:
+                norms = row_norms(x)
+            else:  # f16 storage: chunked, in f32
+                norms = torch.cat([index[i: i + (1 << 20)].float().norm(dim=1) for i in range(0, index.size(0), 1 << 20)])
+            if row_scale is not None:
+                norms = norms * row_scale.view(-1).abs()
+            hit = bool((norms.max() <= 1.0 + 1e-4).item())
+        if len(_UNIT_ROWS_VERIFIED) > 64:
+            _UNIT_ROWS_VERIFIED.clear()
+        _UNIT_ROWS_VERIFIED[key] = hit
+    return hit
+
+
 def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_scale: Optional[torch.Tensor] = None,
                      row_id_base: int = 0, fallback: bool = True,
                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                     products: Optional[int] = None, shadow: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     products: Optional[int] = None, shadow: Optional[torch.Tensor] = None,
+                     check_norms: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """cosine_topk for many queries at once (see evi_cosine_topk_gemm): one split-bf16 GEMM pass over the index
     selects candidates, the scan's arithmetic re-scores them; the result equals cosine_topk bit for bit.  Reads the
     proof flag back (one synchronisation); when the proof fails (heavy score ties, adversarial row order) the scan
@@ -246,6 +275,14 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         if row_scale.numel() != N:
             raise ValueError(f"row_scale length {row_scale.numel()} != N {N}")
     if Q == 0 or N == 0:
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
+    # the proof's error bound is kApproxEps * |q| * |row|, with |row| <= 1 built in: an index of longer rows would pass
+    # the gap test with true top-k rows discarded.  Verified once per index (cached); such an index goes to the scan.
+    if check_norms and not rows_are_unit_norm(x, row_scale):
+        if not fallback:
+            raise ValueError("cosine_topk_gemm needs rows of norm <= 1 (normalize_embeddings, or row_scale = row_inv_norm): "
+                             "its exactness proof assumes them")
+        cosine_topk_gemm.last_products = 0
         return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
     lib = _lib.load()
     ws = _workspace(dev, "cosine_topk_gemm", int(lib.evi_cosine_topk_gemm_workspace_bytes(Q, N, D, int(k))))

@@ -530,3 +530,45 @@ def test_segment_topk_long_lists_every_score_shape(dev, k):
     assert np.array_equal(cnt.cpu().numpy(), rcnt)
     assert np.array_equal(idx.cpu().numpy(), ridx)
     assert np.array_equal(val.cpu().numpy(), rval, equal_nan=True)
+
+
+def test_proof_paths_refuse_rows_and_queries_far_from_unit_norm(dev):
+    """The exactness proofs bound the selection error by eps * |q| * |row| with |row| <= 1 and |q| ~ 1 built in.
+    (a) an index of rows of norm 10 with near-ties around the k-th score: the GEMM-shaped path must not 'prove' a wrong
+    result — it hands the batch to the scan (method gemm / auto) or raises (fallback=False); (b) queries of norm 1e-4 or
+    1e4 in the two-stage scan: the f16 hi / lo split loses bits there, the proof is refused and the device-side fallback
+    returns the scan's result bit for bit."""
+    from evi_rag_amd import ops
+
+    N, D, Q, k = 50000, 256, 128, 100
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = ops.normalize_embeddings(torch.randn(N, D, device=dev, generator=g))
+    q = ops.normalize_embeddings(torch.randn(Q, D, device=dev, generator=g))
+    # near-ties: 400 rows whose scores against every query differ by ~1e-5 relative
+    x[1000:1400] = ops.normalize_embeddings(x[999].repeat(400, 1) + 2e-5 * torch.randn(400, D, device=dev, generator=g))
+    long_rows = 10.0 * x
+    assert ops.rows_are_unit_norm(x) and not ops.rows_are_unit_norm(long_rows)
+    s0, i0 = ops.cosine_topk(q, long_rows, k)
+    for method in ("gemm", "auto"):
+        s1, i1 = ops.cosine_topk(q, long_rows, k, method=method)
+        assert torch.equal(i1, i0) and torch.equal(s1, s0), method
+    assert ops.cosine_topk_gemm.last_products == 0  # the scan produced it
+    with pytest.raises(ValueError, match="norm <= 1"):
+        ops.cosine_topk_gemm(q, long_rows, k, fallback=False)
+    # with the inverse norms as row_scale the rows count as unit again and the GEMM path may run
+    inv = ops.row_inv_norm(long_rows)
+    s2, i2 = ops.cosine_topk(q, long_rows, k, row_scale=inv)
+    s3, i3 = ops.cosine_topk_gemm(q, long_rows, k, row_scale=inv)
+    assert torch.equal(i3, i2) and torch.equal(s3, s2)
+    # in-place edits are seen (cache keyed on the tensor version)
+    long_rows.mul_(0.1)
+    assert ops.rows_are_unit_norm(long_rows)
+
+    shadow = ops.index_shadow_f16(x)
+    for scale in (1e-4, 1e4):
+        qs = q[:32] * scale
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        s4, i4 = ops.cosine_topk_two_stage(qs, x, shadow, k, status=flag)
+        s5, i5 = ops.cosine_topk(qs, x, k)
+        assert int(flag.item()) == 1  # proof refused ...
+        assert torch.equal(i4, i5) and torch.equal(s4, s5)  # ... and repaired on the device
