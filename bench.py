@@ -134,13 +134,15 @@ def cpu_baseline(shard, queries, k, n_total, cpu_rows, budget_s):
     return ob.time_cosine_topk(q, x, k, n_total=n_total, budget_s=budget_s)
 
 
-def pmc_traffic_gbs(N, D, Q, k, world, kernel_ms_per_step, method="scan"):
-    """HBM traffic of the scan kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), as GB/s at this run's kernel time;
-    null when no profile exists for this configuration (counters cannot be read inside the bench)."""
+def pmc_traffic(N, D, Q, k, world, kernel_ms_per_step, method="scan"):
+    """`roofline.traffic` + where it comes from.  Hardware counters cannot be read inside the bench, so the HBM bytes of
+    the scan kernel are those of the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), as GB/s at this run's kernel time; `traffic_source` names the file
+    so that nobody reads the figure as live.  Null when no profile exists for this configuration."""
+    none = {"traffic": None, "traffic_source": None}
     if world != 1 or kernel_ms_per_step <= 0:
-        return None
-    best = None
+        return none
+    best, best_name = None, None
     prof_dir = os.path.join(REPO_ROOT, "profiles")
     for name in sorted(os.listdir(prof_dir)) if os.path.isdir(prof_dir) else []:
         if name.endswith("_pmc_traffic.json"):
@@ -148,10 +150,12 @@ def pmc_traffic_gbs(N, D, Q, k, world, kernel_ms_per_step, method="scan"):
                 p = json.load(fh)
             c = p.get("config", {})
             if (c.get("index_rows"), c.get("dim"), c.get("queries_per_step"), c.get("k"), c.get("method", "scan")) == (N, D, Q, k, method):
-                best = p  # the latest round's file wins
+                best, best_name = p, name  # the latest round's file wins
     if best is None:
-        return None
-    return best["hbm_bytes_per_step"] / (kernel_ms_per_step * 1e-3) / 1e9
+        return none
+    return {"traffic": best["hbm_bytes_per_step"] / (kernel_ms_per_step * 1e-3) / 1e9,
+            "traffic_source": f"profiles/{best_name}: committed rocprofv3 --pmc passes ({best['hbm_bytes_per_step']} HBM bytes per step), "
+                              "rescaled by this run's kernel time; not read live"}
 
 
 def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=4096, relations=4096, cpu_seconds=8.0):
@@ -280,34 +284,50 @@ def bench_eval_pipeline(dev, D, model, *, graphs_total=128, batch_size=32, nodes
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def bench_encode(dev, D, *, texts=4096, batch_size=64, iters=3):
-    """E1-E4 stage: `TextEncoder.encode_to_device` over synthetic WebQSP-sized texts (8..32 tokens, batches of 64 as
-    configs/build_retrieval_pipeline.yaml) with a RANDOM-INIT BERT of the bge-base shape (12 layers, 768 wide, 12 heads,
-    3072 FFN, 30 522-word vocabulary: no weights exist offline).  The transformer forward is PyTorch-ROCm, as north_star
-    states; the pooling tail is evi_masked_mean_pool.  Token ids are drawn directly (no tokenizer vocabulary offline):
-    the stand-in tokenizer pads a batch to its longest text like the reference's `padding=True`."""
+def _random_bert(dev, D):
     from transformers import BertConfig, BertModel
-
-    from evi_rag_amd.text_encode import TextEncoder
 
     heads = {384: 12, 768: 12, 1024: 16}.get(D, 12)
     layers = {384: 6, 768: 12, 1024: 24}.get(D, 12)
     torch.manual_seed(0)
     model = BertModel(BertConfig(vocab_size=30522, hidden_size=D, num_hidden_layers=layers, num_attention_heads=heads,
                                  intermediate_size=4 * D, max_position_embeddings=512), add_pooling_layer=False).to(dev).eval()
+    return model, layers
+
+
+class _LengthTokenizer:
+    """Stand-in tokenizer (no vocabulary offline): text "i" has lengths[i] random token ids; a batch is padded to its longest
+    text like the reference's `padding=True` (scripts/text_encode_utils.py:52-57)."""
+
+    def __init__(self, lengths):
+        self.lengths = lengths
+
+    def __call__(self, batch, padding=True, truncation=True, return_tensors="pt"):
+        lens = [self.lengths[int(t)] for t in batch]
+        L = max(lens)
+        g = torch.Generator().manual_seed(int(batch[0]))
+        ids = torch.randint(1000, 30000, (len(batch), L), generator=g)
+        mask = (torch.arange(L).view(1, L) < torch.tensor(lens).view(-1, 1)).to(torch.int64)
+        return {"input_ids": ids * mask, "attention_mask": mask}
+
+
+def bench_encode(dev, D, *, texts=4096, batch_size=64, iters=3, autocast=None, fp8_table=False):
+    """E1-E4 stage: `TextEncoder.encode_to_device` over synthetic WebQSP-sized texts (8..32 tokens, batches of 64 as
+    configs/build_retrieval_pipeline.yaml) with a RANDOM-INIT BERT of the bge shape for D (no weights exist offline).  The
+    transformer forward is PyTorch-ROCm, as north_star states; the pooling tail is evi_masked_mean_pool.
+    autocast="bf16" + fp8_table=True is the BASELINE config 5 form: the forward under bf16 autocast, the resulting table
+    stored as OCP e4m3 + per-row scale, and overlap@k of (bf16 encode, fp8 table) against (f32 encode, f32 table) for the
+    same texts and questions — a random-init encoder's embeddings are nearly collinear, so that overlap is a LOWER bound
+    on what a trained encoder gives."""
+    from evi_rag_amd import ops
+    from evi_rag_amd.text_encode import TextEncoder
+
+    model, layers = _random_bert(dev, D)
     rng = np.random.default_rng(0)
     lengths = rng.integers(8, 33, texts)
-
-    class Tok:
-        def __call__(self, batch, padding=True, truncation=True, return_tensors="pt"):
-            lens = [lengths[int(t)] for t in batch]
-            L = max(lens)
-            g = torch.Generator().manual_seed(int(batch[0]))
-            ids = torch.randint(1000, 30000, (len(batch), L), generator=g)
-            mask = (torch.arange(L).view(1, L) < torch.tensor(lens).view(-1, 1)).to(torch.int64)
-            return {"input_ids": ids * mask, "attention_mask": mask}
-
-    enc = TextEncoder.from_components(Tok(), model, str(dev), fp16=False)
+    enc = TextEncoder.from_components(_LengthTokenizer(lengths), model, str(dev), fp16=False)
+    if autocast is not None:
+        enc.autocast = {"bf16": torch.bfloat16, "f16": torch.float16}[autocast]
     names = [str(i) for i in range(texts)]
     enc.encode_to_device(names[: 4 * batch_size], batch_size)
     torch.cuda.synchronize(dev)
@@ -320,10 +340,99 @@ def bench_encode(dev, D, *, texts=4096, batch_size=64, iters=3):
     tokens = int(sum(max(lengths[b: b + batch_size]) * len(lengths[b: b + batch_size]) for b in range(0, texts, batch_size)))
     params = sum(p.numel() for n, p in model.named_parameters() if "embeddings" not in n)
     flops = 2.0 * params * tokens
-    return {"workload": f"{texts} texts of 8..32 tokens in batches of {batch_size}; random-init BERT {layers}L/{D}H (bge-base shape), f32; "
-                        "PyTorch-ROCm forward + evi_masked_mean_pool",
-            "texts_per_s": texts / best, "ms_per_batch": best / (texts / batch_size) * 1e3, "padded_tokens": tokens,
-            "encoder_tflops": flops / best / 1e12, "out_shape": list(out.shape)}
+    res = {"workload": f"{texts} texts of 8..32 tokens in batches of {batch_size}; random-init BERT {layers}L/{D}H, "
+                       f"{'f32' if autocast is None else autocast + ' autocast'}; PyTorch-ROCm forward + evi_masked_mean_pool",
+           "texts_per_s": texts / best, "ms_per_batch": best / (texts / batch_size) * 1e3, "padded_tokens": tokens,
+           "encoder_tflops": flops / best / 1e12, "out_shape": list(out.shape)}
+    if fp8_table:
+        k = 100
+        enc.autocast = None
+        ref = ops.normalize_embeddings(enc.encode_to_device(names, batch_size))      # f32 pipeline: f32 encode, f32 table
+        low = ops.normalize_embeddings(out)                                          # the reduced-precision encode above
+        table8, scale8 = ops.quantize_rows_fp8(low)
+        q_ref, q_low = ref[:32].contiguous(), low[:32].contiguous()                  # the first 32 texts double as questions
+        _, i_ref = ops.cosine_topk(q_ref, ref, k)
+        _, i_low = ops.cosine_topk(q_low, table8, k, row_scale=scale8)
+        _, i_mid = ops.cosine_topk(q_low, low, k)
+        ov = lambda a, b: float(((a.unsqueeze(2) == b.unsqueeze(1)).any(dim=2).float().sum(dim=1) / k).mean().item())  # noqa: E731
+        res["fp8_table"] = {"rows": texts, "k": k, "table_bytes": int(table8.numel() + 4 * scale8.numel()),
+                            "overlap_at_k_vs_f32_pipeline": ov(i_low, i_ref),
+                            "overlap_at_k_encoder_only (bf16 encode, f32 table)": ov(i_mid, i_ref),
+                            "max_abs_embedding_diff": float((low - ref).abs().max().item()),
+                            "note": "random-init encoder: embeddings nearly collinear, overlap is a lower bound"}
+    return res
+
+
+def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3, nodes=1500, edges=4096, relations=4096):
+    """ONE query = one question, one stream, one timed loop (SURVEY.md §8d restated metric): a batch of 32 question texts ->
+    `TextEncoder.encode_to_device` (random-init bge-base-shaped BERT + pooling kernel) -> L2 normalise -> exact cosine
+    top-500 over the resident index -> `Retriever.forward` on the batch's WebQSP-shaped subgraphs (with the encoded
+    questions as `question_emb`) -> fused ranking metrics.  The index candidates do not choose the subgraphs (the
+    reference has no such link either: its graphs come from the dataset), so the stages are chained in time, not in data,
+    except for the question embeddings.  Per-stage times come from events on the same stream; the slowest is named."""
+    from evi_rag_amd import metrics as M, ops, synthetic
+    from evi_rag_amd.retriever import Retriever
+    from evi_rag_amd.text_encode import TextEncoder
+
+    index = build_shard(dev, 0, rows, D, seed)
+    ws = torch.empty(ops.cosine_topk_workspace_bytes(questions, rows, D, k), dtype=torch.uint8, device=dev)
+    out_topk = (torch.empty((questions, k), dtype=torch.float32, device=dev), torch.empty((questions, k), dtype=torch.int64, device=dev))
+    model, layers = _random_bert(dev, D)
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(8, 33, questions * (iters + warmup))
+    enc = TextEncoder.from_components(_LengthTokenizer(lengths), model, str(dev), fp16=False)
+    sb = synthetic.make_batch(questions, nodes_per_graph=nodes, edges_per_graph=edges, emb_dim=D, num_relations=relations,
+                              num_entities=1 << 17, seed=1)
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.answer_entity_ids_ptr = torch.from_numpy(sb.answer_ptr).to(dev)
+    batch.num_relations = relations
+    torch.manual_seed(0)
+    scorer = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
+    scorer.emit_edge_embeddings = False  # what the evaluation keeps: logits
+    coll = M.RetrieverMetricCollection(K_WINDOW)
+    target = batch.labels > 0.5
+    stages = ["encode", "topk", "scorer", "metrics"]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iters)]
+
+    def one(it, marks=None):
+        names = [str(it * questions + j) for j in range(questions)]
+        if marks:
+            marks[0].record()
+        q = ops.normalize_embeddings(enc.encode_to_device(names, questions), EPS)
+        if marks:
+            marks[1].record()
+        ops.cosine_topk(q, index, k, workspace=ws, out=out_topk)
+        if marks:
+            marks[2].record()
+        batch.question_emb = q
+        out = scorer(batch)
+        if marks:
+            marks[3].record()
+        coll.update(preds=out.logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=questions)
+        if marks:
+            marks[4].record()
+
+    for it in range(warmup):
+        one(it)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for it in range(iters):
+        one(warmup + it, ev[it])
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    per = {s: sum(ev[it][j].elapsed_time(ev[it][j + 1]) for it in range(iters)) / iters for j, s in enumerate(stages)}
+    metrics = {kk: float(v) for kk, v in coll.compute().items()}
+    # hits of the top-k stage: a sanity check that the loop computed something (every query's best row is itself a row id)
+    slowest = max(per, key=per.get)
+    res = {"workload": f"{questions} questions per batch: encode (random-init BERT {layers}L/{D}H, f32) -> top-{k} over {rows} x {D} f32 "
+                       f"-> scorer on {questions} WebQSP-shaped graphs (E={sb.num_edges}, D=H={D}, logits only) -> fused metrics",
+           "queries_per_s": questions * iters / wall, "ms_per_batch": wall / iters * 1e3,
+           "stage_ms_per_batch": per, "slowest_stage": slowest,
+           "host_gap_ms_per_batch": wall / iters * 1e3 - sum(per.values()),
+           "reachability@100": metrics.get("answer/reachability@100"), "best_score_mean": float(out_topk[0][:, 0].mean().item())}
+    del index, ws
+    torch.cuda.empty_cache()
+    return res
 
 
 def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, iters=20, cpu_graphs=8, cpu=True):
@@ -391,6 +500,14 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
     deg = (csr.in_ptr[seeds + 1] - csr.in_ptr[seeds] + csr.out_ptr[seeds + 1] - csr.out_ptr[seeds]).sum().item()
     rec("evi_select_start_edges", timed(expand), int(deg) * 8 + E, "incident (eid, score) of every seed + the E-byte mask")
     total_ms = sum(k["ms_per_batch"] for k in res["kernels"].values())
+    dom = max(res["kernels"], key=lambda n: res["kernels"][n]["ms_per_batch"])
+    dk = res["kernels"][dom]
+    res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": dk["GB_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": dk["GB_per_s"] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                       "algorithmic_bytes_per_batch": dk["algorithmic_bytes"], "kernel_ms_per_batch": dk["ms_per_batch"],
+                       "all_four_kernels": {"algorithmic_bytes_per_batch": sum(k["algorithmic_bytes"] for k in res["kernels"].values()),
+                                            "ms_per_batch": total_ms,
+                                            "GB_per_s": sum(k["algorithmic_bytes"] for k in res["kernels"].values()) / (total_ms * 1e-3) / 1e9}}
     res["gpu_graphs_per_s"] = B / (total_ms * 1e-3)
     res["gpu_epoch_seconds"] = graphs / res["gpu_graphs_per_s"]
     if cpu:  # the reference's own Python / numpy algorithms, restated (oracle), on a sample of the same graphs
@@ -440,78 +557,57 @@ def launch_ranks(args):
     raise SystemExit(0)
 
 
-def main():
-    args = parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        launch_ranks(args)
-    # stdout carries exactly ONE JSON line: native libraries that write to fd 1 (RCCL prints a version banner at
-    # communicator creation) are sent to stderr for the life of the process, and the result goes to the saved fd
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        args.gpus = world  # under a launcher WORLD_SIZE is authoritative
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible "
-                         "(one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # EVI_FORCE_EXCHANGE=1 under torch.distributed.run with ONE rank rehearses the multi-rank path (all-gather + merge
-    # on the side stream) on a single GPU
-    rehearse = world == 1 and os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and "MASTER_ADDR" in os.environ
-    if world > 1 or rehearse:
-        dist.init_process_group("nccl", device_id=dev)
+class Ctx:
+    """What every leg needs: the device, the rank layout and the loaded library."""
+
+    def __init__(self, dev, world, rank, lib):
+        self.dev, self.world, self.rank, self.lib = dev, world, rank, lib
+
+    def fence(self):
+        torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(self.dev)
+
+
+def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, want_two_stage=False, sustained_s=0.0,
+                  cpu_rows=0, cpu_seconds=0.0, workload=None):
+    """One index configuration end to end: build the (sharded) resident index in its storage type, W untimed + K timed
+    steps through ShardedIndex.topk_async, live kernel times (hipExtLaunchKernelGGL events inside the library), planted-row
+    Hits@k.  Returns the JSON object of the leg (complete on rank 0)."""
+    import ctypes
 
     from evi_rag_amd import _lib, ops
+    from evi_rag_amd.dist import ShardedIndex, _local_scan
 
-    if args.graph_kernels:  # config 3 leg only
-        if rank == 0:
-            res = bench_graph_kernels(dev, args.graph_batch, cpu=not args.no_cpu_baseline)
-            os.write(result_fd, (json.dumps(res) + "\n").encode())
-        return
-    lib = _lib.load()
-    N, D, Q, k = args.rows, args.dim, args.queries, args.k
+    dev, world, rank, lib = ctx.dev, ctx.world, ctx.rank, ctx.lib
     row_begin = N * rank // world
     row_end = N * (rank + 1) // world
-    shard = build_shard(dev, row_begin, row_end, D, args.seed, torch.float16 if args.index_dtype == "f16" else torch.float32)
-    elem_bytes = 2 if args.index_dtype == "f16" else 4
-    n_batches = args.warmup + args.steps
-    queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, args.seed, world)
+    shard = build_shard(dev, row_begin, row_end, D, seed, torch.float16 if index_dtype == "f16" else torch.float32)
+    elem_bytes = 2 if index_dtype == "f16" else 4
+    n_batches = warmup + steps
+    queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, seed, world)
     row_scale = None
-    shard_f32_sample = None
-    if args.index_dtype == "fp8":
-        shard_f32_sample = shard[: args.cpu_rows].clone()
+    f32_sample = None
+    if index_dtype == "fp8":
+        f32_sample = shard[: max(cpu_rows, 1 << 20)].clone()  # CPU baseline / overlap@k reference rows
         shard, row_scale = ops.quantize_rows_fp8(shard)
         elem_bytes = 1
         torch.cuda.empty_cache()
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
-    from evi_rag_amd.dist import ShardedIndex
-
-    if args.topk_method == "two_stage" and args.index_dtype != "f32":
+    if method == "two_stage" and index_dtype != "f32":
         raise SystemExit("--topk-method two_stage goes with the f32 index (its f16 shadow is built here)")
-    method = args.topk_method if args.index_dtype in ("f32", "f16") else "scan"
+    method = method if index_dtype in ("f32", "f16") else "scan"
     shadow = ops.index_shadow_f16(shard) if method == "two_stage" else None
     index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow)
     index.workspace = ws
-    import ctypes
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    def timed_run(index):
+    def timed_run(index, steps=steps, warmup=warmup):
         """W untimed + K timed steps of `index`; returns (seconds — max over ranks, kernel ms per class, launches, last result)."""
         def step(b):
-            # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge on a
-            # side stream, overlapped with the next batch's scan (every result is complete at the closing fence)
-            s, i, _ = index.topk_async(queries[b], k)
+            # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge,
+            # pipelined with the next batch's scan (every result is complete at the closing fence)
+            s, i, _ = index.topk_async(queries[b % n_batches], k)
             return s, i
 
         # With an exchange the timed region runs two pipelined lanes (ShardedIndex._topk_async_lanes); kernel event times
@@ -521,11 +617,9 @@ def main():
         ms = (ctypes.c_double * 4)()
         launches = (ctypes.c_int32 * 4)()
         if lanes:
-            calib = max(args.warmup, 1)
-            from evi_rag_amd.dist import _local_scan
-
+            calib = max(warmup, 1)
             _local_scan(index, queries[0], k, None, index.workspace)  # cold start (first touch of the workspace) untimed
-            fence()
+            ctx.fence()
             t_ramp = time.perf_counter()  # ~0.1 s of sustained load first: right after start-up the same kernels run ~10 % slower
             while time.perf_counter() - t_ramp < 0.1:
                 for b in range(4):
@@ -534,40 +628,40 @@ def main():
             lib.evi_timing_enable(1)
             for b in range(calib):
                 _local_scan(index, queries[b % n_batches], k, None, index.workspace)  # the shard's scan + selections, one stream
-            fence()
+            ctx.fence()
             lib.evi_timing_enable(0)
             _lib.check(lib.evi_timing_read(ms, launches, 4))
             for c in range(4):
-                ms[c] = ms[c] / calib * args.steps
-                launches[c] = int(round(launches[c] / calib * args.steps))
+                ms[c] = ms[c] / calib * steps
+                launches[c] = int(round(launches[c] / calib * steps))
             # untimed pipelined steps: buffers and workspaces of both lanes exist before the clock starts, and the pipeline is
             # in its steady state (the first ~20 ms of two-lane steps after an idle period run ~10 % slower)
             t_ramp = time.perf_counter()
             n_pre = 0
-            while n_pre < max(2, args.warmup) or time.perf_counter() - t_ramp < 0.05:
+            while n_pre < max(2, warmup) or time.perf_counter() - t_ramp < 0.05:
                 for b in range(4):
-                    step((n_pre + b) % n_batches)
+                    step(n_pre + b)
                 n_pre += 4
                 torch.cuda.synchronize(dev)
         else:
             t_ramp = time.perf_counter()
-            for b in range(args.warmup):
+            for b in range(warmup):
                 step(b)
             torch.cuda.synchronize(dev)
             # keep warming (untimed) until ~50 ms of sustained load have passed: in the first tens of milliseconds after an
             # idle period the same kernels run up to 10 % slower, which a 3-step warm-up of a small shard does not cover
-            while args.warmup > 0 and time.perf_counter() - t_ramp < 0.05:
+            while warmup > 0 and time.perf_counter() - t_ramp < 0.05:
                 for b in range(min(4, n_batches)):
                     step(b)
                 torch.cuda.synchronize(dev)
-        fence()
+        ctx.fence()
         if not lanes:
             lib.evi_timing_enable(1)
         t0 = time.perf_counter()
         out = None
-        for b in range(args.warmup, n_batches):
+        for b in range(warmup, warmup + steps):
             out = step(b)
-        fence()
+        ctx.fence()
         elapsed = time.perf_counter() - t0
         if not lanes:
             lib.evi_timing_enable(0)
@@ -589,10 +683,45 @@ def main():
     # either way; the flag (max over ranks, a collective) only says that such repairs happened inside the timed region
     two_stage_fallback = index.two_stage_failed() if method == "two_stage" else False
 
+    # sustained leg: >= sustained_s seconds of back-to-back steps in chunks, so that a clock / thermal droop that a
+    # 0.1 s timed region cannot show becomes visible (queries/s per chunk, first vs last)
+    sustained = None
+    if sustained_s > 0:
+        per_chunk = max(steps, int(0.25 / max(elapsed / steps, 1e-6)))
+        chunks = []
+        ctx.fence()
+        t_all = time.perf_counter()
+        lib.evi_timing_enable(1)
+        n_done = 0
+        while time.perf_counter() - t_all < sustained_s or len(chunks) < 4:
+            t0 = time.perf_counter()
+            for b in range(per_chunk):
+                index.topk_async(queries[(n_done + b) % n_batches], k)
+            ctx.fence()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            chunks.append(Q * per_chunk / dt)
+            n_done += per_chunk
+            if len(chunks) >= 64:
+                break
+        total_s = time.perf_counter() - t_all
+        lib.evi_timing_enable(0)
+        sms = (ctypes.c_double * 4)()
+        sln = (ctypes.c_int32 * 4)()
+        _lib.check(lib.evi_timing_read(sms, sln, 4))
+        sustained = {"seconds": total_s, "steps": n_done, "queries_per_s": Q * n_done / total_s,
+                     "ms_per_step": total_s / n_done * 1e3, "chunk_steps": per_chunk,
+                     "queries_per_s_first_chunk": chunks[0], "queries_per_s_last_chunk": chunks[-1],
+                     "queries_per_s_min_chunk": min(chunks), "queries_per_s_max_chunk": max(chunks),
+                     "kernel_ms_per_step": (sms[0] / n_done) if not (index._exchange and index.two_lanes) else None}
+
     # extra leg (f32 headline run only): the same batches through the two-stage exact scan; its last result must equal
     # the f32 scan's bit for bit
     two_stage = None
-    if method == "scan" and args.index_dtype == "f32" and not args.no_two_stage:
+    if method == "scan" and index_dtype == "f32" and want_two_stage:
         shadow = ops.index_shadow_f16(shard)
         idx2 = ShardedIndex(shard, N, method="two_stage", shadow=shadow)
         idx2.workspace = ws
@@ -600,31 +729,42 @@ def main():
         failed = idx2.two_stage_failed()
         same = bool(torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1]))
         b2 = two_stage_bytes(row_end - row_begin)
-        sc2 = ms2[0] / args.steps
+        sc2 = ms2[0] / steps
         two_stage = {
             "what": "f16 shadow of the index scanned for k + max(256, k/2) candidates per query, candidates re-scored from the "
-                    "f32 rows with the scan's own MFMA chain; a per-batch gap test proves the result equals the f32 scan's",
-            "value": Q * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
+                    "f32 rows with the scan's own MFMA chain; a per-batch gap test proves the result equals the f32 scan's, and a "
+                    "batch whose proof fails is re-done on the device by the gated f32 scan (no read-back)",
+            "value": Q * steps / e2, "unit": "queries/s", "ms_per_step": e2 / steps * 1e3,
             "identical_to_f32_scan": same, "proof_failed": failed, "extra_index_memory_bytes": int(shadow.numel()) * 2,
             "roofline": {"bound": "hbm", "achieved": b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (b2 / (sc2 * 1e-3) / 1e9 if sc2 > 0 else 0.0) / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_gbs(N, D, Q, k, world, sc2, "two_stage"),
                          "kernel": "k_cosine_score<F16=1> over the shadow", "algorithmic_bytes_per_step": b2,
-                         "launches_per_step": l2[0] / args.steps, "kernel_ms_per_step": sc2,
-                         "select_and_rescore_ms_per_step": ms2[1] / args.steps},
+                         "launches_per_step": l2[0] / steps, "kernel_ms_per_step": sc2,
+                         "select_and_rescore_ms_per_step": ms2[1] / steps},
         }
+        two_stage["roofline"].update(pmc_traffic(N, D, Q, k, world, sc2, "two_stage"))
         del shadow, idx2, out2
         torch.cuda.empty_cache()
 
     # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
     s_last, i_last = out
-    g = gold[n_batches - 1].to(dev).view(Q, 1)
+    g = gold[(warmup + steps - 1) % n_batches].to(dev).view(Q, 1)
     rank_of_gold = torch.where((i_last == g).any(dim=1), (i_last == g).float().argmax(dim=1), torch.full((Q,), 10 ** 9, device=dev))
     hits = {f"hits@{kk}": float((rank_of_gold < kk).float().mean().item()) for kk in K_WINDOW if kk <= k}
     sorted_ok = bool((s_last[:, 1:] <= s_last[:, :-1]).all().item())
 
+    # fp8: overlap@k of the e4m3 result with the f32 result on the same rows (the f32 rows kept aside above)
+    overlap = None
+    if index_dtype == "fp8" and world == 1:
+        nr = f32_sample.shape[0]
+        s8, i8 = ops.cosine_topk(queries[0], shard[:nr], k, row_scale=row_scale[:nr])
+        s32, i32 = ops.cosine_topk(queries[0], f32_sample, k)
+        inter = (i8.unsqueeze(2) == i32.unsqueeze(1)).any(dim=2).float().sum(dim=1)
+        overlap = {"rows": int(nr), "overlap_at_k": float((inter / k).mean().item()), "k": k,
+                   "max_abs_score_diff_on_common_rows": float((s8[:, 0] - s32[:, 0]).abs().max().item())}
+
+    result = None
     if rank == 0:
-        steps = args.steps
         shard_rows = row_end - row_begin
         bytes_per_step = shard_rows * D * elem_bytes + Q * D * 4 + Q * k * 12 + (shard_rows * 4 if row_scale is not None else 0)
         if method == "two_stage":
@@ -637,22 +777,22 @@ def main():
             "unit": "queries/s",
             "n_gpus": world,
             "steps": steps,
-            "warmup": args.warmup,
+            "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 index x f32 queries (f16 MFMA, f32 accumulate)",
-                      "fp8": "e4m3 index + f32 row scale x f32 queries (f16 MFMA, f32 accumulate)"}[args.index_dtype],
+                      "fp8": "e4m3 index + f32 row scale x f32 queries (e4m3 widened to f16 in registers, f16 MFMA, f32 accumulate)"}[index_dtype],
             "data": "synthetic",
             "config": {
-                "workload": ("configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k" if N < 50_000_000 else
-                             "configs[3] shape: 100 M-triple index, brute-force cosine top-k" + (" on ONE GPU" if world == 1 else "")),
+                "workload": workload or ("configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k" if N < 50_000_000 else
+                                         "configs[3] shape: 100 M-triple index, brute-force cosine top-k" + (" on ONE GPU" if world == 1 else "")),
                 "index_rows": N,
                 "dim": D,
                 "queries_per_step": Q,
                 "k": k,
-                "index_dtype": args.index_dtype,
+                "index_dtype": index_dtype,
                 "topk_method": method,
                 "sharding": f"rows/{world}" if world > 1 else "none",
             },
@@ -662,7 +802,6 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_gbs(N, D, Q, k, world, score_ms_per_step, method) if args.index_dtype == "f32" else None,
                 "kernel": "k_cosine_score",
                 "algorithmic_bytes_per_step": bytes_per_step,
                 "launches_per_step": launches[0] / steps,
@@ -672,14 +811,20 @@ def main():
             "hits_at_k": hits,
             "sorted_ok": sorted_ok,
         }
+        result["roofline"].update(pmc_traffic(N, D, Q, k, world, score_ms_per_step, method) if index_dtype == "f32"
+                                  else {"traffic": None, "traffic_source": None})
         if bool(getattr(index, "_exchange", False) and getattr(index, "two_lanes", False)):
             result["config"]["pipeline"] = "two lanes (two hardware queues): scan, selections, all-gather and merge of a batch on its lane"
             result["roofline"]["timed_in"] = ("warm-up steps that run the shard's scan and selections alone on one stream: kernel event "
                                               "times taken while two lanes run include the time a kernel waits for CUs")
+        if sustained is not None:
+            result["sustained"] = sustained
         if two_stage is not None:
             result["two_stage"] = two_stage
-        if args.topk_method == "two_stage":
+        if method == "two_stage":
             result["two_stage_proof_failed"] = two_stage_fallback
+        if overlap is not None:
+            result["overlap_vs_f32"] = overlap
         if ms[2] > ms[0]:
             # the many-query path did the work: the dominant kernel is the split-bf16 GEMM (MFMA-bound), priced by the
             # flops it executes (3 bf16 products per f32 product) against the dense bf16 peak
@@ -687,23 +832,89 @@ def main():
             products = ops.cosine_topk_gemm.last_products or 3  # 1: plain bf16 selection, 3: split-bf16
             executed = products * 2.0 * Q * shard_rows * D / (gemm_ms * 1e-3) / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s", "frac": executed / 2500.0,
-                                  "traffic": None, "products_per_f32_product": products,
+                                  "traffic": None, "traffic_source": None, "products_per_f32_product": products,
                                   "kernel": "k_gemm_nt_bf16x3 (threshold-filter epilogue)",
                                   "algorithmic_flops_per_step": 2.0 * Q * shard_rows * D, "launches_per_step": launches[2] / steps,
                                   "kernel_ms_per_step": gemm_ms, "select_ms_per_step": ms[1] / steps}
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(shard if shard_f32_sample is None else shard_f32_sample, queries, k, N,
-                                                  args.cpu_rows, args.cpu_seconds)
+        if world == 1 and cpu_seconds > 0 and cpu_rows > 0:
+            result["cpu_baseline"] = cpu_baseline(shard if f32_sample is None else f32_sample, queries, k, N, cpu_rows, cpu_seconds)
+    del shard, ws, index, queries
+    torch.cuda.empty_cache()
+    return result
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
+    # stdout carries exactly ONE JSON line: native libraries that write to fd 1 (RCCL prints a version banner at
+    # communicator creation) are sent to stderr for the life of the process, and the result goes to the saved fd
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world  # under a launcher WORLD_SIZE is authoritative
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible "
+                         "(one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # EVI_FORCE_EXCHANGE=1 under torch.distributed.run with ONE rank rehearses the multi-rank path (all-gather + merge
+    # on the side stream) on a single GPU
+    rehearse = world == 1 and os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or rehearse:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from evi_rag_amd import _lib
+
+    if args.graph_kernels:  # config 3 leg only
+        if rank == 0:
+            res = bench_graph_kernels(dev, args.graph_batch, cpu=not args.no_cpu_baseline)
+            os.write(result_fd, (json.dumps(res) + "\n").encode())
+        return
+    ctx = Ctx(dev, world, rank, _lib.load())
+    cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+    extra = world == 1 and not args.no_extra_legs
+    result = run_index_leg(ctx, N=args.rows, D=args.dim, Q=args.queries, k=args.k, index_dtype=args.index_dtype,
+                           method=args.topk_method, steps=args.steps, warmup=args.warmup, seed=args.seed,
+                           want_two_stage=not args.no_two_stage, sustained_s=2.0 if extra else 0.0,
+                           cpu_rows=args.cpu_rows, cpu_seconds=cpu_s)
+    if rank == 0:
+        D = args.dim
+        if extra:
+            # BASELINE configs 4 and 5 as far as ONE GPU can show them: the shard one of 8 ranks holds of the 100 M-row index
+            # (12.5 M rows), in the storage type the config names, through the same scan — each with its own roofline
+            result["config4_shard"] = run_index_leg(
+                ctx, N=12_500_000, D=768, Q=args.queries, k=args.k, index_dtype="f16", method="scan", steps=args.steps,
+                warmup=args.warmup, seed=3, cpu_rows=1 << 18, cpu_seconds=min(cpu_s, 5.0),
+                workload="configs[3] per-rank shard: 1/8 of the 100 M x 768 index, f16 storage (what each of 8 MI355X scans per batch)")
+            result["config5_shard"] = run_index_leg(
+                ctx, N=12_500_000, D=1024, Q=args.queries, k=args.k, index_dtype="fp8", method="scan", steps=args.steps,
+                warmup=args.warmup, seed=4, cpu_rows=1 << 18, cpu_seconds=min(cpu_s, 5.0),
+                workload="configs[4] per-rank shard: 1/8 of the 100 M x 1024 index, OCP e4m3 storage + f32 row scale "
+                         "(bge-large dim); overlap@k against the f32 index reported instead of bit-exactness")
+            result["config3_graph_kernels"] = {
+                f"batch_{b}": bench_graph_kernels(dev, b, cpu=(cpu_s > 0 and b == 32)) for b in (32, 512)}
         if world == 1 and not args.no_graph_eval:
-            del shard, ws, index
-            torch.cuda.empty_cache()
             result["graph_eval"] = bench_graph_eval(dev, D, cpu_seconds=0.0 if args.no_cpu_baseline else 8.0)
         if world == 1 and not args.no_encode:
             torch.cuda.empty_cache()
             try:
                 result["encode"] = bench_encode(dev, D)
+                if extra:
+                    result["config5_encode"] = bench_encode(dev, 1024, autocast="bf16", fp8_table=True)
             except ImportError as exc:  # transformers missing: the leg is informational
                 result["encode"] = {"skipped": str(exc)}
+        if extra and not args.no_graph_eval and not args.no_encode:
+            torch.cuda.empty_cache()
+            try:
+                result["end_to_end"] = bench_end_to_end(dev, D, rows=args.rows, k=args.k, seed=args.seed)
+            except ImportError as exc:
+                result["end_to_end"] = {"skipped": str(exc)}
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if world > 1 or rehearse:
         dist.barrier()

@@ -138,9 +138,9 @@ def _split_override(arg: str) -> Tuple[str, str, bool]:
 
 
 def compose(config_dir: os.PathLike, config_name: str = "eval", overrides: Sequence[str] = (), *,
-            hydra_runtime: Optional[Mapping[str, Any]] = None) -> Dict[str, Any]:
+            hydra_runtime: Optional[Mapping[str, Any]] = None, searchpath: Sequence[os.PathLike] = ()) -> Dict[str, Any]:
     """The merged, fully interpolated config as plain dicts / lists."""
-    raw, hydra_node = compose_raw(config_dir, config_name, overrides, hydra_runtime=hydra_runtime)
+    raw, hydra_node = compose_raw(config_dir, config_name, overrides, hydra_runtime=hydra_runtime, searchpath=searchpath)
     return resolve_config(raw, hydra_node)
 
 
@@ -159,10 +159,43 @@ def resolve_config(raw: Mapping[str, Any], hydra_node: Dict[str, Any]) -> Dict[s
     return out
 
 
+def _searchpath_dirs(value: Any) -> List[Path]:
+    """`hydra.searchpath=[file:///abs/dir,...]` (Hydra's config search path): extra directories whose group files are found
+    after the primary directory's.  Only `file://` entries (or plain paths) are supported."""
+    items = value if isinstance(value, (list, tuple)) else [value]
+    out = []
+    for item in items:
+        text = str(item)
+        if text.startswith("pkg://"):
+            raise ConfigError(f"hydra.searchpath entry {text!r}: pkg:// locations are not supported, use file://")
+        out.append(Path(text[len("file://"):] if text.startswith("file://") else text))
+    return out
+
+
 def compose_raw(config_dir: os.PathLike, config_name: str = "eval", overrides: Sequence[str] = (), *,
-                hydra_runtime: Optional[Mapping[str, Any]] = None) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+                hydra_runtime: Optional[Mapping[str, Any]] = None,
+                searchpath: Sequence[os.PathLike] = ()) -> Tuple[Dict[str, Any], Dict[str, Any]]:
     """(merged but NOT interpolated config, the hydra node that ${hydra:...} reads)."""
     root_dir = Path(config_dir)
+    search_dirs: List[Path] = [root_dir] + [Path(d) for d in searchpath]
+    rest = []
+    for arg in overrides:
+        if arg.lstrip("+").startswith("hydra.searchpath="):
+            search_dirs += _searchpath_dirs(yaml.safe_load(arg.split("=", 1)[1]))
+        else:
+            rest.append(arg)
+    overrides = rest
+
+    def is_group(rel: str) -> bool:
+        return any((d / rel).is_dir() for d in search_dirs)
+
+    def find_option(group: str, option: str) -> Optional[Path]:
+        for d in search_dirs:
+            path = d / group / f"{option}.yaml"
+            if path.exists():
+                return path
+        return None
+
     primary_path = root_dir / f"{config_name}.yaml"
     if not primary_path.exists():
         raise FileNotFoundError(f"primary config {primary_path} not found")
@@ -175,7 +208,7 @@ def compose_raw(config_dir: os.PathLike, config_name: str = "eval", overrides: S
     value_overrides: List[Tuple[str, Any, bool]] = []
     for arg in overrides:
         key, value, add = _split_override(arg)
-        if (root_dir / key.replace(".", "/")).is_dir() and "/" not in value:
+        if is_group(key.replace(".", "/")) and "/" not in value:
             group_choice[key.replace(".", "/")] = None if value in ("null", "~", "") else value
         else:
             value_overrides.append((key, yaml.safe_load(value) if value != "" else "", add))
@@ -192,12 +225,13 @@ def compose_raw(config_dir: os.PathLike, config_name: str = "eval", overrides: S
     def load_option(group: str, option: str, optional: bool):
         key = (group, option)
         if key not in cache:
-            path = root_dir / group / f"{option}.yaml"
-            if not path.exists():
+            path = find_option(group, option)
+            if path is None:
                 if optional:
                     cache[key] = ({}, False, [], {})
                     return cache[key]
-                raise ConfigError(f"config group {group!r} has no option {option!r} ({path} not found)")
+                raise ConfigError(f"config group {group!r} has no option {option!r} "
+                                  f"({', '.join(str(d / group / (option + '.yaml')) for d in search_dirs)} not found)")
             body, is_global = _load(path)
             sub_entries, sub_over = _parse_defaults(body.pop("defaults", None), str(path), group)
             if not any(e.is_self for e in sub_entries):
@@ -206,6 +240,30 @@ def compose_raw(config_dir: os.PathLike, config_name: str = "eval", overrides: S
         return cache[key]
 
     file_choice: Dict[str, Optional[str]] = {}
+
+    def collect(group: str, option: str, optional: bool, depth: int = 0) -> bool:
+        """`override /g: opt` requests of this option and of every option its own defaults list pulls in (an experiment
+        that extends another experiment inherits that one's overrides, as in Hydra >= 1.1)."""
+        if depth > 8:
+            raise ConfigError(f"defaults nesting too deep at {group}/{option}")
+        _, _, sub_entries, sub_over = load_option(group, option, optional)
+        changed = False
+        for g, opt in sub_over.items():
+            if g not in listed:
+                raise ConfigError(f"{group}/{option}: `override /{g}` but {g!r} is not in the primary defaults list")
+            if file_choice.get(g, "\0") != opt:
+                file_choice[g] = opt
+                changed = True
+        for se in sub_entries:
+            if se.is_self or se.option is None:
+                continue
+            sub_option = group_choice.get(se.group, se.option) if se.group != group else se.option
+            if sub_option is not None and se.group not in listed:
+                changed |= collect(se.group, sub_option, se.optional, depth + 1)
+            elif sub_option is not None and se.group == group:
+                changed |= collect(se.group, sub_option, se.optional, depth + 1)
+        return changed
+
     for _ in range(16):
         changed = False
         for e in entries:
@@ -214,13 +272,7 @@ def compose_raw(config_dir: os.PathLike, config_name: str = "eval", overrides: S
             option = group_choice.get(e.group, file_choice.get(e.group, e.option))
             if option is None or e.group == "hydra":
                 continue
-            _, _, _, sub_over = load_option(e.group, option, e.optional)
-            for g, opt in sub_over.items():
-                if g not in listed:
-                    raise ConfigError(f"{e.group}/{option}: `override /{g}` but {g!r} is not in the primary defaults list")
-                if file_choice.get(g, "\0") != opt:
-                    file_choice[g] = opt
-                    changed = True
+            changed |= collect(e.group, option, e.optional)
         if not changed:
             break
     else:
@@ -253,8 +305,8 @@ def compose_raw(config_dir: os.PathLike, config_name: str = "eval", overrides: S
         if option is None:
             continue
         if e.group == "hydra":
-            path = root_dir / "hydra" / f"{option}.yaml"
-            if path.exists():
+            path = find_option("hydra", option)
+            if path is not None:
                 body, _ = _load(path)
                 body.pop("defaults", None)
                 _merge(hydra_node, {k: v for k, v in body.items() if k not in ("runtime", "job")})

@@ -87,6 +87,11 @@ class TextEncoder:
         self.progress = progress
         return self
 
+    # Reduced-precision forward (BASELINE config 5; not in the reference, whose `fp16` flag only changes the pooling
+    # dtype, scripts/text_encode_utils.py:28-30): set to torch.bfloat16 / torch.float16 and the transformer runs under
+    # torch.autocast on the device; the pooling kernel takes the half-precision hidden states as they are.
+    autocast: Optional[torch.dtype] = None
+
     @torch.no_grad()
     def encode_to_device(self, texts: Sequence[str], batch_size: int) -> torch.Tensor:
         """As `encode`, but the result stays in HBM: no per-batch device-to-host sync."""
@@ -96,7 +101,11 @@ class TextEncoder:
         for start, end in _iter_batches(len(texts), batch_size):
             inputs = self.tokenizer(list(texts[start:end]), padding=True, truncation=True, return_tensors="pt")
             inputs = {k: v.to(self.device) for k, v in inputs.items()}
-            hidden = self.model(**inputs).last_hidden_state
+            if self.autocast is not None:
+                with torch.autocast(device_type="cuda", dtype=self.autocast):
+                    hidden = self.model(**inputs).last_hidden_state
+            else:
+                hidden = self.model(**inputs).last_hidden_state
             pooled.append(masked_mean_pool(hidden, inputs["attention_mask"], fp16=self.dtype == torch.float16))
         return torch.cat(pooled, dim=0)
 
@@ -134,4 +143,50 @@ def encode_to_memmap(encoder: TextEncoder, texts: Sequence[str], emb_ids: Sequen
     return tensor
 
 
-__all__ = ["TextEncoder", "encode_to_memmap", "masked_mean_pool", "scatter_rows", "ENCODER_EPS"]
+def encode_tables(encoder: TextEncoder, *, entity_embedding_records: Sequence[dict], entity_struct_records: Sequence[dict],
+                  relation_records: Sequence[dict], batch_size: int, embeddings_out_dir, precompute_entities: bool = True,
+                  precompute_relations: bool = True, show_progress: bool = False):
+    """The entity / relation encode sequence of the offline pipeline (scripts/build_retrieval_pipeline.py:1262-1309), with
+    the vocabulary records the reference takes them from (`EntityVocab.embedding_records` / `.struct_records`,
+    `RelationVocab.records` = the rows of embedding_vocab / entity_vocab / relation_vocab.parquet):
+
+      * entity labels sorted by `embedding_id` (:1270-1275) -> `encode_to_memmap` into a zero table of
+        max(struct_records.embedding_id, default 0) + 1 rows (:1276-1287; row 0 = the non-text placeholder stays zero)
+        -> `entity_embeddings.pt`;
+      * relation labels sorted by `relation_id` (:1290-1300) -> `encoder.encode` -> `relation_embeddings.pt` [R, D].
+
+    Returns (entity_table or None, relation_table or None) as CPU f32 tensors, files written like the reference's."""
+    out_dir = Path(embeddings_out_dir)
+    if precompute_entities or precompute_relations:
+        out_dir.mkdir(parents=True, exist_ok=True)
+    entity_table = relation_table = None
+    if precompute_entities:
+        emb_rows = sorted(((rec["embedding_id"], rec.get("label", "")) for rec in entity_embedding_records), key=lambda x: x[0])
+        text_labels = [str(label) for _, label in emb_rows]
+        text_ids = [int(eid) for eid, _ in emb_rows]
+        max_embedding_id = max((int(rec["embedding_id"]) for rec in entity_struct_records), default=0)
+        entity_table = encode_to_memmap(encoder, text_labels, text_ids, batch_size, max_embedding_id,
+                                        out_dir / "entity_embeddings.pt", "Entities", show_progress)
+    if precompute_relations:
+        relation_rows = sorted(((rec["relation_id"], rec.get("label", "")) for rec in relation_records), key=lambda x: x[0])
+        relation_labels = [str(label) for _, label in relation_rows]
+        relation_table = encoder.encode(relation_labels, batch_size, show_progress=show_progress, desc="Relations")
+        torch.save(relation_table, out_dir / "relation_embeddings.pt")
+    return entity_table, relation_table
+
+
+def encode_questions(encoder: TextEncoder, questions: Sequence[str], batch_size: int, chunk_size: int = 2000) -> List[List[float]]:
+    """Question embeddings as the pipeline's pass 2 makes them (scripts/build_retrieval_pipeline.py:1318-1334, 1360): the
+    samples are processed in chunks of `chunk_size` (parquet_chunk_size), every chunk's question texts go through
+    `encoder.encode(texts, batch_size)` on their own — so batch boundaries restart at each chunk — and a sample's
+    `question_emb` column is the list of floats of its row.  One D2H copy per chunk instead of one `.tolist()` per row."""
+    out: List[List[float]] = []
+    for start in range(0, len(questions), max(int(chunk_size), 1)):
+        chunk = [str(q) for q in questions[start: start + chunk_size]]
+        emb = encoder.encode(chunk, batch_size, show_progress=False, desc="Questions")
+        out.extend(emb.tolist())
+    return out
+
+
+__all__ = ["TextEncoder", "encode_to_memmap", "encode_tables", "encode_questions", "masked_mean_pool", "scatter_rows",
+           "ENCODER_EPS"]

@@ -590,6 +590,87 @@ def gen_encode(tmpdir):
     save("encode", **arrays)
 
 
+# ---- E4: the encode call sites of the offline pipeline ----------------------------------------------------
+def gen_encode_tables(tmpdir):
+    """Runs the reference's `preprocess` (scripts/build_retrieval_pipeline.py:1140-1447) end to end on a synthetic raw
+    parquet split with embeddings requested — vocabulary pass, then its encode sequence (:1243-1309: entity labels sorted
+    by embedding_id -> encode_to_memmap; relation labels sorted by relation_id -> encode; :1318-1334, :1360: questions per
+    chunk -> question_emb list per sample) — with `TextEncoder` replaced by the lookup model of gen_encode (no weights
+    offline: E1 stays unpinned).  Stores the vocabulary records it encoded from and the three tables it wrote."""
+    from pathlib import Path
+
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    torch.manual_seed(17)
+    D = 16
+    table = torch.randn(98, D)
+    tok = _FakeTokenizer()
+
+    class _Enc(teu.TextEncoder):
+        def __init__(self, model_name, device, fp16, progress):
+            self.tokenizer, self.model, self.device = tok, _FakeModel(table), "cpu"
+            self.dtype = torch.float16 if fp16 else torch.float32
+            self.progress = progress
+
+    raw = Path(tmpdir) / "raw"
+    out = Path(tmpdir) / "normalized"
+    emb_dir = Path(tmpdir) / "embeddings"
+    raw.mkdir()
+    names = ["Barack Obama", "Honolulu", "United States of America", "m.02mjmr", "Michelle Obama", "Chicago", "g.11b6", "Hawaii",
+             "Pacific Ocean", "m.0abc", "Illinois", "White House", "Harvard Law School", "lawyer", "1961"]
+    rels = ["people.person.place_of_birth", "location.location.containedby", "people.person.spouse_s", "common.topic.alias",
+            "people.person.profession", "education.education.institution", "location.location.adjoin_s"]
+    rng = np.random.default_rng(55)
+    rows = {"train": [], "test": []}
+    for split, n in (("train", 5), ("test", 3)):
+        for qi in range(n):
+            m = int(rng.integers(4, 11))
+            graph = [[names[int(rng.integers(len(names)))], rels[int(rng.integers(len(rels)))], names[int(rng.integers(len(names)))]]
+                     for _ in range(m)]
+            ents = sorted({t[0] for t in graph} | {t[2] for t in graph})
+            rows[split].append({"id": f"{split}-{qi}", "question": f"where was {names[qi % 5]} born {qi}",
+                                "answer": [ents[-1]], "q_entity": [ents[0]], "a_entity": [ents[-1]], "graph": graph})
+    for split, rr in rows.items():
+        pq.write_table(pa.Table.from_pylist(rr), raw / f"{split}-00000.parquet")
+    keep_all = brp.SplitFilter(skip_no_topic=False, skip_no_ans=False, skip_no_path=False)
+    cfg = brp.EmbeddingConfig(encoder="fake", device="cpu", batch_size=4, fp16=False, progress_bar=False, embeddings_out_dir=emb_dir,
+                              precompute_entities=True, precompute_relations=True, precompute_questions=True,
+                              canonicalize_relations=False, cosine_eps=1e-6)
+    import re as _re
+
+    text_cfg = brp.TextEntityConfig(mode="regex", prefixes=(), regex=_re.compile("^(?!m\\.|g\\.).*"))  # configs/dataset/webqsp.yaml:25
+    orig = brp.TextEncoder
+    brp.TextEncoder = _Enc
+    try:
+        brp.preprocess(dataset="webqsp", kb="freebase", raw_root=raw, out_dir=out,
+                       column_map={"question_id_field": "id", "question_field": "question", "answer_text_field": "answer",
+                                   "q_entity_field": "q_entity", "a_entity_field": "a_entity", "graph_field": "graph"},
+                       entity_normalization="none", text_cfg=text_cfg, train_filter=keep_all, eval_filter=keep_all,
+                       override_filters={}, embedding_cfg=cfg, parquet_chunk_size=max(brp._MIN_CHUNK_SIZE, 3))
+    finally:
+        brp.TextEncoder = orig
+    ent = torch.load(emb_dir / "entity_embeddings.pt")
+    rel = torch.load(emb_dir / "relation_embeddings.pt")
+    ev = pq.read_table(out / "entity_vocab.parquet").to_pylist()
+    ee = pq.read_table(out / "embedding_vocab.parquet").to_pylist() if (out / "embedding_vocab.parquet").exists() else None
+    rv = pq.read_table(out / "relation_vocab.parquet").to_pylist()
+    qs = pq.read_table(out / "questions.parquet").to_pylist()
+    print("normalized files:", sorted(p.name for p in out.iterdir()))
+    import json
+
+    fixture = {"D": D, "lookup_table": table.numpy().tolist(), "batch_size": 4,
+               "entity_vocab": ev, "embedding_vocab": ee, "relation_vocab": rv,
+               "questions": [{"question_uid": q.get("question_uid"), "question": q["question"], "question_emb": q["question_emb"]} for q in qs],
+               "entity_embeddings": ent.numpy().tolist(), "relation_embeddings": rel.numpy().tolist()}
+    import gzip
+
+    path = os.path.join(HERE, "encode_tables.json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as fh:
+        fh.write(json.dumps(fixture).encode())
+    print(f"wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
+
+
 # ---- T3: eval_retriever/<split>.pt payload of the reference's writer callback -----------------------------
 def gen_topk_writer(cases, tmpdir):
     """Drives the reference's RetrieverTopKEdgeWriter (src/callbacks/retriever_topk_edge_writer.py: on_test_start ->
@@ -702,6 +783,8 @@ def main():
     gen_retriever("retriever_bwd", 16, 16, fwd, seed=2, rounds=(0, 4), direction="backward")
     with tempfile.TemporaryDirectory() as tmp:
         gen_encode(tmp)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_encode_tables(tmp)
     with tempfile.TemporaryDirectory() as tmp:
         gen_topk_writer(_writer_cases(toy, out, mid, out_mid), tmp)
 

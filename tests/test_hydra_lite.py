@@ -143,3 +143,50 @@ def test_compose_the_reference_tree_itself(monkeypatch):
     assert cfg["trainer"]["devices"] == 1 and cfg["paths"]["root_dir"] == "/proj" and "hydra" not in cfg
     cwq = hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever", "dataset=cwq", "ckpt.retriever=/w/r.ckpt"])
     assert cwq["dataset"]["name"] == "cwq" and cwq["run"]["dataset_variants"] == ["cwq", "cwq-sub"]
+
+
+@pytest.mark.skipif(not REFERENCE_CONFIGS.is_dir(), reason="the reference checkout is only present in the build container")
+def test_overlay_composes_over_the_reference_tree(monkeypatch):
+    """The shipped configs/ overlay over the reference's real tree, found through hydra.searchpath:
+    everything equals the plain `eval_retriever` composition except the swapped `_target_`s, and those instantiate."""
+    from pathlib import Path
+
+    from evi_rag_amd import hydra_lite as hl
+
+    overlay = Path(__file__).resolve().parent.parent / "configs"
+    monkeypatch.setenv("PROJECT_ROOT", "/proj")
+    base = hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever", "dataset=webqsp", "ckpt.retriever=/w/r.ckpt"])
+    cfg = hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever_mi355x", "dataset=webqsp", "ckpt.retriever=/w/r.ckpt",
+                                                 f"hydra.searchpath=[file://{overlay}]"])
+    assert cfg["model"]["retriever"]["_target_"] == "evi_rag_amd.retriever.Retriever"
+    assert cfg["model"]["loss"]["_target_"] == "evi_rag_amd.loss.RetrieverLoss"
+    assert cfg["callbacks"]["retriever_topk_edge_writer"]["_target_"] == "evi_rag_amd.topk_writer.RetrieverTopKEdgeWriter"
+    # identical apart from the three swapped targets
+    import copy
+
+    same = copy.deepcopy(cfg)
+    same["model"]["retriever"]["_target_"] = base["model"]["retriever"]["_target_"]
+    same["model"]["loss"]["_target_"] = base["model"]["loss"]["_target_"]
+    same["callbacks"]["retriever_topk_edge_writer"]["_target_"] = base["callbacks"]["retriever_topk_edge_writer"]["_target_"]
+    import json
+    import re
+
+    def norm(c):  # the run directory carries the experiment's name and a timestamp
+        return re.sub(r"\d{4}-\d{2}-\d{2}_\d{2}-\d{2}-\d{2}", "T", json.dumps(c, sort_keys=True).replace("eval_retriever_mi355x", "eval_retriever"))
+
+    assert norm(same) == norm(base)
+    # the same through the keyword instead of the command-line override
+    assert norm(hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever_mi355x", "dataset=webqsp", "ckpt.retriever=/w/r.ckpt"],
+                           searchpath=[overlay])) == norm(cfg)
+    # the group-level overlays
+    m = hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever", "model=retriever_module_mi355x", "dataset=webqsp",
+                                               "ckpt.retriever=/w/r.ckpt"], searchpath=[overlay])
+    assert m["model"]["retriever"]["_target_"] == "evi_rag_amd.retriever.Retriever" and m["model"]["retriever"]["emb_dim"] == 1024
+    assert m["model"]["loss"]["infonce_temperature"] == 0.07
+    # and the swapped targets instantiate (host-side construction only: no GPU call)
+    model = hl.instantiate(cfg["model"]["retriever"])
+    from evi_rag_amd.retriever import Retriever
+
+    assert isinstance(model, Retriever) and model.emb_dim == 1024
+    with pytest.raises(hl.ConfigError, match="pkg://"):
+        hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever", "hydra.searchpath=[pkg://x]"])

@@ -245,3 +245,52 @@ def test_large_graph_takes_the_global_memory_paths(dev):
     for g, (nn, a, b, s, t) in enumerate(((n, src, dst, [5], [19999, 123]), (small_n, s2, d2, [0], [250]))):
         ref = ograph.shortest_path_single(nn, a.tolist(), b.tolist(), s, t)
         assert res[g] == (list(ref[0]), list(ref[1])), g
+
+
+def test_encode_tables_sequence_matches_the_reference_pipeline(dev, tmp_path):
+    """E4: the tables the REFERENCE's `preprocess` wrote (entity_embeddings.pt, relation_embeddings.pt, the question_emb
+    column) for a synthetic raw split, from the vocabulary records it wrote — tests/golden/make_golden.py:gen_encode_tables
+    ran it with the lookup encoder — against `encode_tables` / `encode_questions` driven by the same records here."""
+    import gzip
+    import json
+
+    from evi_rag_amd import text_encode as T
+
+    with gzip.open(os.path.join(GOLD, "encode_tables.json.gz"), "rb") as fh:
+        z = json.loads(fh.read().decode())
+    table = torch.tensor(z["lookup_table"], device=dev)
+
+    class Tok:
+        def __call__(self, texts, padding=True, truncation=True, return_tensors="pt"):
+            ids = [[(sum(map(ord, w)) % 97) + 1 for w in t.split()][:8] for t in texts]
+            L = max(1, max(len(i) for i in ids))
+            input_ids = torch.zeros((len(ids), L), dtype=torch.long)
+            mask = torch.zeros((len(ids), L), dtype=torch.long)
+            for r, row in enumerate(ids):
+                input_ids[r, : len(row)] = torch.tensor(row, dtype=torch.long)
+                mask[r, : len(row)] = 1
+            return {"input_ids": input_ids, "attention_mask": mask}
+
+    class Model(torch.nn.Module):
+        def forward(self, input_ids, attention_mask):
+            hid = table[input_ids] + 0.01 * torch.arange(input_ids.size(1), dtype=torch.float32, device=dev).view(1, -1, 1)
+            return types.SimpleNamespace(last_hidden_state=hid)
+
+    enc = T.TextEncoder.from_components(Tok(), Model(), str(dev), fp16=False)
+    # the records arrive in vocabulary (first-seen) order, not sorted by id: the sort is part of what is pinned
+    assert [r["embedding_id"] for r in z["embedding_vocab"]] != sorted(r["embedding_id"] for r in z["embedding_vocab"])
+    ent, rel = T.encode_tables(enc, entity_embedding_records=z["embedding_vocab"], entity_struct_records=z["entity_vocab"],
+                               relation_records=z["relation_vocab"], batch_size=z["batch_size"], embeddings_out_dir=tmp_path / "emb")
+    want_ent, want_rel = np.asarray(z["entity_embeddings"], np.float32), np.asarray(z["relation_embeddings"], np.float32)
+    assert ent.shape == want_ent.shape and rel.shape == want_rel.shape and ent.dtype == torch.float32
+    np.testing.assert_allclose(ent.numpy(), want_ent, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rel.numpy(), want_rel, rtol=0, atol=1e-6)
+    zero_rows = np.nonzero(np.abs(want_ent).sum(1) == 0)[0]
+    assert 0 in zero_rows and np.all(ent.numpy()[zero_rows] == 0)  # the non-text placeholder row stays exactly zero
+    assert torch.equal(torch.load(tmp_path / "emb" / "entity_embeddings.pt"), ent)
+    assert torch.equal(torch.load(tmp_path / "emb" / "relation_embeddings.pt"), rel)
+    # questions: per chunk of parquet_chunk_size samples (the golden run used the reference's minimum chunk size)
+    qs = z["questions"]
+    got = T.encode_questions(enc, [q["question"] for q in qs], z["batch_size"], chunk_size=3)
+    assert len(got) == len(qs) and all(isinstance(v, float) for v in got[0])
+    np.testing.assert_allclose(np.asarray(got, np.float32), np.asarray([q["question_emb"] for q in qs], np.float32), rtol=0, atol=1e-6)
