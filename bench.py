@@ -469,11 +469,20 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
         res["kernels"][name] = {"ms_per_batch": ms, "algorithmic_bytes": nbytes, "GB_per_s": nbytes / (ms * 1e-3) / 1e9,
                                 "graphs_per_s": B / (ms * 1e-3), "note": note}
 
-    csr = ops.graph_csr(ei, ptr, eptr)
-    rec("evi_graph_csr", timed(lambda: ops.graph_csr(ei, ptr, eptr)), E * 16 + 2 * (E * 8 + N * 4),
-        "edge_index read (16 B/edge) + both CSR halves written (nbr + eid per edge, ptr per node)")
+    csr = ops.graph_csr(ei, ptr, eptr, num_nodes=N)
+    csr_ws = torch.empty(int(lib.evi_graph_csr_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+    rec("evi_graph_csr", timed(lambda: ops.graph_csr(ei, ptr, eptr, num_nodes=N, out=csr, workspace=csr_ws)),
+        E * 16 + 2 * (E * 8 + N * 4), "edge_index read (16 B/edge) + both CSR halves written (nbr + eid per edge, ptr per node)")
     rounds = 2
-    rec("evi_dde_node_struct", timed(lambda: ops.dde_node_struct(topic, ptr, csr, rounds, rounds)),
+    S = 1 + 2 * rounds
+    ns = torch.empty((N, 2 * S), dtype=torch.float32, device=dev)
+
+    def dde():
+        _lib.check(lib.evi_dde_node_struct(topic.data_ptr(), topic.size(1), 2, N, csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
+                                           csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), rounds, rounds, ns.data_ptr(),
+                                           ops._stream(dev)))
+
+    rec("evi_dde_node_struct", timed(dde),
         2 * rounds * (E * 12 + N * 16) + N * 10 * 4, "per round E*(4 nbr + 8 gathered) + N*(8 ptr + 8 out); 2 + 2 rounds")
     jg = torch.arange(B, dtype=torch.int32, device=dev)
     sp, doff = t(sb.q_ptr), t(sb.ptr[:-1])
@@ -486,8 +495,8 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
 
     ms = timed(bfs)
     levels = int(dist_lv.max().item()) + 1
-    rec("evi_bfs_levels", ms, levels * N * 4 + 2 * E * 8,
-        f"undirected, {levels} levels: N*4 scanned per level + every CSR row once (nbr + dist probe)")
+    rec("evi_bfs_levels", ms, N * 4 + 2 * E * 8 + N * 16,
+        f"undirected, {levels} levels, frontier queues in LDS: every CSR row once (ptr pair + nbr), the levels written once")
     res["two_hop_frontier_nodes_per_graph"] = int(((dist_lv >= 0) & (dist_lv <= 2)).sum().item()) / B
     mask = torch.empty(E, dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -499,6 +508,27 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
 
     deg = (csr.in_ptr[seeds + 1] - csr.in_ptr[seeds] + csr.out_ptr[seeds + 1] - csr.out_ptr[seeds]).sum().item()
     rec("evi_select_start_edges", timed(expand), int(deg) * 8 + E, "incident (eid, score) of every seed + the E-byte mask")
+
+    # the four steps of a labelling batch as ONE hipGraph (what a steady loop replays: no host launch cost between kernels)
+    def sequence():
+        ops.graph_csr(ei, ptr, eptr, num_nodes=N, out=csr, workspace=csr_ws)
+        dde()
+        bfs()
+        expand()
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        sequence()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sequence()
+    seq_ms = timed(graph.replay)
+    res["pipeline"] = {"what": "CSR -> DDE 2+2 -> multi-source BFS -> seed expansion captured as one hipGraph and replayed",
+                       "ms_per_batch": seq_ms, "graphs_per_s": B / (seq_ms * 1e-3),
+                       "sum_of_eager_kernel_legs_ms": sum(k["ms_per_batch"] for k in res["kernels"].values())}
     total_ms = sum(k["ms_per_batch"] for k in res["kernels"].values())
     dom = max(res["kernels"], key=lambda n: res["kernels"][n]["ms_per_batch"])
     dk = res["kernels"][dom]
@@ -508,7 +538,7 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
                        "all_four_kernels": {"algorithmic_bytes_per_batch": sum(k["algorithmic_bytes"] for k in res["kernels"].values()),
                                             "ms_per_batch": total_ms,
                                             "GB_per_s": sum(k["algorithmic_bytes"] for k in res["kernels"].values()) / (total_ms * 1e-3) / 1e9}}
-    res["gpu_graphs_per_s"] = B / (total_ms * 1e-3)
+    res["gpu_graphs_per_s"] = B / (seq_ms * 1e-3)  # the replayed pipeline; the eager per-kernel legs above include host launch gaps
     res["gpu_epoch_seconds"] = graphs / res["gpu_graphs_per_s"]
     if cpu:  # the reference's own Python / numpy algorithms, restated (oracle), on a sample of the same graphs
         from oracle import graph as og

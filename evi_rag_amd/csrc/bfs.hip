@@ -9,10 +9,13 @@
 //                           (seed, answer) pair with a path, the edges u->v with
 //                           dist_s[u] + 1 + dist_a[v] == dist_s[a] (either orientation when undirected)
 //
-// One workgroup per BFS job (a graph and a source set): level-synchronous, the frontier is found by
-// scanning the graph's dist slice (coalesced) and expanded by a CSR row gather; levels are separated
-// by workgroup barriers, never by launches.  Integer work, HBM/L2-latency-bound:
-// per level N_g * 4 bytes (scan) + sum_frontier deg * 4 (neighbours) + deg * 4 (dist probes).
+// One workgroup per BFS job (a graph and a source set): level-synchronous, levels are separated by workgroup barriers,
+// never by launches (a level of a 3 000-node graph is two dependent row gathers deep: spreading one BFS over several
+// CUs would pay a cross-CU barrier of ~5 us per level for ~2 us of work).  Graphs of up to 4 096 nodes — every WebQSP / CWQ
+// graph — keep their levels AND two frontier queues in LDS: a level touches only the frontier's rows
+// (sum_frontier deg * 4 B of neighbours, LDS probes), never the whole dist array; a node is claimed for the next frontier
+// by an LDS compare-and-swap, so it is queued once.  Larger graphs fall back to scanning the dist slice per level
+// (N_g * 4 B per level).  Integer work, L2-latency-bound.
 #include "common.hpp"
 
 namespace evi {
@@ -28,7 +31,101 @@ struct BfsShared {
     int hubs[kBfsHubCap];
 };
 
-// Level-synchronous expansion of the sources already marked 0 in dist[0..ng) (everything else -1).
+// Frontier-queue BFS for graphs whose levels and queues fit LDS.  dist[0..ng) = -1 except the sources (0), which are
+// already in queue[0][0..qcount[0]).  Every thread of the workgroup calls; returns after the first empty frontier.
+constexpr int kBfsThreadDegree = 16;   // frontier nodes up to this degree are expanded by the thread that dequeues them
+constexpr int kBfsWaveDegree = 512;    // up to this by one wave (lanes stride the rows), above by the whole workgroup
+constexpr int kBfsBigCap = 64;
+
+struct BfsQueueShared {
+    int qcount[2];
+    int hub_count;
+    int big_count;
+    int hubs[kBfsHubCap];
+    int big[kBfsBigCap];
+};
+
+__device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __restrict__ q0, int32_t* __restrict__ q1, int64_t n0,
+                                       const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
+                                       const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr, int mode,
+                                       BfsQueueShared* sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int cur = 0;
+    for (int level = 0;; ++level, cur ^= 1) {
+        __syncthreads();  // qcount[cur] and the queue are complete
+        const int n = sh->qcount[cur];
+        if (n == 0) break;  // uniform
+        if (tid == 0) {
+            sh->qcount[cur ^ 1] = 0;
+            sh->hub_count = 0;
+            sh->big_count = 0;
+        }
+        __syncthreads();
+        const int32_t* q = cur ? q1 : q0;
+        int32_t* qn = cur ? q0 : q1;
+        auto visit = [&](int w) {
+            if (dist[w] < 0 && atomicCAS(&dist[w], -1, level + 1) == -1) qn[atomicAdd(&sh->qcount[cur ^ 1], 1)] = w;
+        };
+        // A row of a frontier node, walked by `width` cooperating threads (this one is number `me`): four entries per
+        // trip, the loads of a trip issued before the first LDS compare-and-swap (past-the-end indices are clamped and
+        // their values dropped) — a walk that probes after every load runs at one L2 latency per neighbour.
+        auto walk = [&](const int32_t* __restrict__ nbr, int b, int e, int me, int width) {
+            for (int p0 = b + me; p0 < e; p0 += 4 * width) {
+                int w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = nbr[p0 + u * width < e ? p0 + u * width : e - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p0 + u * width < e) visit(w[u] - (int)n0);
+            }
+        };
+        for (int i = tid; i < n; i += kBfsThreads) {
+            const int v = q[i];
+            const int64_t gv = n0 + v;
+            int ob = 0, oe = 0, ib = 0, ie = 0;
+            if (mode != 2) {
+                ob = out_ptr[gv];
+                oe = out_ptr[gv + 1];
+            }
+            if (mode != 1) {
+                ib = in_ptr[gv];
+                ie = in_ptr[gv + 1];
+            }
+            const int deg = (oe - ob) + (ie - ib);
+            if (deg > kBfsWaveDegree) {  // power-law hubs: a 2 000-entry row is 30 trips for a wave, 2 for the workgroup
+                const int slot = atomicAdd(&sh->big_count, 1);
+                if (slot < kBfsBigCap) {
+                    sh->big[slot] = v;
+                    continue;
+                }
+            }
+            if (deg > kBfsThreadDegree) {
+                const int slot = atomicAdd(&sh->hub_count, 1);
+                if (slot < kBfsHubCap) {
+                    sh->hubs[slot] = v;
+                    continue;
+                }  // list full: expand it here (correct, slower)
+            }
+            walk(out_nbr, ob, oe, 0, 1);
+            walk(in_nbr, ib, ie, 0, 1);
+        }
+        __syncthreads();
+        const int nh = sh->hub_count < kBfsHubCap ? sh->hub_count : kBfsHubCap;
+        for (int h = wave; h < nh; h += kBfsThreads / 64) {
+            const int64_t gv = n0 + sh->hubs[h];
+            if (mode != 2) walk(out_nbr, out_ptr[gv], out_ptr[gv + 1], lane, 64);
+            if (mode != 1) walk(in_nbr, in_ptr[gv], in_ptr[gv + 1], lane, 64);
+        }
+        const int nb = sh->big_count < kBfsBigCap ? sh->big_count : kBfsBigCap;
+        for (int h = 0; h < nb; ++h) {
+            const int64_t gv = n0 + sh->big[h];
+            if (mode != 2) walk(out_nbr, out_ptr[gv], out_ptr[gv + 1], tid, kBfsThreads);
+            if (mode != 1) walk(in_nbr, in_ptr[gv], in_ptr[gv + 1], tid, kBfsThreads);
+        }
+    }
+}
+
+// Level-synchronous expansion of the sources already marked 0 in dist[0..ng) (everything else -1), by scanning dist.
 // mode 0: undirected (out- and in-rows), 1: follow edges (out-rows), 2: against edges (in-rows).
 // A frontier node is expanded by the thread that finds it, unless its rows are long (power-law hubs):
 // those are queued in LDS and expanded by one wave each, lanes striding the row.
@@ -106,6 +203,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
     int mode, int32_t* __restrict__ dist_out, int lds_nodes) {
     __shared__ BfsShared sh;
+    __shared__ BfsQueueShared shq;
     extern __shared__ int32_t lds_dist[];  // [lds_nodes]: the levels of graphs that fit stay on chip until the end
     const int j = blockIdx.x, tid = threadIdx.x;
     const int g = job_graph[j];
@@ -113,13 +211,23 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     const int ng = (int)(n1 - n0);
     int32_t* out = dist_out + dist_off[j];  // local node id -> level
     int32_t* dist = ng <= lds_nodes ? lds_dist : out;
+    const int qcap = lds_nodes / 3;  // queue mode: dist | queue 0 | queue 1, a third of the dynamic LDS each
+    const bool queued = ng <= qcap;
+    if (tid == 0) shq.qcount[0] = shq.qcount[1] = 0;
     for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
     __syncthreads();
     for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
         const int64_t s = src_idx[i];
-        if (s >= n0 && s < n1) dist[s - n0] = 0;  // out-of-range sources are ignored (:619)
+        if (s < n0 || s >= n1) continue;  // out-of-range sources are ignored (:619)
+        if (!queued)
+            dist[s - n0] = 0;
+        else if (atomicCAS(&dist[s - n0], -1, 0) == -1)  // a source listed twice is queued once
+            lds_dist[qcap + atomicAdd(&shq.qcount[0], 1)] = (int32_t)(s - n0);
     }
-    bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &sh);
+    if (queued)
+        bfs_block_queue(dist, lds_dist + qcap, lds_dist + 2 * qcap, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &shq);
+    else
+        bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &sh);
     if (dist != out) {
         __syncthreads();
         for (int v = tid; v < ng; v += kBfsThreads) out[v] = dist[v];

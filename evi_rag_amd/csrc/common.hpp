@@ -335,16 +335,7 @@ __device__ inline uint64_t block_kth_largest(SelectShared& sh, Load load, int64_
                 if (i0 + (int64_t)u * nt < cnt && (key[u] & mask) == prefix) atomicAdd(&sh.hist[(key[u] >> shift) & 0xFF], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int64_t acc = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (acc + sh.hist[d] >= need) break;
-                acc += sh.hist[d];
-            }
-            sh.scalar[1] = (uint32_t)d;
-            sh.scalar[2] = (uint32_t)acc;
-        }
+        radix_pick_digit(sh, (uint32_t)need);  // one wave scans the 256 buckets (need <= cnt < 2^32)
         __syncthreads();
         need -= sh.scalar[2];
         prefix |= (uint64_t)sh.scalar[1] << shift;

@@ -54,6 +54,17 @@ __global__ void k_softmax_logit(const float* __restrict__ s, const int64_t* __re
 }
 
 // ---- G8 ---------------------------------------------------------------------------------------------
+// one launch zeroes the E-byte mask and the status word (two hipMemsetAsync cost two ~4.5 us fill kernels)
+__global__ void k_zero_mask(uint8_t* __restrict__ mask, int64_t E, int32_t* __restrict__ status) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i == 0) *status = 0;
+    if (i + 16 <= E && (reinterpret_cast<uintptr_t>(mask) & 15) == 0) {
+        *reinterpret_cast<uint4*>(mask + i) = make_uint4(0, 0, 0, 0);
+    } else {
+        for (int64_t j = i; j < E && j < i + 16; ++j) mask[j] = 0;
+    }
+}
+
 // One workgroup per (seed entry).  Incident entries of seed s: its out-row (s is the head: "heads
 // block") then its in-row (s is the tail: "tails block").  The reference ranks them by a stable
 // descending score sort of [heads block ; tails block] (each block in ascending edge id), so equal
@@ -89,7 +100,20 @@ __global__ __launch_bounds__(kSelectThreads) void k_select_start_edges(
         const uint32_t e = (uint32_t)(tail_block ? in_eid[ib + (i - dout)] : out_eid[ob + i]);
         return make_key(scores[e], (tail_block ? 0x80000000u : 0u) | e);
     };
-    // only the SET of the k best entries is needed: find the k-th key, keep everything at or above it
+    // only the SET of the k best entries is needed: find the k-th key, keep everything at or above it.  The keys of a row
+    // that fits LDS (8 192 entries: every seed but the largest hubs) are gathered ONCE — each costs two dependent loads,
+    // edge id then score — and the eight radix passes read them from LDS.
+    if (deg <= kSortCap) {
+        for (int i = threadIdx.x; i < deg; i += blockDim.x) sh.keys[i] = load(i);
+        __syncthreads();
+        auto staged = [&](int64_t i) -> uint64_t { return sh.keys[i]; };
+        const uint64_t kth = block_kth_largest(sh, staged, deg, k);
+        for (int i = threadIdx.x; i < deg; i += blockDim.x) {
+            const uint64_t key = sh.keys[i];
+            if (key >= kth) mask[key_index(key) & 0x7FFFFFFFu] = 1;
+        }
+        return;
+    }
     const uint64_t kth = block_kth_largest(sh, load, deg, k);
     for (int i = threadIdx.x; i < deg; i += blockDim.x) {
         const uint64_t key = load(i);
@@ -160,8 +184,11 @@ extern "C" int evi_select_start_edges(const float* edge_scores, int64_t E, const
     EVI_REQUIRE(out_mask || E == 0, "evi_select_start_edges: null mask");
     EVI_REQUIRE(status, "evi_select_start_edges: null status");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    EVI_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), st));
-    if (E > 0) EVI_HIP_CHECK(hipMemsetAsync(out_mask, 0, (size_t)E, st));
+    {
+        const int64_t threads = (E + 15) / 16 > 0 ? (E + 15) / 16 : 1;
+        hipLaunchKernelGGL(k_zero_mask, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, out_mask, E, status);
+        EVI_LAUNCH_CHECK();
+    }
     if (E == 0 || num_seeds == 0) return EVI_OK;
     EVI_REQUIRE(edge_scores && seed_nodes && in_ptr && in_eid && out_ptr && out_eid, "evi_select_start_edges: null pointer");
     hipLaunchKernelGGL(k_select_start_edges, dim3((unsigned)num_seeds), dim3(kSelectThreads), 0, st, edge_scores,

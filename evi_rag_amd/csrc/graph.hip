@@ -8,10 +8,17 @@
 //   evi_dde_node_struct   — PEConv/DDE mean propagation + topic-major stacking
 //                           (src/models/components/graph.py:13-74, retriever.py:519-553)
 //
-// Graphs in a batch are independent and small (N_g ~ 10^3, E_g ~ 10^3..10^5), so a graph never
-// leaves its CU: rounds are separated by workgroup barriers, not kernel launches, and the per-node
-// state stays in L2.  All kernels are HBM/L2-latency-bound integer and gather work; algorithmic
-// bytes per DDE round = E*(4 nbr + C*4 gather) + N*(8 rowptr + C*4 write).
+// Graphs in a batch are independent and small (N_g ~ 10^3, E_g ~ 10^3..10^5).  All kernels are HBM/L2-latency-bound
+// integer and gather work; algorithmic bytes per DDE round = E*(4 nbr + C*4 gather) + N*(8 rowptr + C*4 write)
+// (SURVEY.md §8d).  The reference's batch is 32 graphs, so "one workgroup per graph" leaves 7/8 of the chip idle:
+//   * the CSR is a counting sort whose counters live in LDS (global atomics run at the memory side, ~20 G/s scattered);
+//     a graph's edge list is cut into P parts (P = 8 at 32 graphs, 1 from 512 graphs on), every part counts and fills from
+//     its own LDS counters, and a per-graph scan in between turns the P x N_g partial counts into row pointers and
+//     per-part cursors — B x P workgroups, no global atomics, no per-level barriers of 1024 threads;
+//   * DDE is node-parallel over the WHOLE batch: one thread per (node, chain) — the forward chain walks in-rows, the
+//     reverse chain out-rows, both are independent given the previous round — and one launch per round pair instead of
+//     workgroup barriers, so a round is one row gather deep whatever the batch size.  Long rows (power-law hubs) are
+//     summed by the whole wave.
 //
 // CSR rows are filled through atomic cursors, so the order of a row's entries is not defined.
 // Nothing downstream depends on it: BFS levels are order-free, and DDE sums a row in f64 before
@@ -23,6 +30,7 @@ namespace evi {
 constexpr int kGraphThreads = 1024;
 constexpr int kHubDegree = 32;
 constexpr int kHubListCap = 4096;
+constexpr int kCsrMaxParts = 8;  // edge-list parts per graph of the small-batch CSR build
 
 // ---- edge -> graph assignment -----------------------------------------------------------------
 // status bits: 1 = head outside [ptr[0], ptr[B]), 2 = head/tail in different graphs,
@@ -90,32 +98,47 @@ struct GraphShared {
 };
 
 // Exclusive scan of cnt[0..n1-n0) (one counter per node of the graph) into ptr[n0..n1) (+ base);
-// ptr[n1] = base + total.  All threads call.
-__device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt, int32_t* ptr, int64_t n0,
-                                            int64_t n1, int base) {
-    const int tid = threadIdx.x;
-    if (tid == 0) sh.carry = base;
-    __syncthreads();
+// ptr[n1] = base + total.  All threads call.  Wave-level shuffles scan 64 counters at a time, the 16 wave totals go
+// through LDS: two barriers per 1024 nodes instead of the twenty of a log-step LDS scan.
+__device__ inline int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(v, off, 64);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+template <class Count>
+__device__ inline void block_exclusive_scan_fn(GraphShared& sh, Count cnt, int32_t* ptr, int64_t n0, int64_t n1, int base) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kGraphThreads / 64;
+    int carry = base;
     for (int64_t v0 = n0; v0 < n1; v0 += kGraphThreads) {
         const int64_t v = v0 + tid;
-        const int val = v < n1 ? cnt[v - n0] : 0;
-        sh.scan[tid] = val;
+        const int val = v < n1 ? cnt((int)(v - n0)) : 0;
+        const int incl = wave_inclusive_scan(val);
+        if (lane == 63) sh.scan[wave] = incl;
         __syncthreads();
-        for (int off = 1; off < kGraphThreads; off <<= 1) {
-            const int add = tid >= off ? sh.scan[tid - off] : 0;
-            __syncthreads();
-            sh.scan[tid] += add;
-            __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const int t = sh.scan[w];
+            if (w < wave) before += t;
+            total += t;
         }
-        const int incl = sh.scan[tid];
-        const int carry = sh.carry;
-        if (v < n1) ptr[v] = carry + incl - val;
-        __syncthreads();
-        if (tid == kGraphThreads - 1) sh.carry = carry + incl;
-        __syncthreads();
+        if (v < n1) ptr[v] = carry + before + incl - val;
+        carry += total;
+        __syncthreads();  // sh.scan is rewritten by the next chunk
     }
-    if (tid == 0) ptr[n1] = sh.carry;
+    if (tid == 0) ptr[n1] = carry;
     __syncthreads();
+}
+
+__device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt, int32_t* ptr, int64_t n0,
+                                            int64_t n1, int base) {
+    block_exclusive_scan_fn(sh, [&](int i) { return cnt[i]; }, ptr, n0, n1, base);
 }
 
 // Counting-sort CSR of one graph.  cin / cout are the per-node counters, indexed by LOCAL node id: in
@@ -174,86 +197,258 @@ __global__ __launch_bounds__(kGraphThreads) void k_graph_csr(
                   out_eid);
 }
 
+// ---- CSR in P parts per graph (small batches) ------------------------------------------------------------
+// part counts / cursors: [2][P][N] int32 in the workspace (in-counters first, out-counters second), part-major: the count
+// and fill kernels of part p stream their own [N_g] slice, the scan kernel reads P coalesced streams.
+__device__ inline void part_range(int64_t e0, int64_t e1, int P, int p, int64_t& b, int64_t& e) {
+    const int64_t len = e1 - e0;
+    b = e0 + len * p / P;
+    e = e0 + len * (p + 1) / P;
+}
+
+// A: count the part's edges per node in LDS, publish the partial counts.
+__global__ __launch_bounds__(kGraphThreads) void k_csr_part_count(
+    const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int64_t N, int P, int32_t* __restrict__ part, int lds_nodes) {
+    extern __shared__ int32_t lds_cnt[];  // [2 * lds_nodes]
+    const int g = blockIdx.x / P, p = blockIdx.x % P, tid = threadIdx.x;
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    if (ng > lds_nodes) return;  // oversize graph: k_csr_part_scan builds it whole (global counters)
+    int32_t* cin = lds_cnt;
+    int32_t* cout = lds_cnt + lds_nodes;
+    for (int v = tid; v < ng; v += kGraphThreads) cin[v] = cout[v] = 0;
+    __syncthreads();
+    int64_t b, e;
+    part_range(edge_ptr[g], edge_ptr[g + 1], P, p, b, e);
+    for (int64_t i = b + tid; i < e; i += kGraphThreads) {
+        const int64_t s = edge_index[i], d = edge_index[E + i];
+        if (s < n0 || s >= n1 || d < n0 || d >= n1) continue;
+        atomicAdd(&cin[d - n0], 1);
+        atomicAdd(&cout[s - n0], 1);
+    }
+    __syncthreads();
+    int32_t* pin = part + (int64_t)p * N + n0;
+    int32_t* pout = part + ((int64_t)P + p) * N + n0;
+    for (int v = tid; v < ng; v += kGraphThreads) {
+        pin[v] = cin[v];
+        pout[v] = cout[v];
+    }
+}
+
+// B: one workgroup per graph: row pointers from the summed partial counts; the partial counts become each part's first
+// write position of the row.  Graphs too large for the parts' LDS counters are built here in one piece (legacy path).
+__global__ __launch_bounds__(kGraphThreads) void k_csr_part_scan(
+    const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int64_t N, int P, int32_t* __restrict__ part, int32_t* __restrict__ in_ptr,
+    int32_t* __restrict__ in_nbr, int32_t* __restrict__ in_eid, int32_t* __restrict__ out_ptr,
+    int32_t* __restrict__ out_nbr, int32_t* __restrict__ out_eid, int lds_nodes) {
+    __shared__ GraphShared sh;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    if (ng > lds_nodes) {  // the graph's slices of parts 0 of `part` serve as its global counters
+        csr_build(sh, edge_index, E, n0, n1, e0, e1, part + n0, part + (int64_t)P * N + n0, in_ptr, in_nbr, in_eid, out_ptr,
+                  out_nbr, out_eid);
+        return;
+    }
+    // Both halves in ONE pass: a node's in- and out-totals ride in the two halves of a 64-bit word through the same
+    // wave / workgroup scan (each sum stays below 2^31, so no carry crosses), and the part cursors are written from the
+    // registers that still hold the part counts — per 1024 nodes: 2 P independent loads, one scan, two barriers.
+    int32_t* pci = part + n0;                       // + q * N + v
+    int32_t* pco = part + (int64_t)P * N + n0;
+    unsigned long long* wsum = reinterpret_cast<unsigned long long*>(sh.scan);
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long carry = (unsigned long long)(uint32_t)e0 | ((unsigned long long)(uint32_t)e0 << 32);
+    for (int v0 = 0; v0 < ng; v0 += kGraphThreads) {
+        const int v = v0 + tid;
+        const bool live = v < ng;
+        int ci[kCsrMaxParts], co[kCsrMaxParts];
+#pragma unroll
+        for (int q = 0; q < kCsrMaxParts; ++q) {
+            ci[q] = (live && q < P) ? pci[(int64_t)q * N + v] : 0;
+            co[q] = (live && q < P) ? pco[(int64_t)q * N + v] : 0;
+        }
+        unsigned int ti = 0, to = 0;
+#pragma unroll
+        for (int q = 0; q < kCsrMaxParts; ++q) {
+            ti += (unsigned)ci[q];
+            to += (unsigned)co[q];
+        }
+        const unsigned long long val = (unsigned long long)ti | ((unsigned long long)to << 32);
+        unsigned long long incl = val;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned long long before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kGraphThreads / 64; ++w) {
+            const unsigned long long t = wsum[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        const unsigned long long mine = carry + before + incl - val;
+        if (live) {
+            int run_i = (int)(uint32_t)mine, run_o = (int)(uint32_t)(mine >> 32);
+            in_ptr[n0 + v] = run_i;
+            out_ptr[n0 + v] = run_o;
+#pragma unroll
+            for (int q = 0; q < kCsrMaxParts; ++q)
+                if (q < P) {
+                    pci[(int64_t)q * N + v] = run_i;
+                    pco[(int64_t)q * N + v] = run_o;
+                    run_i += ci[q];
+                    run_o += co[q];
+                }
+        }
+        carry += total;
+        __syncthreads();  // wsum is rewritten by the next chunk
+    }
+    if (tid == 0) {
+        in_ptr[n1] = (int)(uint32_t)carry;
+        out_ptr[n1] = (int)(uint32_t)(carry >> 32);
+    }
+}
+
+// C: every part scatters its edges from its own cursors (LDS).
+__global__ __launch_bounds__(kGraphThreads) void k_csr_part_fill(
+    const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int64_t N, int P, const int32_t* __restrict__ part,
+    int32_t* __restrict__ in_nbr, int32_t* __restrict__ in_eid, int32_t* __restrict__ out_nbr,
+    int32_t* __restrict__ out_eid, int lds_nodes) {
+    extern __shared__ int32_t lds_cnt[];
+    const int g = blockIdx.x / P, p = blockIdx.x % P, tid = threadIdx.x;
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    if (ng > lds_nodes) return;
+    int32_t* cin = lds_cnt;
+    int32_t* cout = lds_cnt + lds_nodes;
+    const int32_t* pin = part + (int64_t)p * N + n0;
+    const int32_t* pout = part + ((int64_t)P + p) * N + n0;
+    for (int v = tid; v < ng; v += kGraphThreads) {
+        cin[v] = pin[v];
+        cout[v] = pout[v];
+    }
+    __syncthreads();
+    int64_t b, e;
+    part_range(edge_ptr[g], edge_ptr[g + 1], P, p, b, e);
+    for (int64_t i = b + tid; i < e; i += kGraphThreads) {
+        const int64_t s = edge_index[i], d = edge_index[E + i];
+        if (s < n0 || s >= n1 || d < n0 || d >= n1) continue;
+        const int pi = atomicAdd(&cin[d - n0], 1);
+        in_nbr[pi] = (int32_t)s;
+        in_eid[pi] = (int32_t)i;
+        const int po = atomicAdd(&cout[s - n0], 1);
+        out_nbr[po] = (int32_t)d;
+        out_eid[po] = (int32_t)i;
+    }
+}
+
 // ---- DDE --------------------------------------------------------------------------------------------
 // ns[v][c*S + j], S = 1 + R + RR: j = 0 topic, 1..R forward rounds, R+1..R+RR reverse rounds.
-// One mean-propagation round from column jin to column jout over the given CSR (rows = receivers).
+// One launch = one mean-propagation round of BOTH chains over the whole batch: thread t < Npad works on node t of the
+// forward chain (receivers' rows = in-rows), thread Npad + t on node t of the reverse chain (out-rows).  A round reads
+// column jin of the neighbours (jin == 0: the topic one-hot itself, so no initial copy pass is needed) and writes column
+// jout of its own node; the first launch also copies the topic columns into ns[:, c*S].
+struct DdeChain {
+    const int32_t* ptr;
+    const int32_t* nbr;
+    int jin, jout;  // jout < 0: chain idle in this launch
+};
+
 template <int C>
-__device__ inline void dde_round(GraphShared& sh, float* __restrict__ ns, int S, int jin, int jout,
-                                 const int32_t* __restrict__ ptr, const int32_t* __restrict__ nbr, int64_t n0,
-                                 int64_t n1) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) sh.hub_count = 0;
-    __syncthreads();
-    bool overflow_hub = false;
-    for (int64_t v = n0 + tid; v < n1; v += kGraphThreads) {
-        const int b = ptr[v], e = ptr[v + 1];
-        const int deg = e - b;
-        if (deg > kHubDegree) {
-            const int slot = atomicAdd(&sh.hub_count, 1);
-            if (slot < kHubListCap) {
-                sh.hubs[slot] = (int)(v - n0);
-                continue;
-            }
-            overflow_hub = true;  // list full: fall through and do it serially (correct, slower)
-        }
+__global__ __launch_bounds__(256) void k_dde_round(const float* __restrict__ topic, int topic_stride, float* __restrict__ ns,
+                                                   int S, int64_t N, int64_t Npad, DdeChain fwd, DdeChain rev,
+                                                   int write_topic) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int chain = t >= Npad ? 1 : 0;  // wave-uniform: Npad is a multiple of 64
+    const int64_t v = t - (chain ? Npad : 0);
+    const DdeChain ch = chain ? rev : fwd;
+    const bool live = v < N;
+    if (live && write_topic && chain == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) ns[v * (C * S) + c * S] = topic[v * topic_stride + c];
+    }
+    if (ch.jout < 0) return;  // uniform per wave
+    const bool from_topic = ch.jin == 0;
+    auto prev = [&](int64_t u, int c) -> float {
+        return from_topic ? topic[u * topic_stride + c] : ns[u * (C * S) + c * S + ch.jin];
+    };
+    int b = 0, e = 0;
+    if (live) {
+        b = ch.ptr[v];
+        e = ch.ptr[v + 1];
+    }
+    const int deg = e - b;
+    const bool hub = deg > kHubDegree;
+    if (live && !hub) {
         double acc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = 0.0;
-        for (int p = b; p < e; ++p) {
-            const float* xu = ns + (int64_t)nbr[p] * (C * S) + jin;
+        // four neighbours per trip, every load of a trip issued before the first use (an index past the row's end is
+        // clamped and its value dropped): a row of <= 4 entries costs two dependent memory latencies, not two per entry
+        for (int p = b; p < e; p += 4) {
+            int64_t u[4];
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += (double)xu[c * S];
+            for (int i = 0; i < 4; ++i) u[i] = ch.nbr[p + i < e ? p + i : e - 1];
+            float x[4][C];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < C; ++c) x[i][c] = prev(u[i], c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (p + i < e) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += (double)x[i][c];
+                }
         }
         const float cnt = deg > 0 ? (float)deg : 1.0f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) ns[v * (C * S) + c * S + jout] = (float)acc[c] / cnt;
+        for (int c = 0; c < C; ++c) ns[v * (C * S) + c * S + ch.jout] = (float)acc[c] / cnt;
     }
-    (void)overflow_hub;
-    __syncthreads();
-    const int nh = sh.hub_count < kHubListCap ? sh.hub_count : kHubListCap;
-    for (int h = wave; h < nh; h += kGraphThreads / 64) {
-        const int64_t v = n0 + sh.hubs[h];
-        const int b = ptr[v], e = ptr[v + 1];
+    // long rows (power-law hubs): the wave sums them together, one after the other
+    unsigned long long hubs = __ballot(hub);
+    while (hubs) {
+        const int l = __ffsll((long long)hubs) - 1;
+        hubs &= hubs - 1;
+        const int hb = __shfl(b, l, 64), he = __shfl(e, l, 64);
+        const int64_t hv = (t - lane + l) - (chain ? Npad : 0);
         double acc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = 0.0;
-        for (int p = b + lane; p < e; p += 64) {
-            const float* xu = ns + (int64_t)nbr[p] * (C * S) + jin;
+        for (int p = hb + lane; p < he; p += 256) {  // four entries per lane per trip, loads first
+            int64_t u[4];
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += (double)xu[c * S];
+            for (int i = 0; i < 4; ++i) u[i] = ch.nbr[p + 64 * i < he ? p + 64 * i : he - 1];
+            float x[4][C];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < C; ++c) x[i][c] = prev(u[i], c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (p + 64 * i < he) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += (double)x[i][c];
+                }
         }
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
         if (lane == 0) {
-            const float cnt = (float)(e - b);
+            const float cnt = (float)(he - hb);
 #pragma unroll
-            for (int c = 0; c < C; ++c) ns[v * (C * S) + c * S + jout] = (float)acc[c] / cnt;
+            for (int c = 0; c < C; ++c) ns[hv * (C * S) + c * S + ch.jout] = (float)acc[c] / cnt;
         }
     }
-    __syncthreads();
-}
-
-template <int C>
-__global__ __launch_bounds__(kGraphThreads) void k_dde(
-    const float* __restrict__ topic, int topic_stride, const int64_t* __restrict__ node_ptr,
-    const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
-    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr, int rounds, int rev_rounds,
-    float* __restrict__ ns) {
-    __shared__ GraphShared sh;
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
-    const int S = 1 + rounds + rev_rounds;
-    for (int64_t v = n0 + tid; v < n1; v += kGraphThreads)
-#pragma unroll
-        for (int c = 0; c < C; ++c) ns[v * (C * S) + c * S] = topic[v * topic_stride + c];
-    __syncthreads();
-    // forward rounds: messages flow src -> dst, so a node averages over its in-edges
-    for (int j = 1; j <= rounds; ++j) dde_round<C>(sh, ns, S, j - 1, j, in_ptr, in_nbr, n0, n1);
-    // reverse rounds on edge_index.flip(0): a node averages over its out-edges' heads
-    for (int j = 1; j <= rev_rounds; ++j)
-        dde_round<C>(sh, ns, S, j == 1 ? 0 : rounds + j - 1, rounds + j, out_ptr, out_nbr, n0, n1);
 }
 
 }  // namespace evi
@@ -304,7 +499,22 @@ extern "C" int evi_qa_edge_mask(const int64_t* edge_index, int64_t E, int64_t nu
     return EVI_OK;
 }
 
-extern "C" size_t evi_graph_csr_workspace_bytes(int64_t N) { return (size_t)(N > 0 ? N : 1) * 2 * sizeof(int32_t); }
+constexpr int kCsrLdsNodes = 6144;  // 48 KiB of dynamic LDS: the counters of graphs up to 6144 nodes stay on chip
+
+// parts per graph: enough workgroups to cover the chip twice at small batches, one from 512 graphs on
+static int csr_parts(int B) {
+    int P = 1;
+    while (P < kCsrMaxParts && (int64_t)B * P * 2 <= 512) P <<= 1;
+    if (const char* e = getenv("EVI_CSR_PARTS")) {  // tuning / tests: force the number of parts (1, 2, 4, 8)
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
+    }
+    return P;
+}
+
+extern "C" size_t evi_graph_csr_workspace_bytes(int64_t N) {
+    return (size_t)(N > 0 ? N : 1) * 2 * kCsrMaxParts * sizeof(int32_t);
+}
 
 extern "C" int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t* node_ptr,
                              const int64_t* edge_ptr, int B, int64_t N, int32_t* in_ptr, int32_t* in_nbr,
@@ -318,22 +528,32 @@ extern "C" int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t
     if (workspace_bytes < evi_graph_csr_workspace_bytes(N))
         return fail(EVI_ERR_NOMEM, "evi_graph_csr: workspace %zu B < %zu B", workspace_bytes,
                     evi_graph_csr_workspace_bytes(N));
-    int32_t* cnt_in = static_cast<int32_t*>(workspace);
-    int32_t* cnt_out = cnt_in + (N > 0 ? N : 1);
-    // 48 KiB of dynamic LDS: the counters of graphs up to 6144 nodes stay on chip (larger graphs use the workspace)
-    constexpr int kLdsNodes = 6144;
-    hipLaunchKernelGGL(k_graph_csr, dim3(B), dim3(kGraphThreads), 2 * kLdsNodes * sizeof(int32_t),
-                       reinterpret_cast<hipStream_t>(stream), edge_index, E, node_ptr, edge_ptr, in_ptr, in_nbr, in_eid,
-                       out_ptr, out_nbr, out_eid, cnt_in, cnt_out, kLdsNodes);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int P = csr_parts(B);
+    const size_t lds = 2 * kCsrLdsNodes * sizeof(int32_t);
+    if (P == 1) {
+        int32_t* cnt_in = static_cast<int32_t*>(workspace);
+        int32_t* cnt_out = cnt_in + (N > 0 ? N : 1);
+        hipLaunchKernelGGL(k_graph_csr, dim3(B), dim3(kGraphThreads), lds, st, edge_index, E, node_ptr, edge_ptr, in_ptr, in_nbr,
+                           in_eid, out_ptr, out_nbr, out_eid, cnt_in, cnt_out, kCsrLdsNodes);
+    } else {
+        int32_t* part = static_cast<int32_t*>(workspace);  // [2][N][P]
+        const int64_t Nn = N > 0 ? N : 1;
+        hipLaunchKernelGGL(k_csr_part_count, dim3(B * P), dim3(kGraphThreads), lds, st, edge_index, E, node_ptr, edge_ptr, Nn, P,
+                           part, kCsrLdsNodes);
+        hipLaunchKernelGGL(k_csr_part_scan, dim3(B), dim3(kGraphThreads), 0, st, edge_index, E, node_ptr, edge_ptr, Nn, P, part,
+                           in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid, kCsrLdsNodes);
+        hipLaunchKernelGGL(k_csr_part_fill, dim3(B * P), dim3(kGraphThreads), lds, st, edge_index, E, node_ptr, edge_ptr, Nn, P,
+                           (const int32_t*)part, in_nbr, in_eid, out_nbr, out_eid, kCsrLdsNodes);
+    }
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
 
-extern "C" int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics,
-                                   const int64_t* node_ptr, int B, const int32_t* in_ptr, const int32_t* in_nbr,
-                                   const int32_t* out_ptr, const int32_t* out_nbr, int rounds, int rev_rounds,
-                                   float* node_struct, void* stream) {
-    EVI_REQUIRE(B >= 1, "evi_dde_node_struct: B must be >= 1, got %d", B);
+extern "C" int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
+                                   const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr,
+                                   const int32_t* out_nbr, int rounds, int rev_rounds, float* node_struct, void* stream) {
+    EVI_REQUIRE(N >= 0, "evi_dde_node_struct: N must be >= 0, got %lld", (long long)N);
     EVI_REQUIRE(rounds >= 0 && rounds <= 4 && rev_rounds >= 0 && rev_rounds <= 4,
                 "DDE supports at most 4 rounds per direction; got num_rounds=%d, num_reverse_rounds=%d.", rounds,
                 rev_rounds);
@@ -341,10 +561,21 @@ extern "C" int evi_dde_node_struct(const float* topic_one_hot, int topic_stride,
         return fail(EVI_ERR_INVALID, "num_topics must be 2 (seed vs non-seed), got %d", num_topics);
     EVI_REQUIRE(topic_stride >= num_topics, "evi_dde_node_struct: topic_one_hot feature dim %d < num_topics=%d",
                 topic_stride, num_topics);
-    EVI_REQUIRE(topic_one_hot && node_ptr && in_ptr && out_ptr && node_struct, "evi_dde_node_struct: null pointer");
-    hipLaunchKernelGGL(k_dde<2>, dim3(B), dim3(kGraphThreads), 0, reinterpret_cast<hipStream_t>(stream),
-                       topic_one_hot, topic_stride, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, rounds,
-                       rev_rounds, node_struct);
+    if (N == 0) return EVI_OK;
+    EVI_REQUIRE(topic_one_hot && in_ptr && out_ptr && node_struct, "evi_dde_node_struct: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int S = 1 + rounds + rev_rounds;
+    const int64_t Npad = (N + 63) / 64 * 64;
+    const unsigned grid = (unsigned)((2 * Npad + 255) / 256);
+    const int steps = rounds > rev_rounds ? rounds : rev_rounds;
+    for (int j = 1; j <= (steps > 0 ? steps : 1); ++j) {
+        // forward round j: a node averages column j-1 over its in-edges' tails (messages flow src -> dst);
+        // reverse round j (edge_index.flip(0)): over its out-edges' heads, restarted from the one-hot
+        DdeChain fwd{in_ptr, in_nbr, j - 1, j <= rounds ? j : -1};
+        DdeChain rev{out_ptr, out_nbr, j == 1 ? 0 : rounds + j - 1, j <= rev_rounds ? rounds + j : -1};
+        hipLaunchKernelGGL(k_dde_round<2>, dim3(grid), dim3(256), 0, st, topic_one_hot, topic_stride, node_struct, S, N, Npad,
+                           fwd, rev, j == 1 ? 1 : 0);
+    }
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -530,7 +530,7 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.out_ptr = take((size_t)(N + 1) * 4);
     L.out_nbr = take(e1 * 4);
     L.out_eid = take(e1 * 4);
-    L.csr_ws = take(n1 * 8);
+    L.csr_ws = take(evi_graph_csr_workspace_bytes(N));
     L.wa = take((size_t)H * D * f);
     L.wb = take((size_t)H * D * f);
     L.wc = take((size_t)H * D * f);
@@ -557,10 +557,6 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
 
 using namespace evi;
 
-extern "C" int evi_graph_csr(const int64_t*, int64_t, const int64_t*, const int64_t*, int, int64_t, int32_t*, int32_t*,
-                             int32_t*, int32_t*, int32_t*, int32_t*, void*, size_t, void*);
-extern "C" int evi_dde_node_struct(const float*, int, int, const int64_t*, int, const int32_t*, const int32_t*,
-                                   const int32_t*, const int32_t*, int, int, float*, void*);
 
 extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                                         int dde_reverse_rounds, int64_t num_relations) {
@@ -649,9 +645,9 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     // 2. structure features
     if ((rc = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
                             I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
-                            (size_t)N * 8, stream)))
+                            evi_graph_csr_workspace_bytes(N), stream)))
         return rc;
-    if ((rc = evi_dde_node_struct(b->topic_one_hot, b->topic_stride, 2, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
+    if ((rc = evi_dde_node_struct(b->topic_one_hot, b->topic_stride, 2, N, I32(L.in_ptr), I32(L.in_nbr),
                                   I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
         return rc;
 

@@ -532,20 +532,28 @@ class GraphCSR:
         self.out_ptr, self.out_nbr, self.out_eid = out_ptr, out_nbr, out_eid
 
 
-def graph_csr(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr: torch.Tensor) -> GraphCSR:
+def graph_csr(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr: torch.Tensor, *, num_nodes: Optional[int] = None,
+              out: Optional[GraphCSR] = None, workspace: Optional[torch.Tensor] = None) -> GraphCSR:
+    """In-/out-edge CSR of every graph of the batch (evi_graph_csr).  num_nodes: the batch's node count when the caller
+    knows it (saves the read-back of node_ptr[-1]); out / workspace: caller-owned buffers (hipGraph capture, steady loops)."""
     dev = _require_gpu(edge_index, node_ptr, edge_ptr)
     ei = _i64c(edge_index, "edge_index")
     ptr = _i64c(node_ptr.view(-1), "node_ptr")
     eptr = _i64c(edge_ptr.view(-1), "edge_ptr")
     E, B = ei.size(1), ptr.numel() - 1
-    N = int(ptr[-1].item())
+    N = int(num_nodes) if num_nodes is not None else int(ptr[-1].item())
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)  # noqa: E731
-    csr = GraphCSR(mk(N + 1), mk(E), mk(E), mk(N + 1), mk(E), mk(E))
+    csr = out if out is not None else GraphCSR(mk(N + 1), mk(E), mk(E), mk(N + 1), mk(E), mk(E))
+    if out is not None and (csr.in_ptr.numel() < N + 1 or csr.in_nbr.numel() < max(E, 1) or csr.out_ptr.numel() < N + 1):
+        raise ValueError("out: CSR buffers too small for this batch")
     lib = _lib.load()
-    ws = _workspace(dev, "graph_csr", int(lib.evi_graph_csr_workspace_bytes(N)))
+    need = int(lib.evi_graph_csr_workspace_bytes(N))
+    if workspace is not None and workspace.numel() * workspace.element_size() < need:
+        raise ValueError(f"workspace holds {workspace.numel() * workspace.element_size()} B, need {need} B")
+    ws = workspace if workspace is not None else _workspace(dev, "graph_csr", need)
     _lib.check(lib.evi_graph_csr(_ptr(ei), E, _ptr(ptr), _ptr(eptr), B, N, csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
                                  csr.in_eid.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
-                                 csr.out_eid.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+                                 csr.out_eid.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), _stream(dev)))
     return csr
 
 
@@ -560,7 +568,7 @@ def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: Gr
     S = 1 + int(num_rounds) + int(num_reverse_rounds)
     ns = torch.empty((N, num_topics * S), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    _lib.check(lib.evi_dde_node_struct(_ptr(t), t.size(1), int(num_topics), _ptr(ptr), B, csr.in_ptr.data_ptr(),
+    _lib.check(lib.evi_dde_node_struct(_ptr(t), t.size(1), int(num_topics), N, csr.in_ptr.data_ptr(),
                                        csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
                                        int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))
     return ns

@@ -479,10 +479,9 @@ int evi_scatter_rows(const float* src, const int64_t* ids, int64_t n, int D, flo
  * aggr="mean", source_to_target), then rev_rounds rounds along reversed edges restarted from the
  * one-hot.  A node without in-edges gets 0.  Sums are formed in f64 and rounded once.
  * Replaces PEConv/DDE, src/models/components/graph.py:13-74. */
-int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics,
-                        const int64_t* node_ptr, int B, const int32_t* in_ptr, const int32_t* in_nbr,
-                        const int32_t* out_ptr, const int32_t* out_nbr, int rounds, int rev_rounds,
-                        float* node_struct, void* stream);
+int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
+                        const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr,
+                        const int32_t* out_nbr, int rounds, int rev_rounds, float* node_struct, void* stream);
 
 /* ---- S1-S6: the edge scorer ------------------------------------------------------------------- */
 

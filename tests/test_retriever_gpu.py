@@ -341,3 +341,68 @@ def test_out_of_range_relation_id_on_the_hint_path_is_reported_not_read_out_of_b
     with pytest.raises(IndexError, match="edge_attr out of range"):
         model.check_deferred()
     model.check_deferred()  # the flag was reset
+
+
+@pytest.mark.parametrize("parts", [1, 2, 4, 8])
+def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
+    """The CSR is built from P edge-list parts per graph at small batches (B x P workgroups, LDS counters) and in one piece
+    at large ones: every P must give the same rows (as multisets; the order inside a row is unspecified), the same DDE
+    features and the same BFS levels.  The batch mixes tiny graphs, a hub, a graph without edges and one with more nodes
+    than the parts' LDS counters hold (built in one piece inside the scan kernel)."""
+    from evi_rag_amd import _lib, ops
+
+    monkeypatch.setenv("EVI_CSR_PARTS", str(parts))
+    rng = np.random.default_rng(5)
+    sizes = [(40, 90), (3000, 10000), (1, 0), (7000, 9000), (64, 4000), (500, 1)]
+    ei, ptr, eptr = [], [0], [0]
+    for n, e in sizes:
+        s = rng.integers(0, n, e)
+        d = rng.integers(0, n, e)
+        if e > 100:
+            d[: e // 3] = 0  # a hub: a third of the edges end in node 0
+        ei.append(np.stack([s, d]) + ptr[-1])
+        ptr.append(ptr[-1] + n)
+        eptr.append(eptr[-1] + e)
+    ei = np.concatenate(ei, axis=1).astype(np.int64)
+    N, E, B = ptr[-1], eptr[-1], len(sizes)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    csr = ops.graph_csr(t(ei), t(np.asarray(ptr, np.int64)), t(np.asarray(eptr, np.int64)))
+    in_ptr, in_nbr, in_eid = (x.cpu().numpy() for x in (csr.in_ptr, csr.in_nbr, csr.in_eid))
+    out_ptr, out_nbr, out_eid = (x.cpu().numpy() for x in (csr.out_ptr, csr.out_nbr, csr.out_eid))
+    assert np.array_equal(np.diff(in_ptr[: N + 1]), np.bincount(ei[1], minlength=N)) and in_ptr[0] == 0 and in_ptr[N] == E
+    assert np.array_equal(np.diff(out_ptr[: N + 1]), np.bincount(ei[0], minlength=N)) and out_ptr[N] == E
+    assert np.array_equal(np.sort(in_eid[:E]), np.arange(E)) and np.array_equal(np.sort(out_eid[:E]), np.arange(E))
+    assert np.array_equal(ei[0][in_eid[:E]], in_nbr[:E]) and np.array_equal(ei[1][out_eid[:E]], out_nbr[:E])
+    assert np.array_equal(ei[1][in_eid[:E]], np.repeat(np.arange(N), np.diff(in_ptr[: N + 1])))
+    assert np.array_equal(ei[0][out_eid[:E]], np.repeat(np.arange(N), np.diff(out_ptr[: N + 1])))
+    # DDE over that CSR vs the oracle
+    topic = np.zeros((N, 2), np.float32)
+    topic[:, 1] = 1.0
+    seeds = np.asarray([ptr[g] + (0 if n < 3 else 2) for g, (n, _) in enumerate(sizes)])
+    topic[seeds] = [1.0, 0.0]
+    for rounds in [(2, 2), (0, 3), (4, 1), (0, 0)]:
+        ns = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds).cpu().numpy()
+        np.testing.assert_allclose(ns, ograph.node_structure_features(topic, ei, *rounds), rtol=0, atol=2e-6)
+    # multi-source BFS per graph vs the oracle (queue mode for the small graphs, scan mode for the 7000-node one)
+    lib = _lib.load()
+    jg = torch.arange(B, dtype=torch.int32, device=dev)
+    src = np.concatenate([[ptr[g], ptr[g] + min(5, n - 1), ptr[g]] for g, (n, _) in enumerate(sizes)]).astype(np.int64)
+    sp = np.arange(0, 3 * B + 1, 3).astype(np.int64)
+    doff = np.asarray(ptr[:-1], np.int64)
+    dist = torch.empty(N, dtype=torch.int32, device=dev)
+    sp_d, src_d, doff_d, ptr_d = t(sp), t(src), t(doff), t(np.asarray(ptr, np.int64))  # kept alive across the launches
+    for mode in (0, 1, 2):
+        _lib.check(lib.evi_bfs_levels(jg.data_ptr(), sp_d.data_ptr(), src_d.data_ptr(), doff_d.data_ptr(), B,
+                                      ptr_d.data_ptr(), csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
+                                      csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), mode, dist.data_ptr(), ops._stream(dev)))
+        got = dist.cpu().numpy()
+        for g, (n, e) in enumerate(sizes):
+            s_l, d_l = (ei[0, eptr[g]: eptr[g + 1]] - ptr[g]).tolist(), (ei[1, eptr[g]: eptr[g + 1]] - ptr[g]).tolist()
+            if mode == 0:
+                adj = ograph.build_undirected_adjacency(n, s_l, d_l)
+            elif mode == 1:
+                adj = ograph.build_directed_adjacency(n, s_l, d_l)
+            else:
+                adj = ograph.build_directed_adjacency(n, d_l, s_l)
+            ref = ograph.bfs_dist(n, adj, [0, min(5, n - 1), 0])
+            assert got[ptr[g]: ptr[g + 1]].tolist() == ref, (mode, g)
