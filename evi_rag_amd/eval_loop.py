@@ -37,6 +37,11 @@ class RetrieverEvaluator:
                                                         prefix=f"{split}/ablate_topic/") if ablate_topic else None
         self.callbacks = list(callbacks)
         self.emit_predict_outputs = bool(emit_predict_outputs)
+        # RetrieverOutput.edge_embeddings ([E, H] features = state_net.4, a third of the scorer's GEMM work) are consumed in
+        # the evaluation only by the feature metrics (FeatureMonitor) and by callbacks that say so (`needs_edge_embeddings`);
+        # test_step strips them from what it returns anyway (:118).  When nobody reads them the forward runs logits-only:
+        # score_head is folded into state_net.4 (csrc/scorer.hip), same logits, no features formed.
+        self.need_edge_embeddings = bool(feature_metrics) or any(getattr(cb, "needs_edge_embeddings", False) for cb in self.callbacks)
         self.reset()
 
     def reset(self) -> None:
@@ -78,7 +83,7 @@ class RetrieverEvaluator:
     def step(self, batch: Any, batch_idx: int = 0):
         """`_shared_eval_step` (:410-451)."""
         num_graphs = self._require_num_graphs(batch)
-        output = self.model(batch)
+        output = self._forward(batch)
         edge_ptr = getattr(batch, "edge_ptr", None)
         if edge_ptr is not None and isinstance(self.loss, RetrieverLoss):
             # edges grouped by graph (compute_edge_batch validated it): loss scalars stay on the device
@@ -104,7 +109,7 @@ class RetrieverEvaluator:
                 raise ValueError("topic_one_hot is required for ablation metrics.")
             batch.topic_one_hot = torch.zeros_like(torch.as_tensor(topic))
             try:
-                ablated = self.model(batch)
+                ablated = self._forward(batch)
             finally:
                 batch.topic_one_hot = topic
             self._update_metrics(self.metrics_ablate, batch, ablated, num_graphs)
@@ -118,6 +123,17 @@ class RetrieverEvaluator:
             pred.edge_embeddings = None
             return pred
         return None
+
+    def _forward(self, batch: Any):
+        lite = not self.need_edge_embeddings and hasattr(self.model, "emit_edge_embeddings")
+        if not lite:
+            return self.model(batch)
+        keep = self.model.emit_edge_embeddings
+        self.model.emit_edge_embeddings = False
+        try:
+            return self.model(batch)
+        finally:
+            self.model.emit_edge_embeddings = keep
 
     @staticmethod
     def _update_metrics(metrics: RetrieverMetricCollection, batch: Any, output, num_graphs: int) -> None:

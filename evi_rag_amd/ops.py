@@ -677,6 +677,16 @@ def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         ws = _workspace(dev, "gemm_bf16x3", int(lib.evi_gemm_nt_bf16x3_workspace_bytes(N, K)))
         _lib.check(lib.evi_gemm_nt_bf16x3(_ptr(x2), M, K, K, _ptr(w), N, K, b, _ACT[act], _ptr(out), N, ws.data_ptr(),
                                           ws.numel(), _stream(dev)))
+    elif mode == "bf16x3_ps":  # both operands pre-split into bf16 hi / lo planes, LDS-DMA staging (gemm_ps.hip)
+        Kp = (K + 31) // 32 * 32
+        planes = torch.empty((2, M + N, Kp), dtype=torch.bfloat16, device=dev)
+        s = _stream(dev)
+        if M:
+            _lib.check(lib.evi_split_rows_bf16(_ptr(x2), M, K, K, Kp, planes[0, :M].data_ptr(), planes[1, :M].data_ptr(), s))
+        _lib.check(lib.evi_split_rows_bf16(_ptr(w), N, K, K, Kp, planes[0, M:].data_ptr(), planes[1, M:].data_ptr(), s))
+        _lib.check(lib.evi_gemm_nt_bf16x3_presplit(planes[0, :M].data_ptr() if M else None, planes[1, :M].data_ptr() if M else None,
+                                                   M, Kp, planes[0, M:].data_ptr(), planes[1, M:].data_ptr(), N, b, _ACT[act],
+                                                   _ptr(out), N, s))
     else:
-        raise ValueError(f"mode must be 'f32' or 'bf16x3', got {mode!r}")
+        raise ValueError(f"mode must be 'f32', 'bf16x3' or 'bf16x3_ps', got {mode!r}")
     return out.reshape(*x.shape[:-1], N)

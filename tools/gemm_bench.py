@@ -9,6 +9,9 @@ import torch
 from evi_rag_amd import ops
 
 
+MODES = ("bf16x3", "bf16x3_ps", "f32")
+
+
 def main():
     dev = torch.device("cuda:0")
     shapes = [(131072, 2308, 768, "state_net.0 (one 65536-edge chunk, both directions)"),
@@ -21,11 +24,11 @@ def main():
         w = torch.randn((N, K), generator=g, device=dev) / K ** 0.5
         b = torch.randn((N,), generator=g, device=dev)
         res = {}
-        for mode in ("bf16x3", "f32"):
+        for mode in MODES:
             ops.linear_act(x, w, b, None, mode=mode)
         torch.cuda.synchronize()
         for rnd in range(5):
-            for mode in ("bf16x3", "f32"):
+            for mode in MODES:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 ops.linear_act(x, w, b, None, mode=mode)
@@ -36,7 +39,7 @@ def main():
         for mode, v in res.items():
             v.sort()
             med = v[len(v) // 2]
-            mult = 3.0 if mode == "bf16x3" else 1.0
+            mult = 3.0 if mode.startswith("bf16x3") else 1.0
             print(f"{name:55s} M={M} K={K} N={N} {mode:7s} median {med:.3f} ms  algorithmic {fl / med / 1e9:.0f} TF/s  "
                   f"executed {mult * fl / med / 1e9:.0f} TF/s", flush=True)
 
