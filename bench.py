@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--index-dtype", choices=["f32", "f16", "fp8"], default="f32",
                     help="storage dtype of the resident index (f16 / fp8 e4m3 + per-row scale: BASELINE configs 4 / 5; "
                          "the headline is f32)")
+    ap.add_argument("--fp8-mfma", action="store_true",
+                    help="with --index-dtype fp8: the native fp8 matrix instruction (two e4m3 query pieces) instead of widening "
+                         "the index bytes to f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-stage", action="store_true",
                     help="skip the extra leg that times the two-stage exact scan (f16 shadow selection + f32 re-scoring)")
@@ -601,7 +604,7 @@ class Ctx:
 
 
 def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, want_two_stage=False, sustained_s=0.0,
-                  cpu_rows=0, cpu_seconds=0.0, workload=None):
+                  cpu_rows=0, cpu_seconds=0.0, workload=None, fp8_mfma=False, fp8_ab=False):
     """One index configuration end to end: build the (sharded) resident index in its storage type, W untimed + K timed
     steps through ShardedIndex.topk_async, live kernel times (hipExtLaunchKernelGGL events inside the library), planted-row
     Hits@k.  Returns the JSON object of the leg (complete on rank 0)."""
@@ -629,7 +632,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         raise SystemExit("--topk-method two_stage goes with the f32 index (its f16 shadow is built here)")
     method = method if index_dtype in ("f32", "f16") else "scan"
     shadow = ops.index_shadow_f16(shard) if method == "two_stage" else None
-    index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow)
+    index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow, fp8_mfma=fp8_mfma and index_dtype == "fp8")
     index.workspace = ws
 
     def timed_run(index, steps=steps, warmup=warmup):
@@ -776,6 +779,25 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         del shadow, idx2, out2
         torch.cuda.empty_cache()
 
+    # A/B in this process (fp8 index): the same batches through the native fp8 matrix instruction (two e4m3 query pieces)
+    fp8_native = None
+    if index_dtype == "fp8" and fp8_ab and not fp8_mfma:
+        idx3 = ShardedIndex(shard, N, row_scale=row_scale, method="scan", fp8_mfma=True)
+        idx3.workspace = ws
+        e3, ms3, l3, out3 = timed_run(idx3)
+        b3 = (row_end - row_begin) * D + Q * D * 4 + Q * k * 12 + (row_end - row_begin) * 4
+        sc3 = ms3[0] / steps
+        inter = (out3[1].unsqueeze(2) == out[1].unsqueeze(1)).any(dim=2).float().sum(dim=1)
+        fp8_native = {"what": "e4m3 index bytes fed to v_mfma_f32_16x16x32_fp8_fp8 as they are; the f32 query as two e4m3 pieces with "
+                              "power-of-two scales (8 significant bits), one accumulator per piece — no widening work on the stream",
+                      "value": Q * steps / e3, "unit": "queries/s", "ms_per_step": e3 / steps * 1e3,
+                      "overlap_at_k_vs_widening_variant": float((inter / k).mean().item()),
+                      "roofline": {"bound": "hbm", "achieved": b3 / (sc3 * 1e-3) / 1e9 if sc3 > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": (b3 / (sc3 * 1e-3) / 1e9 if sc3 > 0 else 0.0) / HBM_PEAK_GBS,
+                                   "kernel": "k_cosine_score<F16=3>", "algorithmic_bytes_per_step": b3, "kernel_ms_per_step": sc3,
+                                   "traffic": None, "traffic_source": None}}
+        del idx3, out3
+
     # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
     s_last, i_last = out
     g = gold[(warmup + steps - 1) % n_batches].to(dev).view(Q, 1)
@@ -813,7 +835,8 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 index x f32 queries (f16 MFMA, f32 accumulate)",
-                      "fp8": "e4m3 index + f32 row scale x f32 queries (e4m3 widened to f16 in registers, f16 MFMA, f32 accumulate)"}[index_dtype],
+                      "fp8": ("e4m3 index + f32 row scale x two-piece e4m3 queries (native fp8 MFMA, f32 accumulate)" if fp8_mfma else
+                              "e4m3 index + f32 row scale x f32 queries (e4m3 widened to f16 in registers, f16 MFMA, f32 accumulate)")}[index_dtype],
             "data": "synthetic",
             "config": {
                 "workload": workload or ("configs[1]: WebQSP-shaped full index, bge-base dim, brute-force cosine top-k" if N < 50_000_000 else
@@ -855,6 +878,8 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             result["two_stage_proof_failed"] = two_stage_fallback
         if overlap is not None:
             result["overlap_vs_f32"] = overlap
+        if fp8_native is not None:
+            result["fp8_mfma"] = fp8_native
         if ms[2] > ms[0]:
             # the many-query path did the work: the dominant kernel is the split-bf16 GEMM (MFMA-bound), priced by the
             # flops it executes (3 bf16 products per f32 product) against the dense bf16 peak
@@ -912,7 +937,7 @@ def main():
     result = run_index_leg(ctx, N=args.rows, D=args.dim, Q=args.queries, k=args.k, index_dtype=args.index_dtype,
                            method=args.topk_method, steps=args.steps, warmup=args.warmup, seed=args.seed,
                            want_two_stage=not args.no_two_stage, sustained_s=2.0 if extra else 0.0,
-                           cpu_rows=args.cpu_rows, cpu_seconds=cpu_s)
+                           cpu_rows=args.cpu_rows, cpu_seconds=cpu_s, fp8_mfma=args.fp8_mfma)
     if rank == 0:
         D = args.dim
         if extra:
@@ -924,7 +949,7 @@ def main():
                 workload="configs[3] per-rank shard: 1/8 of the 100 M x 768 index, f16 storage (what each of 8 MI355X scans per batch)")
             result["config5_shard"] = run_index_leg(
                 ctx, N=12_500_000, D=1024, Q=args.queries, k=args.k, index_dtype="fp8", method="scan", steps=args.steps,
-                warmup=args.warmup, seed=4, cpu_rows=1 << 18, cpu_seconds=min(cpu_s, 5.0),
+                warmup=args.warmup, seed=4, cpu_rows=1 << 18, cpu_seconds=min(cpu_s, 5.0), fp8_ab=True,
                 workload="configs[4] per-rank shard: 1/8 of the 100 M x 1024 index, OCP e4m3 storage + f32 row scale "
                          "(bge-large dim); overlap@k against the f32 index reported instead of bit-exactness")
             result["config3_graph_kernels"] = {

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "evi_cosine_topk": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "evi_cosine_topk_f16": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "evi_cosine_topk_fp8": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "evi_cosine_topk_fp8_mfma": (c_int, [_P, c_int, _P, c_int64, c_int, _P, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "evi_quantize_rows_fp8": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "evi_shortest_path_single": (c_int, [_P] * 6 + [c_int] + [_P] * 9 + [c_int, _P, _P, _P, _P]),
     "evi_first_occurrence_workspace_bytes": (c_size_t, [c_int64, c_int]),

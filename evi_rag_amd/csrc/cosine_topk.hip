@@ -25,6 +25,7 @@
 #include "common.hpp"
 
 #include <hip/hip_ext.h>
+#include <hip/hip_fp8.h>
 
 #include <stdlib.h>
 
@@ -125,6 +126,78 @@ __global__ void k_query_fragments_fp8(const float* __restrict__ q, int Q, int D,
     }
 }
 
+// NATIVE fp8 MFMA variant (F16 == 3): the e4m3 index bytes feed v_mfma_f32_16x16x32_fp8_fp8 as they are, so the query
+// has to be fp8 too.  It is written as TWO e4m3 pieces with a power-of-two scale each,
+//     q ~ s1 * p1 + s2 * p2,   p1 = e4m3(q / s1),  p2 = e4m3((q - s1 p1) / s2),
+// (8 significant bits: |q - s1 p1 - s2 p2| <= 2^-8 |q|_inf per element, ~20x below the index's own e4m3 rounding), one
+// accumulator per piece, recombined in the epilogue.  Same MFMA count as the widening variant (2 per k-step and query
+// block) and no conversion work on the stream.  One workgroup per query (max |q| needs the whole row).
+//   qfrag8n[((((J*2 + m)*4 + g)*2 + piece) * nq_pad + i] = 8 e4m3 bytes of piece(q[i])[64 J + 16 g + 8 m .. + 7]
+//   qscale [piece][32] f32 behind the fragments (byte offset D * 2 * nq_pad)
+__device__ inline float e4m3_to_float(uint32_t b) {
+    const uint32_t e = (b >> 3) & 0xF, m = b & 7;
+    const float mag = e == 0 ? (float)m * 0.001953125f /* 2^-9 */ : __uint_as_float(((e + 120u) << 23) | (m << 20));
+    return (b & 0x80) ? -mag : mag;
+}
+__device__ inline float pow2_scale_for(float amax) {  // smallest power of two s with amax / s <= 448 (1 for amax == 0)
+    if (!(amax > 0.f)) return 1.0f;
+    int e;
+    frexpf(amax / 448.0f, &e);  // amax / 448 = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, e);
+}
+__global__ __launch_bounds__(256) void k_query_fragments_fp8n(const float* __restrict__ q, int Q, int D, int nq_pad,
+                                                              uint64_t* __restrict__ qfrag, float* __restrict__ tau,
+                                                              int32_t* __restrict__ cnt, const int32_t* __restrict__ gate) {
+    if (gate_closed(gate)) return;
+    reset_query_state(tau, cnt);
+    __shared__ float red[256];
+    const int i = blockIdx.x, tid = threadIdx.x;  // one workgroup per query slot (grid = nq_pad)
+    float* qscale = reinterpret_cast<float*>(reinterpret_cast<char*>(qfrag) + (size_t)D * 2 * nq_pad);
+    auto block_max = [&](float v) -> float {
+        red[tid] = v;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+            __syncthreads();
+        }
+        const float m = red[0];
+        __syncthreads();
+        return m;
+    };
+    const bool live = i < Q;
+    float a1 = 0.f;
+    for (int d = tid; d < D; d += 256) a1 = fmaxf(a1, live ? fabsf(q[(int64_t)i * D + d]) : 0.f);
+    const float s1 = pow2_scale_for(block_max(a1));
+    float a2 = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        const float v = live ? q[(int64_t)i * D + d] : 0.f;
+        const uint32_t b1 = (uint32_t)__hip_cvt_float_to_fp8(v / s1, __HIP_SATFINITE, __HIP_E4M3);
+        a2 = fmaxf(a2, fabsf(v - s1 * e4m3_to_float(b1)));
+    }
+    const float s2 = pow2_scale_for(block_max(a2));
+    if (tid == 0) {
+        qscale[i] = s1;
+        qscale[kQueryBlock + i] = s2;
+    }
+    // 8 bytes per (J, m, g): thread -> one such group per trip
+    const int groups = (D / 64) * 8;
+    for (int jmg = tid; jmg < groups; jmg += 256) {
+        const int g = jmg & 3, m = (jmg >> 2) & 1, J = jmg >> 3;
+        uint64_t w1 = 0, w2 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = live ? q[(int64_t)i * D + 64 * J + 16 * g + 8 * m + e] : 0.f;
+            const uint32_t b1 = (uint32_t)__hip_cvt_float_to_fp8(v / s1, __HIP_SATFINITE, __HIP_E4M3) & 0xFF;
+            const float r = v - s1 * e4m3_to_float(b1);
+            const uint32_t b2 = (uint32_t)__hip_cvt_float_to_fp8(r / s2, __HIP_SATFINITE, __HIP_E4M3) & 0xFF;
+            w1 |= (uint64_t)b1 << (8 * e);
+            w2 |= (uint64_t)b2 << (8 * e);
+        }
+        qfrag[((int64_t)jmg * 2 + 0) * nq_pad + i] = w1;
+        qfrag[((int64_t)jmg * 2 + 1) * nq_pad + i] = w2;
+    }
+}
+
 // two e4m3 bytes of w (selected by `sel`) -> two f16 whose value is the fp8 value / 256:
 // f16 bits = sign << 15 | (low 7 bits) << 7 (exact for every finite e4m3 code, subnormals included)
 __device__ inline uint32_t fp8x2_to_f16x2_scaled(uint32_t w, uint32_t sel) {
@@ -154,8 +227,9 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     constexpr int NQ = NQB * 16;
     constexpr int WAVES = THREADS / 64;
     const int tid = threadIdx.x;
-    const int chunks = F16 == 2 ? D / 64 : (F16 ? D / 32 : D / 16);  // 64-byte pieces of a row
-    const int qslots = (D / 16) * 4 * NQ;      // same LDS footprint for both layouts: D * NQ * 4 bytes
+    const int chunks = F16 >= 2 ? D / 64 : (F16 ? D / 32 : D / 16);  // 64-byte pieces of a row
+    const int qslots = F16 == 3 ? (D / 8) * NQ  // native fp8: two 1-byte pieces per element, D * NQ * 2 bytes
+                                : (D / 16) * 4 * NQ;  // same LDS footprint for the other layouts: D * NQ * 4 bytes
     int* lds_cnt = reinterpret_cast<int*>(lds_q + qslots);          // [32]
     float* lds_sc = reinterpret_cast<float*>(lds_cnt + kQueryBlock);  // [32][capq]
     int* lds_id = reinterpret_cast<int*>(lds_sc + kQueryBlock * capq);  // [32][capq]
@@ -177,6 +251,18 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
             tq[b][r] = (dense || qi >= Q) ? -INFINITY : tau[qi];
         }
 
+    float qs1[NQB][4], qs2[NQB][4];  // native fp8: the two piece scales of this lane's queries
+    if (F16 == 3) {
+        const float* qscale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(qfrag) + (size_t)D * 2 * NQ);
+#pragma unroll
+        for (int b = 0; b < NQB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = b * 16 + 4 * g + r;
+                qs1[b][r] = qscale[qi];
+                qs2[b][r] = qscale[kQueryBlock + qi];
+            }
+    }
     const int64_t seg_rows = seg_end - seg_begin;
     const int64_t tiles = (seg_rows + 15) / 16;
     const int groups = chunks / U;
@@ -193,7 +279,7 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
     // iteration therefore has the same number of loads outstanding, so the compiler's counted
     // vmcnt waits release exactly the group that is needed and never drain the prefetch.
     const int64_t stride = (int64_t)gridDim.x * WAVES;
-    const int64_t row_bytes = (int64_t)D * (F16 == 2 ? 1 : (F16 ? 2 : 4));
+    const int64_t row_bytes = (int64_t)D * (F16 >= 2 ? 1 : (F16 ? 2 : 4));
     auto tile_ptr = [&](int64_t t) -> const f32x4* {
         const int64_t r = seg_begin + t * 16 + n;
         const int64_t rc = r < seg_end ? r : seg_end - 1;
@@ -208,6 +294,21 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = gi * U + u;
+            if (F16 == 3) {  // native fp8 MFMA: index bytes as they are, two e4m3 query pieces, one accumulator each
+                typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+                const u32x4n w = __builtin_bit_cast(u32x4n, x[u]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const long xb = (long)(((uint64_t)w[2 * m + 1] << 32) | (uint64_t)w[2 * m]);
+                    const long* lq8 = reinterpret_cast<const long*>(lds_q) + ((((j * 2 + m) * 4 + g) * 2) * NQ) + n;
+#pragma unroll
+                    for (int b = 0; b < NQB; ++b) {
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(lq8[b * 16], xb, acc[b], 0, 0, 0);
+                        acc_lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(lq8[NQ + b * 16], xb, acc_lo[b], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
             if (F16 == 2) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 w = __builtin_bit_cast(u32x4, x[u]);
@@ -292,7 +393,8 @@ __global__ __launch_bounds__(THREADS) void k_cosine_score(
                 for (int r = 0; r < 4; ++r) {
                     const int qi = b * 16 + 4 * g + r;
                     if (qi >= Q) continue;
-                    float dot = F16 ? fmaf(acc_lo[b][r], 1.0f / kLoScale, acc[b][r]) : acc[b][r];
+                    float dot = F16 == 3 ? fmaf(acc_lo[b][r], qs2[b][r], acc[b][r] * qs1[b][r])
+                                : (F16 ? fmaf(acc_lo[b][r], 1.0f / kLoScale, acc[b][r]) : acc[b][r]);
                     if (F16 == 2) dot *= 256.0f;  // the widened bytes carry value / 256
                     const float s = row_scale ? dot * scale : dot;
                     if (dense) {
@@ -551,9 +653,9 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
                     "evi_cosine_topk: D must be a multiple of 16 in [16, 1280], got %d", D);
     if (f16 == 1 && D % 32 != 0)
         return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_f16: D must be a multiple of 32, got %d", D);
-    if (f16 == 2 && D % 64 != 0)
+    if (f16 >= 2 && D % 64 != 0)
         return fail(EVI_ERR_UNSUPPORTED, "evi_cosine_topk_fp8: D must be a multiple of 64, got %d", D);
-    EVI_REQUIRE(f16 != 2 || row_scale || N == 0, "evi_cosine_topk_fp8: row_scale (the per-row dequantisation scale) is required");
+    EVI_REQUIRE(f16 < 2 || row_scale || N == 0, "evi_cosine_topk_fp8: row_scale (the per-row dequantisation scale) is required");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     const size_t min_ws = evi_cosine_topk_min_workspace_bytes(Q, N, D, k);
@@ -573,7 +675,7 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
     float* cs = reinterpret_cast<float*>(base + w.score_off);
     int32_t* ci = reinterpret_cast<int32_t*>(base + w.id_off);
 
-    const int chunks = f16 == 2 ? D / 64 : (f16 ? D / 32 : D / 16);
+    const int chunks = f16 >= 2 ? D / 64 : (f16 ? D / 32 : D / 16);
     ScanVariant variant = scan_variant();
     if (f16) variant.threads = 1024;
     // loads in flight per lane per group: the largest U <= cap that leaves an EVEN number of groups
@@ -587,14 +689,21 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
     const int cus = device_cu_count();
     const int waves_per_block = variant.threads == 1024 ? 16 : 8;
 
-    for (int q0 = 0; q0 < Q; q0 += kQueryBlock) {
-        const int qn = (Q - q0) < kQueryBlock ? (Q - q0) : kQueryBlock;
+    // 32 queries per pass when their fragments (+ the append counters) fit the 160 KiB of LDS, else 16: at D = 1280 the
+    // f32 / f16 / widened-fp8 fragments of 32 queries are exactly 160 KiB and leave no room for the counters
+    const size_t frag_bytes_32 = f16 == 3 ? (size_t)D * 2 * kQueryBlock : (size_t)D * kQueryBlock * sizeof(float);
+    const int qblock = frag_bytes_32 + kQueryBlock * sizeof(int) > 160 * 1024 ? 16 : kQueryBlock;
+    for (int q0 = 0; q0 < Q; q0 += qblock) {
+        const int qn = (Q - q0) < qblock ? (Q - q0) : qblock;
         const int nqb = qn <= 16 ? 1 : 2;
         const int nq_pad = nqb * 16;
         float* o_score = out_score + (int64_t)q0 * k;
         int64_t* o_index = out_index + (int64_t)q0 * k;
 
-        if (f16 == 2)
+        if (f16 == 3)
+            hipLaunchKernelGGL(k_query_fragments_fp8n, dim3(nq_pad), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
+                               reinterpret_cast<uint64_t*>(qfrag), tau, cnt, gate);
+        else if (f16 == 2)
             hipLaunchKernelGGL(k_query_fragments_fp8, dim3(32), dim3(256), 0, st, q + (int64_t)q0 * D, qn, D, nq_pad,
                                reinterpret_cast<f16x8*>(qfrag), tau, cnt, gate);
         else if (f16)
@@ -611,10 +720,11 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
             EVI_LAUNCH_CHECK();
             continue;
         }
-        const size_t lds_q_bytes = (size_t)(D / 16) * 4 * nq_pad * sizeof(float4);
+        const size_t lds_q_bytes = f16 == 3 ? (size_t)D * 2 * nq_pad : (size_t)(D / 16) * 4 * nq_pad * sizeof(float4);
         // staging entries per query: whatever LDS is left, at most 64
-        int capq = (int)((160 * 1024 - lds_q_bytes - kQueryBlock * sizeof(int)) / (kQueryBlock * 8));
-        capq = capq > 64 ? 64 : (capq < 0 ? 0 : capq);
+        const int64_t lds_left = (int64_t)160 * 1024 - (int64_t)lds_q_bytes - (int64_t)(kQueryBlock * sizeof(int));
+        int capq = lds_left > 0 ? (int)(lds_left / (kQueryBlock * 8)) : 0;
+        capq = capq > 64 ? 64 : capq;
         const size_t lds = lds_q_bytes + kQueryBlock * sizeof(int) + (size_t)kQueryBlock * capq * 8;
         int64_t begin = 0;
         const SegmentSchedule sched = segment_schedule();
@@ -629,7 +739,8 @@ static int cosine_topk_impl(const float* q, int Q, const void* idx, int f16, int
             ScoreArgs sa{grid, lds, st, qfrag, idx, begin, end, D, qn, row_scale, tau,
                          cs, ci, cnt, w.cap, first ? 1 : 0, capq, gate, nullptr, nullptr};
             if (!gate) timing_kernel_events(kTimeCosineScore, &sa.ev_start, &sa.ev_stop);  // gated launches stay out of the accounts
-            const int rc = f16 == 2 ? (nqb == 1 ? launch_score_lowp<1, 2>(U, sa) : launch_score_lowp<2, 2>(U, sa))
+            const int rc = f16 == 3 ? (nqb == 1 ? launch_score_lowp<1, 3>(U, sa) : launch_score_lowp<2, 3>(U, sa))
+                           : f16 == 2 ? (nqb == 1 ? launch_score_lowp<1, 2>(U, sa) : launch_score_lowp<2, 2>(U, sa))
                            : f16  ? (nqb == 1 ? launch_score_lowp<1, 1>(U, sa) : launch_score_lowp<2, 1>(U, sa))
                                   : (nqb == 1 ? launch_score_v<1>(variant, U, sa) : launch_score_v<2>(variant, U, sa));
             if (rc != EVI_OK) return rc;
@@ -675,6 +786,13 @@ extern "C" int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, i
                                    int64_t* out_index, void* workspace, size_t workspace_bytes,
                                    void* stream) {
     return cosine_topk_impl(q, Q, idx_fp8, 2, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
+                            workspace_bytes, stream);
+}
+
+extern "C" int evi_cosine_topk_fp8_mfma(const float* q, int Q, const void* idx_fp8, int64_t N, int D,
+                                        const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                                        int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream) {
+    return cosine_topk_impl(q, Q, idx_fp8, 3, N, D, row_scale, k, row_id_base, out_score, out_index, workspace,
                             workspace_bytes, stream);
 }
 

@@ -34,10 +34,10 @@ def shard_graphs(num_graphs: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_graphs, world_size))
 
 
-def _default_local_topk(queries, shard, k, row_id_base, row_scale=None, method="scan"):
+def _default_local_topk(queries, shard, k, row_id_base, row_scale=None, method="scan", fp8_mfma=False):
     from . import ops
 
-    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale, method=method)
+    return ops.cosine_topk(queries, shard, k, row_id_base=row_id_base, row_scale=row_scale, method=method, fp8_mfma=fp8_mfma)
 
 
 def _local_scan(self: "ShardedIndex", queries, k, out, workspace, lane: int = 0):
@@ -53,7 +53,7 @@ def _local_scan(self: "ShardedIndex", queries, k, out, workspace, lane: int = 0)
                                          status=self.two_stage_status, fallback="device",
                                          workspace=self._two_stage_workspace(queries, k, lane))
     return ops.cosine_topk(queries, self.shard, k, row_id_base=self.row_begin, row_scale=self.row_scale,
-                           workspace=workspace, out=out, method=self.method)
+                           workspace=workspace, out=out, method=self.method, fp8_mfma=self.fp8_mfma)
 
 
 def _default_merge(scores, ids):
@@ -68,11 +68,12 @@ class ShardedIndex:
     def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
                  local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
                  row_scale: Optional[torch.Tensor] = None, method: str = "scan",
-                 shadow: Optional[torch.Tensor] = None, exchange: Optional[Callable] = None) -> None:
+                 shadow: Optional[torch.Tensor] = None, exchange: Optional[Callable] = None, fp8_mfma: bool = False) -> None:
         """exchange(all_records, local_record): fills `all_records` (world x record bytes, uint8, rank order) from every
         rank's `local_record`, ordered on the CURRENT stream.  Default: one `dist.all_gather_into_tensor` over `group`
         (RCCL).  Injected by the tests that run two ranks on ONE GPU, where RCCL refuses two ranks per device."""
         self.group = group
+        self.fp8_mfma = bool(fp8_mfma)  # e4m3 shard: native fp8 matrix instruction instead of widening to f16 (ops.cosine_topk)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bounds = shard_bounds(int(num_rows_total), self.world)
@@ -160,7 +161,7 @@ class ShardedIndex:
                                              status=self.two_stage_status,
                                              workspace=self._two_stage_workspace(queries, k))  # device-side fallback: always exact
         elif self._local_topk is _default_local_topk:
-            s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale, self.method)
+            s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale, self.method, self.fp8_mfma)
         elif self.row_scale is not None:
             s, i = self._local_topk(queries, self.shard, k, self.row_begin, self.row_scale)
         else:

@@ -147,13 +147,17 @@ def cosine_topk(
     workspace: Optional[torch.Tensor] = None,
     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
     method: str = "scan",
+    fp8_mfma: bool = False,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Top-k rows of `index` per query by dot product (cosine when both are L2-normalised, or when
     `index` is raw and row_scale = row_inv_norm(index)).  Returns (scores [Q,k] f32, ids [Q,k] i64),
     ordered (score desc, id asc); slots past min(k, N) hold (-inf, -1).
     method: "scan" (default: 32 queries per pass over the index, never synchronises), "gemm" (many queries in
     one GEMM-shaped pass, same result, one synchronisation — see cosine_topk_gemm) or "auto" (gemm for
-    Q >= 96 on an f32 index of unit rows when its limits allow, else scan)."""
+    Q >= 96 on an f32 index of unit rows when its limits allow, else scan).
+    fp8_mfma (e4m3 index only): feed the index bytes to the native fp8 matrix instruction with the query as two e4m3
+    pieces (evi_cosine_topk_fp8_mfma) instead of widening them to f16 — no conversion work on the stream; scores carry
+    8 significant query bits, far inside the index's own quantisation noise."""
     if method not in ("scan", "gemm", "auto"):
         raise ValueError(f"method must be 'scan', 'gemm' or 'auto', got {method!r}")
     if method != "scan" and index.dtype in (torch.float32, torch.float16) and queries.dim() == 2 and index.dim() == 2:
@@ -194,7 +198,10 @@ def cosine_topk(
     else:
         out_score = torch.empty((Q, k), dtype=torch.float32, device=dev)
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
-    fn = {torch.float16: lib.evi_cosine_topk_f16, torch.uint8: lib.evi_cosine_topk_fp8}.get(x.dtype, lib.evi_cosine_topk)
+    if fp8_mfma and x.dtype != torch.uint8:
+        raise ValueError("fp8_mfma goes with an e4m3 (uint8) index")
+    fn = {torch.float16: lib.evi_cosine_topk_f16,
+          torch.uint8: lib.evi_cosine_topk_fp8_mfma if fp8_mfma else lib.evi_cosine_topk_fp8}.get(x.dtype, lib.evi_cosine_topk)
     _lib.check(
         fn(
             _ptr(q), Q, _ptr(x), N, D, _ptr(row_scale), int(k), int(row_id_base),

@@ -134,6 +134,14 @@ int evi_cosine_topk_fp8(const float* q, int Q, const void* idx_fp8, int64_t N, i
                         const float* row_scale, int k, int64_t row_id_base,
                         float* out_score, int64_t* out_index,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same index through the NATIVE fp8 matrix instruction (v_mfma_f32_16x16x32_fp8_fp8): the e4m3 bytes are the B
+ * operand as they are (no widening work on the stream), the f32 query is written as two e4m3 pieces with a
+ * power-of-two scale each (8 significant bits per element) and accumulated separately.  Scores differ from
+ * evi_cosine_topk_fp8's (which are exact for the dequantised rows) by <= 2^-8 |q|_inf |row|_1 in the worst case,
+ * ~20x below the index's own e4m3 rounding; ranking differences are reported as overlap@k by the callers. */
+int evi_cosine_topk_fp8_mfma(const float* q, int Q, const void* idx_fp8, int64_t N, int D,
+                             const float* row_scale, int k, int64_t row_id_base, float* out_score,
+                             int64_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same result as evi_cosine_topk (ids and scores bit-identical) for MANY queries (Q in the hundreds; f32
  * index, rows of unit norm after row_scale, D % 16 == 0, k <= 1365): the scores of all queries against a

@@ -145,6 +145,49 @@ def test_cosine_topk_fp8_index_matches_oracle(dev, Q, N, D, k):
         ops.cosine_topk(qn, codes, 5)  # no scale
 
 
+@pytest.mark.parametrize("Q,N,D,k", [(32, 200000, 768, 500), (5, 3000, 64, 50), (17, 70001, 1024, 100), (32, 40000, 1280, 200)])
+def test_cosine_topk_fp8_native_mfma_variant(dev, Q, N, D, k):
+    """BASELINE config 5 "fp8 MFMA scoring": the e4m3 index through v_mfma_f32_16x16x32_fp8_fp8 with the f32 query written as
+    two e4m3 pieces (power-of-two scales).  Checked against the exact scores of the DEQUANTISED rows (float64 oracle):
+      * every returned score is within the two-piece bound of the exact one: |q - s1 p1 - s2 p2|_inf <= 2^-8 max|q| per
+        element, so |delta score| <= 2^-8 max|q| * sum|x_row| * row_scale (measured: far smaller);
+      * the list is sorted (score desc, id asc) and holds no duplicate or out-of-range id;
+      * it agrees with the widening variant (exact for the dequantised rows) on >= 97 % of the ids, and differing ids are
+        near-ties: their exact scores lie within the bound of the exact k-th score."""
+    from evi_rag_amd import ops
+
+    x = _make_index(N, D, seed=N + D + 3)
+    q = np.random.default_rng(Q + 5).standard_normal((Q, D), dtype=np.float32)
+    q[0] *= 1e-3   # tiny and huge queries: the piece scales are per query
+    q[min(1, Q - 1)] *= 1e4
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qd = torch.from_numpy(q).to(dev)
+    codes, scale = ops.quantize_rows_fp8(xn)
+    sc, ids = ops.cosine_topk(qd, codes, k, row_scale=scale, row_id_base=7, fp8_mfma=True)
+    sw, iw = ops.cosine_topk(qd, codes, k, row_scale=scale, row_id_base=7)
+    deq = ocos.e4m3_decode_table()[codes.cpu().numpy()].astype(np.float64) * scale.cpu().numpy().astype(np.float64)[:, None]
+    exact = q.astype(np.float64) @ deq.T  # [Q, N]
+    bound = (2.0 ** -8) * np.abs(q).max(axis=1, keepdims=True) * np.abs(deq).sum(axis=1)[None, :]  # [Q, N]
+    m = min(k, N)
+    s_np, i_np = sc.cpu().numpy(), ids.cpu().numpy() - 7
+    assert (i_np[:, :m] >= 0).all() and (i_np[:, :m] < N).all()
+    for r in range(Q):
+        row_ids = i_np[r, :m]
+        assert np.unique(row_ids).size == m
+        err = np.abs(s_np[r, :m].astype(np.float64) - exact[r, row_ids])
+        assert (err <= bound[r, row_ids] + 1e-6 * np.abs(exact[r, row_ids]) + 1e-30).all(), (r, err.max())
+        ds = np.diff(s_np[r, :m])
+        assert (ds <= 0).all() and (np.diff(row_ids)[ds == 0] > 0).all()
+        kth = np.sort(exact[r])[::-1][m - 1]
+        for rid in np.setdiff1d(row_ids, iw[r, :m].cpu().numpy() - 7):
+            assert abs(exact[r, rid] - kth) <= 2 * bound[r, rid] + 1e-30, (r, rid)
+    a, b = i_np[:, :m], iw[:, :m].cpu().numpy() - 7
+    overlap = np.mean([len(np.intersect1d(a[r], b[r])) / m for r in range(Q)])
+    assert overlap >= 0.97, overlap
+    with pytest.raises(ValueError, match="e4m3"):
+        ops.cosine_topk(qd, xn, k, fp8_mfma=True)
+
+
 def test_cosine_topk_row_scale_equals_prenormalised(dev):
     """raw index + row_scale (fused normalisation) returns the same ids as a normalised index."""
     from evi_rag_amd import ops
@@ -572,3 +615,31 @@ def test_proof_paths_refuse_rows_and_queries_far_from_unit_norm(dev):
         s5, i5 = ops.cosine_topk(qs, x, k)
         assert int(flag.item()) == 1  # proof refused ...
         assert torch.equal(i4, i5) and torch.equal(s4, s5)  # ... and repaired on the device
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16", "fp8", "fp8_mfma"])
+def test_cosine_topk_widest_rows_d1280_32_queries(dev, storage):
+    """D = 1280 (the widest supported row): the f32 / f16 / widened-fp8 fragments of 32 queries fill the 160 KiB of LDS
+    exactly, so the scan takes the queries 16 at a time — same results as two separate 16-query calls and as the oracle."""
+    from evi_rag_amd import ops
+
+    N, D, Q, k = 30000, 1280, 32, 64
+    x = _make_index(N, D, seed=77)
+    q = np.random.default_rng(78).standard_normal((Q, D), dtype=np.float32)
+    xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
+    qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
+    kw = {}
+    if storage == "f16":
+        idx = xn.to(torch.float16)
+    elif storage.startswith("fp8"):
+        idx, sc = ops.quantize_rows_fp8(xn)
+        kw["row_scale"] = sc
+        kw["fp8_mfma"] = storage == "fp8_mfma"
+    else:
+        idx = xn
+    s, i = ops.cosine_topk(qn, idx, k, **kw)
+    s_a, i_a = ops.cosine_topk(qn[:16].contiguous(), idx, k, **kw)
+    s_b, i_b = ops.cosine_topk(qn[16:].contiguous(), idx, k, **kw)
+    assert torch.equal(i, torch.cat([i_a, i_b])) and torch.equal(s, torch.cat([s_a, s_b]))
+    if storage == "f32":
+        check_topk_against_scores(s.cpu().numpy(), i.cpu().numpy(), ocos.cosine_scores(q, x, EPS), k)
