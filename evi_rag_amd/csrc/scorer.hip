@@ -120,7 +120,15 @@ struct EdgeFeatArgs {
     float* aux;  // [(dir_fwd + dir_bwd) * e_count, 2]  (nav gate, -||translation error||)
 };
 
-template <int DPL>
+// Lane -> feature map of the per-edge kernels: lane owns the float4 chunks d = 4 * lane + 256 * i, i < C4 = ceil(D / 256)
+// (D % 4 == 0), so every row access is a 16-byte load / store per lane — 1 KiB per wave instruction, four times fewer
+// memory and LDS instructions than one float per lane (cdna_hip_programming.md guideline 13).
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ inline f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ inline void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+__device__ inline float hsum4(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+template <int C4>
 __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
     extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
     const float gate_b = a.struct_gate_b[0];
     const int half = F >> 1;
     const float inv_d = 1.0f / (float)D;
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int64_t le = (int64_t)blockIdx.x * waves + wave; le < a.e_count; le += (int64_t)gridDim.x * waves) {
         const int64_t e = a.e_begin + le;
@@ -159,16 +168,16 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
         const float* rp = a.rel_repr + rrow * D;
         const float* gp = a.gate_q + g * D;
         const float* bp = a.bias_q + g * D;
-        float h[DPL], t[DPL], rc[DPL];
+        f4 h[C4], t[C4], rc[C4];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int d = lane + 64 * i;
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
             if (d < D) {
-                h[i] = hp[d];
-                t[i] = tp[d];
-                rc[i] = rp[d] * gp[d] + bp[d];
+                h[i] = ld4(hp + d);
+                t[i] = ld4(tp + d);
+                rc[i] = ld4(rp + d) * ld4(gp + d) + ld4(bp + d);
             } else {
-                h[i] = t[i] = rc[i] = 0.f;
+                h[i] = t[i] = rc[i] = z4;
             }
         }
         // struct_proj.0 for BOTH directions in one pass over the weights: struct_raw = cat(ns[a], ns[b]) with
@@ -176,21 +185,24 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
         // feeds two accumulators; the raw features are wave-uniform scalars.
         const float* nsh = a.node_struct + hv * half;
         const float* nst = a.node_struct + tv * half;
-        float s2[2][DPL];
+        f4 s2[2][C4];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int d = lane + 64 * i;
-            s2[0][i] = s2[1][i] = d < D ? l_b[d] : 0.f;
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            s2[0][i] = s2[1][i] = d < D ? ld4(l_b + d) : z4;
         }
         for (int j = 0; j < half; ++j) {
             const float xh = nsh[j], xt = nst[j];
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
                 if (d < D) {
-                    const float w1 = lds_wt[j * D + d], w2 = lds_wt[(half + j) * D + d];
-                    s2[0][i] = fmaf(w2, xt, fmaf(w1, xh, s2[0][i]));
-                    s2[1][i] = fmaf(w2, xh, fmaf(w1, xt, s2[1][i]));
+                    const f4 w1 = ld4(lds_wt + j * D + d), w2 = ld4(lds_wt + (half + j) * D + d);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s2[0][i][c] = fmaf(w2[c], xt, fmaf(w1[c], xh, s2[0][i][c]));
+                        s2[1][i][c] = fmaf(w2[c], xh, fmaf(w1[c], xt, s2[1][i][c]));
+                    }
                 }
             }
         }
@@ -199,28 +211,33 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
-            float s[DPL];
+            f4 sv[C4];
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) s[i] = s2[dir][i];
+            for (int i = 0; i < C4; ++i) sv[i] = s2[dir][i];
             // LayerNorm over D, exact GELU
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) sum += (lane + 64 * i < D) ? s[i] : 0.f;
+            for (int i = 0; i < C4; ++i) sum += (4 * lane + 256 * i < D) ? hsum4(sv[i]) : 0.f;
             const float mean = wsum(sum) * inv_d;
             float var = 0.f;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const float c = (lane + 64 * i < D) ? s[i] - mean : 0.f;
-                var += c * c;
-            }
+            for (int i = 0; i < C4; ++i)
+                if (4 * lane + 256 * i < D) {
+                    const f4 c = sv[i] - mean;
+                    var += hsum4(c * c);
+                }
             const float rstd = 1.0f / sqrtf(wsum(var) * inv_d + kLnEps);
             float gacc = 0.f;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
                 if (d < D) {
-                    s[i] = gelu_erf((s[i] - mean) * rstd * l_lw[d] + l_lb[d]);
-                    gacc = fmaf(l_gw[d], s[i], gacc);
+                    const f4 lw = ld4(l_lw + d), lb = ld4(l_lb + d), gw = ld4(l_gw + d);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sv[i][c] = gelu_erf((sv[i][c] - mean) * rstd * lw[c] + lb[c]);
+                        gacc = fmaf(gw[c], sv[i][c], gacc);
+                    }
                 }
             }
             const float nav = sigmoidf_(wsum(gacc) + gate_b);
@@ -228,12 +245,12 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             float* xs = a.XS + row * D;
             float dsq = 0.f;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
                 if (d < D) {
-                    const float err = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
-                    xs[d] = s[i];
-                    dsq = fmaf(err, err, dsq);
+                    const f4 err = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
+                    st4(xs + d, sv[i]);
+                    dsq += hsum4(err * err);
                 }
             }
             dsq = wsum(dsq);
@@ -246,11 +263,11 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
         float* pp = a.P + le * D;
         float* rx = a.RCX + le * D;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int d = lane + 64 * i;
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
             if (d < D) {
-                pp[d] = h[i] * rc[i] * t[i];
-                rx[d] = rc[i];
+                st4(pp + d, h[i] * rc[i] * t[i]);
+                st4(rx + d, rc[i]);
             }
         }
     }
@@ -323,7 +340,7 @@ struct CombineArgs {
     float* logits_bwd;
 };
 
-template <int DPL, int FOLD>
+template <int C4, int FOLD>
 __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -334,16 +351,20 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
     const float* rc = a.RC + le * H;
     const float* hh = a.HcN + a.edge_index[e] * H;
     const float* ht = a.HcN + a.edge_index[a.E + e] * H;
-    float base[DPL], diff[DPL], pav[DPL];
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f4 base[C4], diff[C4], pav[C4], wdv[C4], lnw[C4], lnb[C4];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int d = lane + 64 * i;
+    for (int i = 0; i < C4; ++i) {
+        const int d = 4 * lane + 256 * i;
         if (d < H) {
-            pav[i] = pa[d];
-            base[i] = rc[d];
-            diff[i] = hh[d] - ht[d];
+            pav[i] = ld4(pa + d);
+            base[i] = ld4(rc + d);
+            diff[i] = ld4(hh + d) - ld4(ht + d);
+            wdv[i] = ld4(a.wd + d);
+            lnw[i] = ld4(a.ln_w + d);
+            lnb[i] = ld4(a.ln_b + d);
         } else {
-            pav[i] = base[i] = diff[i] = 0.f;
+            pav[i] = base[i] = diff[i] = wdv[i] = lnw[i] = lnb[i] = z4;
         }
     }
     float lg[2] = {0.f, 0.f};
@@ -354,40 +375,45 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
         const int64_t row = (int64_t)out_row * a.e_count + le;
         const float nav = a.aux[row * 2], negdist = a.aux[row * 2 + 1];
         const float* sb = a.SB + row * H;
-        float v[DPL];
+        f4 v[C4];
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int d = lane + 64 * i;
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
             if (d < H) {
-                float x = fmaf(nav, pav[i], sb[d]);
+                f4 x = nav * pav[i] + ld4(sb + d);
                 x += dir == 0 ? diff[i] : -diff[i];
                 x += base[i];
-                x = fmaf(a.wd[d], negdist, x);
+                x += wdv[i] * negdist;
                 v[i] = x;
-                sum += x;
+                sum += hsum4(x);
             } else {
-                v[i] = 0.f;
+                v[i] = z4;
             }
         }
         const float mean = wsum(sum) / (float)H;
         float var = 0.f;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const float c = (lane + 64 * i < H) ? v[i] - mean : 0.f;
-            var += c * c;
-        }
+        for (int i = 0; i < C4; ++i)
+            if (4 * lane + 256 * i < H) {
+                const f4 c = v[i] - mean;
+                var += hsum4(c * c);
+            }
         const float rstd = 1.0f / sqrtf(wsum(var) / (float)H + kLnEps);
         float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int d = lane + 64 * i;
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
             if (d < H) {
-                const float y = gelu_erf((v[i] - mean) * rstd * a.ln_w[d] + a.ln_b[d]);
-                if (FOLD)
-                    dot = fmaf(a.v[d], y, dot);
-                else
-                    a.h1n[row * H + d] = y;
+                f4 y;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) y[c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
+                if (FOLD) {
+                    const f4 vh = ld4(a.v + d);
+                    dot += hsum4(vh * y);
+                } else {
+                    st4(a.h1n + row * H + d, y);
+                }
             }
         }
         if (FOLD) lg[dir] = wsum(dot) + a.v[H];
@@ -411,7 +437,7 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
 }
 
 // score_head + directional combine (retriever.py:369-381, 482-483), one wave per edge.
-template <int DPL>
+template <int C4>
 __global__ __launch_bounds__(256) void k_score_combine(
     const float* __restrict__ feats, int64_t e_begin, int64_t e_count, int H, int dir_fwd, int dir_bwd,
     const float* __restrict__ score_w, const float* __restrict__ score_b, const float* __restrict__ edge_bias,
@@ -423,16 +449,17 @@ __global__ __launch_bounds__(256) void k_score_combine(
     const int64_t e = e_begin + le;
     const float* ff = feats + le * H;
     const float* fb = feats + ((dir_fwd ? e_count : 0) + le) * H;
-    float vf[DPL], vb[DPL];
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f4 vf[C4], vb[C4];
     float af = 0.f, ab = 0.f;
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int d = lane + 64 * i;
-        vf[i] = (d < H && dir_fwd) ? ff[d] : 0.f;
-        vb[i] = (d < H && dir_bwd) ? fb[d] : 0.f;
-        const float w = d < H ? score_w[d] : 0.f;
-        af = fmaf(vf[i], w, af);
-        ab = fmaf(vb[i], w, ab);
+    for (int i = 0; i < C4; ++i) {
+        const int d = 4 * lane + 256 * i;
+        vf[i] = (d < H && dir_fwd) ? ld4(ff + d) : z4;
+        vb[i] = (d < H && dir_bwd) ? ld4(fb + d) : z4;
+        const f4 w = d < H ? ld4(score_w + d) : z4;
+        af += hsum4(vf[i] * w);
+        ab += hsum4(vb[i] * w);
     }
     const float eb = edge_bias ? edge_bias[e] : 0.f;
     const float lf = wsum(af) + score_b[0] + eb;
@@ -456,9 +483,9 @@ __global__ __launch_bounds__(256) void k_score_combine(
     }
     if (edge_features) {
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int d = lane + 64 * i;
-            if (d < H) edge_features[e * H + d] = (dir_fwd && dir_bwd) ? wf * vf[i] + wb * vb[i] : (dir_fwd ? vf[i] : vb[i]);
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < H) st4(edge_features + e * H + d, (dir_fwd && dir_bwd) ? wf * vf[i] + wb * vb[i] : (dir_fwd ? vf[i] : vb[i]));
         }
     }
 }
@@ -475,23 +502,19 @@ static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const floa
     return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st);
 }
 
+// float4 chunks per lane: ceil(d / 256), d <= 1280
 static int dpl_for(int d) {
-    const int need = (d + 63) / 64;
-    const int opts[] = {1, 2, 4, 8, 12, 16, 20};
-    for (int o : opts)
-        if (o >= need) return o;
-    return 0;
+    const int need = (d + 255) / 256;
+    return need < 1 ? 1 : (need > 5 ? 0 : need);
 }
 
 #define EVI_DPL_DISPATCH(dpl, CALL)              \
     switch (dpl) {                               \
         case 1: { constexpr int DPL = 1; CALL; } break;   \
         case 2: { constexpr int DPL = 2; CALL; } break;   \
+        case 3: { constexpr int DPL = 3; CALL; } break;   \
         case 4: { constexpr int DPL = 4; CALL; } break;   \
-        case 8: { constexpr int DPL = 8; CALL; } break;   \
-        case 12: { constexpr int DPL = 12; CALL; } break; \
-        case 16: { constexpr int DPL = 16; CALL; } break; \
-        default: { constexpr int DPL = 20; CALL; } break; \
+        default: { constexpr int DPL = 5; CALL; } break;  \
     }
 
 struct FwdLayout {

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Runs the WebQSP-shaped scorer forward (32 graphs, E ~ 131k, D = H = 768) a few times: the workload for
+`rocprofv3 --kernel-trace --stats -- python3 tools/scorer_forward_profile.py [lite]` (per-kernel time of the forward)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from evi_rag_amd import synthetic
+from evi_rag_amd.retriever import Retriever
+
+
+def main():
+    dev = torch.device("cuda:0")
+    D = int(os.environ.get("EVI_PROFILE_D", "768"))
+    sb = synthetic.make_batch(32, nodes_per_graph=1500, edges_per_graph=4096, emb_dim=D, num_relations=4096, num_entities=1 << 17, seed=1)
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = 4096
+    torch.manual_seed(0)
+    model = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
+    model.emit_edge_embeddings = not (len(sys.argv) > 1 and sys.argv[1] == "lite")
+    for _ in range(3):
+        model(batch)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 10
+    for _ in range(n):
+        model(batch)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"forward ({'logits only' if not model.emit_edge_embeddings else 'with edge features'}): {e0.elapsed_time(e1) / n:.3f} ms per batch, "
+          f"E={sb.num_edges} N={sb.num_nodes}")
+
+
+if __name__ == "__main__":
+    main()
