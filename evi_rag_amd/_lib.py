@@ -35,7 +35,7 @@ class EviRetrieverWeights(Structure):
                     "entity_w", "entity_b", "relation_w", "relation_b", "query_w", "query_b", "non_text_emb",
                     "q_gate_w", "q_gate_b", "q_bias_w", "q_bias_b", "struct_w", "struct_b", "struct_ln_w",
                     "struct_ln_b", "struct_gate_w", "struct_gate_b", "state0_w", "state0_b", "state_ln_w",
-                    "state_ln_b", "state4_w", "state4_b", "score_w", "score_b")]
+                    "state_ln_b", "state4_w", "state4_b", "score_w", "score_b", "prepared")]
 
 
 class EviRetrieverBatch(Structure):
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "evi_gemm_nt_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, c_int64, _P, c_int, _P, c_int64, _P]),
     "evi_gemm_nt_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int]),
     "evi_gemm_nt_bf16x3": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, c_int64, _P, c_int, _P, c_int64, _P, c_size_t, _P]),
+    "evi_retriever_prepare_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "evi_retriever_prepare": (c_int, [_P, _P, c_size_t, _P]),
     "evi_retriever_forward_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "evi_retriever_forward": (c_int, [POINTER(EviRetrieverWeights), POINTER(EviRetrieverBatch), c_int,
                                       POINTER(EviRetrieverOutput), _P, c_size_t, _P]),

@@ -85,6 +85,8 @@ int split_rows_bf16x3(const float* x, int64_t rows, int K, int64_t ld, int Kp, v
 size_t gemm_bf16x3_workspace_bytes(int N, int K);
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                           const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st);
+int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
+                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st);
 
 // ---- ordered keys ---------------------------------------------------------------------------
 // A 64-bit key whose unsigned order is the ranking order used everywhere in this library:

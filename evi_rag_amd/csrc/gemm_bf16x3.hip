@@ -436,10 +436,17 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, i
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                           const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
     if (M == 0 || N == 0) return EVI_OK;
-    const int Kp = (K + XK - 1) / XK * XK;
-    __bf16* hi = static_cast<__bf16*>(wsplit);
-    __bf16* lo = reinterpret_cast<__bf16*>(static_cast<char*>(wsplit) + align_up((size_t)N * Kp * 2, 256));
     if (int rc = split_weight_bf16x3(W, N, K, ldw, wsplit, st)) return rc;
+    return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wsplit, N, bias, act, C, ldc, st);
+}
+
+// the same with W already split (split_weight_bf16x3 wrote `wplanes`): what a caller that keeps its weights prepared uses
+int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
+                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st) {
+    if (M == 0 || N == 0) return EVI_OK;
+    const int Kp = (K + XK - 1) / XK * XK;
+    const __bf16* hi = static_cast<const __bf16*>(wplanes);
+    const __bf16* lo = reinterpret_cast<const __bf16*>(static_cast<const char*>(wplanes) + align_up((size_t)N * Kp * 2, 256));
     const GemmFilter flt{};
     const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)));
     const int tok = timing_begin(kTimeGemm, st);

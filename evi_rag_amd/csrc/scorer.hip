@@ -495,11 +495,49 @@ static bool use_f32_gemm() {
     return v && v[0] == 'f';
 }
 
-// act(A W^T + b) on the split-bf16 GEMM (default) or the exact f32 GEMM (EVI_SCORER_GEMM=f32)
+// act(A W^T + b) on the split-bf16 GEMM (default) or the exact f32 GEMM (EVI_SCORER_GEMM=f32).  wplanes: the weight's
+// bf16 hi / lo planes when the caller keeps them prepared (evi_retriever_prepare), else they are made here in `wsplit`.
 static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
-                       const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
+                       const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st,
+                       const void* wplanes = nullptr) {
     if (use_f32_gemm()) return launch_gemm_nt(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
+    if (wplanes) return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wplanes, N, bias, act, C, ldc, st);
     return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st);
+}
+
+// Everything the forward derives from the WEIGHTS alone, kept across calls by callers whose weights do not change between
+// forwards (evaluation): the column blocks of state_net.0, the transposed struct_proj weight, the folded head, and the
+// bf16 hi / lo planes of the nine GEMM weights.  ~25 small launches per forward otherwise.
+struct PrepLayout {
+    size_t wa, wb, wc, wd, wt, vhead, fold, p_entity, p_query, p_gate, p_bias, p_rel, p_wa, p_wb, p_wc, p_s4, total;
+};
+static PrepLayout prep_layout(int D, int H, int F) {
+    PrepLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t f = sizeof(float);
+    L.wa = take((size_t)H * D * f);
+    L.wb = take((size_t)H * D * f);
+    L.wc = take((size_t)H * D * f);
+    L.wd = take((size_t)H * f);
+    L.wt = take((size_t)F * D * f);
+    L.vhead = take((size_t)(H + 1) * f);
+    L.fold = take((size_t)32 * H * f);
+    L.p_entity = take(gemm_bf16x3_workspace_bytes(D, D));
+    L.p_query = take(gemm_bf16x3_workspace_bytes(D, D));
+    L.p_gate = take(gemm_bf16x3_workspace_bytes(D, D));
+    L.p_bias = take(gemm_bf16x3_workspace_bytes(D, D));
+    L.p_rel = take(gemm_bf16x3_workspace_bytes(D, D));
+    L.p_wa = take(gemm_bf16x3_workspace_bytes(H, D));
+    L.p_wb = take(gemm_bf16x3_workspace_bytes(H, D));
+    L.p_wc = take(gemm_bf16x3_workspace_bytes(H, D));
+    L.p_s4 = take(gemm_bf16x3_workspace_bytes(H, H));
+    L.total = off;
+    return L;
 }
 
 // float4 chunks per lane: ceil(d / 256), d <= 1280
@@ -581,6 +619,42 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
 using namespace evi;
 
 
+extern "C" size_t evi_retriever_prepare_bytes(int D, int H, int dde_rounds, int dde_reverse_rounds) {
+    if (D < 1 || H < 1 || dde_rounds < 0 || dde_reverse_rounds < 0) return 0;
+    return prep_layout(D, H, 2 * 2 * (1 + dde_rounds + dde_reverse_rounds)).total;
+}
+
+extern "C" int evi_retriever_prepare(const EviRetrieverWeights* w, void* prepared, size_t prepared_bytes, void* stream) {
+    EVI_REQUIRE(w && prepared, "evi_retriever_prepare: null pointer");
+    const int D = w->emb_dim, H = w->hidden_dim;
+    EVI_REQUIRE(D >= 1 && H >= 1 && D % 4 == 0 && H % 4 == 0, "evi_retriever_prepare: D and H must be positive multiples of 4");
+    const int F = 2 * 2 * (1 + w->dde_rounds + w->dde_reverse_rounds);
+    const PrepLayout PL = prep_layout(D, H, F);
+    if (prepared_bytes < PL.total)
+        return fail(EVI_ERR_NOMEM, "evi_retriever_prepare: buffer %zu B < %zu B", prepared_bytes, PL.total);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* base = static_cast<char*>(prepared);
+    auto PF = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    hipLaunchKernelGGL(k_slice_state0, dim3(H), dim3(256), 0, st, w->state0_w, H, D, PF(PL.wa), PF(PL.wb), PF(PL.wc), PF(PL.wd));
+    hipLaunchKernelGGL(k_transpose, dim3((F * D + 255) / 256), dim3(256), 0, st, w->struct_w, D, F, PF(PL.wt));
+    hipLaunchKernelGGL(k_fold_head_partial, dim3((H + 255) / 256, kFoldSlices), dim3(256), 0, st, w->state4_w, w->score_w, H,
+                       PF(PL.fold));
+    hipLaunchKernelGGL(k_fold_head_final, dim3((H + 255) / 256), dim3(256), 0, st, PF(PL.fold), w->state4_b, w->score_w,
+                       w->score_b, H, PF(PL.vhead));
+    EVI_LAUNCH_CHECK();
+    int rc;
+    if ((rc = split_weight_bf16x3(w->entity_w, D, D, D, base + PL.p_entity, st))) return rc;
+    if ((rc = split_weight_bf16x3(w->query_w, D, D, D, base + PL.p_query, st))) return rc;
+    if ((rc = split_weight_bf16x3(w->q_gate_w, D, D, D, base + PL.p_gate, st))) return rc;
+    if ((rc = split_weight_bf16x3(w->q_bias_w, D, D, D, base + PL.p_bias, st))) return rc;
+    if ((rc = split_weight_bf16x3(w->relation_w, D, D, D, base + PL.p_rel, st))) return rc;
+    if ((rc = split_weight_bf16x3(PF(PL.wa), H, D, D, base + PL.p_wa, st))) return rc;
+    if ((rc = split_weight_bf16x3(PF(PL.wb), H, D, D, base + PL.p_wb, st))) return rc;
+    if ((rc = split_weight_bf16x3(PF(PL.wc), H, D, D, base + PL.p_wc, st))) return rc;
+    if ((rc = split_weight_bf16x3(w->state4_w, H, H, H, base + PL.p_s4, st))) return rc;
+    return EVI_OK;
+}
+
 extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                                         int dde_reverse_rounds, int64_t num_relations) {
     if (N < 0 || E < 0 || B < 1 || D < 1 || H < 1) return 0;
@@ -637,16 +711,20 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     float* ns = out->node_struct ? out->node_struct : F32(L.ns);
     void* wsplit = base + L.wsplit;
     int rc;
+    // weight-derived pieces: from the caller's prepared buffer when it keeps one, else made below in the workspace
+    const char* prep = static_cast<const char*>(w->prepared);
+    const PrepLayout PL = prep_layout(D, H, F);
+    auto planes = [&](size_t off) -> const void* { return prep ? prep + off : nullptr; };
 
     // 1. projections
-    if ((rc = scorer_gemm(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, wsplit, st))) return rc;
-    if ((rc = scorer_gemm(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, wsplit, st))) return rc;
+    if ((rc = scorer_gemm(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, wsplit, st, planes(PL.p_entity)))) return rc;
+    if ((rc = scorer_gemm(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, wsplit, st, planes(PL.p_entity)))) return rc;
     hipLaunchKernelGGL(k_overwrite_non_text, dim3((unsigned)N), dim3(256), 0, st, node_repr, b->node_embedding_ids,
                        non_text, N, D);
     EVI_LAUNCH_CHECK();
-    if ((rc = scorer_gemm(b->question_emb, B, D, D, w->query_w, D, D, w->query_b, 1, q_proj, D, wsplit, st))) return rc;
-    if ((rc = scorer_gemm(q_proj, B, D, D, w->q_gate_w, D, D, w->q_gate_b, 2, gate_q, D, wsplit, st))) return rc;
-    if ((rc = scorer_gemm(q_proj, B, D, D, w->q_bias_w, D, D, w->q_bias_b, 1, bias_q, D, wsplit, st))) return rc;
+    if ((rc = scorer_gemm(b->question_emb, B, D, D, w->query_w, D, D, w->query_b, 1, q_proj, D, wsplit, st, planes(PL.p_query)))) return rc;
+    if ((rc = scorer_gemm(q_proj, B, D, D, w->q_gate_w, D, D, w->q_gate_b, 2, gate_q, D, wsplit, st, planes(PL.p_gate)))) return rc;
+    if ((rc = scorer_gemm(q_proj, B, D, D, w->q_bias_w, D, D, w->q_bias_b, 1, bias_q, D, wsplit, st, planes(PL.p_bias)))) return rc;
     if (L.dedupe) {
         const int64_t R = b->num_relations;
         int32_t* first = I32(L.rel_first);
@@ -660,9 +738,9 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         hipLaunchKernelGGL(k_gather_relation_rows, dim3((unsigned)R), dim3(256), 0, st, b->edge_embeddings, first, D,
                            F32(L.rel_rows));
         EVI_LAUNCH_CHECK();
-        if ((rc = scorer_gemm(F32(L.rel_rows), R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.rel_rows), R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     } else {
-        if ((rc = scorer_gemm(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     }
 
     // 2. structure features
@@ -675,12 +753,17 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         return rc;
 
     // 3-5. factored state_net.0 (see the header), per edge chunk
-    float *wa = F32(L.wa), *wb = F32(L.wb), *wc = F32(L.wc), *wd = F32(L.wd), *vhead = F32(L.vhead), *hcn = F32(L.hcn);
-    hipLaunchKernelGGL(k_slice_state0, dim3(H), dim3(256), 0, st, w->state0_w, H, D, wa, wb, wc, wd);
-    hipLaunchKernelGGL(k_transpose, dim3((F * D + 255) / 256), dim3(256), 0, st, w->struct_w, D, F, F32(L.wt));
-    EVI_LAUNCH_CHECK();
+    auto PF = [&](size_t off) { return reinterpret_cast<float*>(const_cast<char*>(prep) + off); };
+    float *wa = prep ? PF(PL.wa) : F32(L.wa), *wb = prep ? PF(PL.wb) : F32(L.wb), *wc = prep ? PF(PL.wc) : F32(L.wc);
+    float *wd = prep ? PF(PL.wd) : F32(L.wd), *vhead = prep ? PF(PL.vhead) : F32(L.vhead), *hcn = F32(L.hcn);
+    float* wt = prep ? PF(PL.wt) : F32(L.wt);
+    if (!prep) {
+        hipLaunchKernelGGL(k_slice_state0, dim3(H), dim3(256), 0, st, w->state0_w, H, D, wa, wb, wc, wd);
+        hipLaunchKernelGGL(k_transpose, dim3((F * D + 255) / 256), dim3(256), 0, st, w->struct_w, D, F, wt);
+        EVI_LAUNCH_CHECK();
+    }
     const bool fold = out->edge_features == nullptr;  // logits only: the head is folded into one vector
-    if (fold) {
+    if (fold && !prep) {
         float* partial = F32(L.fold);
         hipLaunchKernelGGL(k_fold_head_partial, dim3((H + 255) / 256, kFoldSlices), dim3(256), 0, st, w->state4_w,
                            w->score_w, H, partial);
@@ -688,7 +771,7 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
                            w->score_b, H, vhead);
         EVI_LAUNCH_CHECK();
     }
-    if ((rc = scorer_gemm(node_repr, N, D, D, wc, H, D, nullptr, 0, hcn, H, wsplit, st))) return rc;
+    if ((rc = scorer_gemm(node_repr, N, D, D, wc, H, D, nullptr, 0, hcn, H, wsplit, st, planes(PL.p_wc)))) return rc;
     const int dpl_d = dpl_for(D), dpl_h = dpl_for(H);
     const size_t feat_lds = (size_t)(F + 4) * D * sizeof(float);
     for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
@@ -706,7 +789,7 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         a.bias_q = bias_q;
         a.node_struct = ns;
         a.F = F;
-        a.struct_wt = F32(L.wt);
+        a.struct_wt = wt;
         a.struct_b = w->struct_b;
         a.struct_ln_w = w->struct_ln_w;
         a.struct_ln_b = w->struct_ln_b;
@@ -736,9 +819,9 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
         const int64_t M = (int64_t)dirs * ec;
-        if ((rc = scorer_gemm(F32(L.P), ec, D, D, wa, H, D, nullptr, 0, F32(L.PA), H, wsplit, st))) return rc;
-        if ((rc = scorer_gemm(F32(L.RCX), ec, D, D, wc, H, D, nullptr, 0, F32(L.RC), H, wsplit, st))) return rc;
-        if ((rc = scorer_gemm(F32(L.XS), M, D, D, wb, H, D, w->state0_b, 0, F32(L.SB), H, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.P), ec, D, D, wa, H, D, nullptr, 0, F32(L.PA), H, wsplit, st, planes(PL.p_wa)))) return rc;
+        if ((rc = scorer_gemm(F32(L.RCX), ec, D, D, wc, H, D, nullptr, 0, F32(L.RC), H, wsplit, st, planes(PL.p_wc)))) return rc;
+        if ((rc = scorer_gemm(F32(L.XS), M, D, D, wb, H, D, w->state0_b, 0, F32(L.SB), H, wsplit, st, planes(PL.p_wb)))) return rc;
         CombineArgs c;
         c.edge_index = b->edge_index;
         c.E = E;
@@ -769,7 +852,7 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         }
         EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, 0>), cgrid, dim3(256), 0, st, c));
         EVI_LAUNCH_CHECK();
-        if ((rc = scorer_gemm(F32(L.h1n), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(F32(L.h1n), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st, planes(PL.p_s4)))) return rc;
         EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_score_combine<DPL>, dim3((unsigned)((ec + 3) / 4)), dim3(256), 0, st,
                                                    F32(L.feats), e0, ec, H, dir_fwd, dir_bwd, w->score_w, w->score_b,
                                                    b->edge_bias, out->logits, out->logits_fwd, out->logits_bwd,

@@ -130,6 +130,7 @@ class Retriever(nn.Module):
         # False: forward() returns edge_embeddings=None and the library folds score_head into state_net.4
         # (logits-only evaluation, e.g. predict_step drops edge_embeddings anyway: retriever_module.py:277-285)
         self.emit_edge_embeddings = bool(emit_edge_embeddings)
+        self.cache_prepared_weights = True  # eval mode: keep the weight-derived pieces of the forward across calls
         self.emb_dim = int(emb_dim)
         self.hidden_dim = int(hidden_dim)
         self.use_topic_pe = bool(topic_pe)
@@ -209,7 +210,26 @@ class Retriever(nn.Module):
         w.state_ln_w, w.state_ln_b = p(self.state_net[1].weight), p(self.state_net[1].bias)
         w.state4_w, w.state4_b = p(self.state_net[4].weight), p(self.state_net[4].bias)
         w.score_w, w.score_b = p(self.score_head.weight), p(self.score_head.bias)
+        w.prepared = None
         return w
+
+    def _prepared_weights(self, w: "_lib.EviRetrieverWeights", dev: torch.device) -> Optional[torch.Tensor]:
+        """In eval mode the weight-derived pieces of the forward (column blocks of state_net.0, folded head, bf16 planes of the
+        GEMM weights) are made once and kept until a parameter changes (tensor version counters / storage / device), instead
+        of ~25 small launches per forward.  Training mode (weights change every step) never caches."""
+        if self.training or not self.cache_prepared_weights:
+            return None
+        params = list(self.parameters())
+        key = (str(dev),) + tuple((t.data_ptr(), t._version) for t in params)
+        cached = getattr(self, "_prep_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        lib = _lib.load()
+        need = int(lib.evi_retriever_prepare_bytes(self.emb_dim, self.hidden_dim, self.dde.num_rounds, self.dde.num_reverse_rounds))
+        buf = torch.empty(need, dtype=torch.uint8, device=dev)
+        _lib.check(lib.evi_retriever_prepare(ctypes.byref(w), buf.data_ptr(), buf.numel(), torch.cuda.current_stream(dev).cuda_stream))
+        self._prep_cache = (key, buf)
+        return buf
 
     def _empty_output(self, head_idx: torch.Tensor, return_features: bool):
         dev = head_idx.device
@@ -359,6 +379,8 @@ class Retriever(nn.Module):
         want_features = return_features or self.emit_edge_embeddings
         features = torch.empty((E, H), dtype=torch.float32, device=dev) if want_features else None
         w = self._weights_struct()
+        prep = self._prepared_weights(w, dev)
+        w.prepared = prep.data_ptr() if prep is not None else None
         b = _lib.EviRetrieverBatch()
         b.num_nodes, b.num_edges, b.num_graphs = N, E, B
         b.edge_index, b.node_ptr, b.edge_ptr, b.edge_batch = (edge_index.data_ptr(), node_ptr.data_ptr(),

@@ -553,6 +553,9 @@ typedef struct EviRetrieverWeights {
     const float* state4_b;
     const float* score_w;        /* score_head.weight [1, H] */
     const float* score_b;        /* [1] */
+    const void* prepared;        /* NULL, or the buffer evi_retriever_prepare filled FROM THESE WEIGHTS: everything the forward
+                                  * derives from the weights alone (column blocks of state_net.0, the folded head, bf16 hi / lo
+                                  * planes of the nine GEMM weights).  The caller re-prepares whenever a weight changes. */
 } EviRetrieverWeights;
 
 /* The flat PyG batch the reference's loader produces (src/data/components/loader.py:43-99), as
@@ -597,6 +600,8 @@ typedef struct EviRetrieverOutput {
  * configs/model/retriever_module.yaml:25).  direction_mode: 0 bidirectional, 1 forward, 2 backward.
  * Dense contractions run on the split-bf16 GEMM (evi_gemm_nt_bf16x3) unless the environment
  * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM. */
+size_t evi_retriever_prepare_bytes(int D, int H, int dde_rounds, int dde_reverse_rounds);
+int evi_retriever_prepare(const EviRetrieverWeights* weights, void* prepared, size_t prepared_bytes, void* stream);
 size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                              int dde_reverse_rounds, int64_t num_relations);
 int evi_retriever_forward(const EviRetrieverWeights* weights, const EviRetrieverBatch* batch,

@@ -426,3 +426,48 @@ def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
                 adj = ograph.build_directed_adjacency(n, d_l, s_l)
             ref = ograph.bfs_dist(n, adj, [0, min(5, n - 1), 0])
             assert got[ptr[g]: ptr[g + 1]].tolist() == ref, (mode, g)
+
+
+def test_prepared_weight_cache_follows_the_weights(dev):
+    """Eval mode keeps the weight-derived pieces of the forward (state_net.0 column blocks, folded head, bf16 planes) across
+    calls: the result must equal the uncached forward bit for bit, and an in-place change of ANY weight, a
+    load_state_dict or a switch to train mode must be seen by the next forward."""
+    from evi_rag_amd.retriever import Retriever
+
+    D = H = 64
+    sb = synthetic.make_batch(3, nodes_per_graph=60, edges_per_graph=150, emb_dim=D, num_relations=16, seed=8)
+    batch = synthetic.as_namespace(sb, device=dev)
+    torch.manual_seed(1)
+    model = Retriever(emb_dim=D, hidden_dim=H).to(dev).eval()
+    model.cache_prepared_weights = False
+    ref = model(batch)
+    ref_lite_model = model
+    model.cache_prepared_weights = True
+    a = model(batch)
+    b = model(batch)  # second call: served from the cache
+    assert model._prep_cache is not None
+    for x, y in ((a, ref), (b, ref)):
+        assert torch.equal(x.logits, y.logits) and torch.equal(x.edge_embeddings, y.edge_embeddings)
+    model.emit_edge_embeddings = False  # folded head from the cache
+    lite = model(batch).logits
+    model.cache_prepared_weights = False
+    assert torch.equal(lite, ref_lite_model(batch).logits)
+    model.cache_prepared_weights = True
+    model.emit_edge_embeddings = True
+    # an in-place edit of one weight
+    with torch.no_grad():
+        model.state_net[4].weight.mul_(1.5)
+        model.score_head.bias.add_(0.25)
+    c = model(batch)
+    model.cache_prepared_weights = False
+    want = model(batch)
+    model.cache_prepared_weights = True
+    assert torch.equal(c.logits, want.logits) and not torch.equal(c.logits, ref.logits)
+    # load_state_dict of other weights
+    torch.manual_seed(2)
+    other = Retriever(emb_dim=D, hidden_dim=H).to(dev).eval()
+    model.load_state_dict(other.state_dict(), strict=True)
+    assert torch.equal(model(batch).logits, other(batch).logits)
+    # train mode never serves from the cache
+    model.train()
+    assert model._prepared_weights(model._weights_struct(), dev) is None
