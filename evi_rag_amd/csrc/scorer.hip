@@ -17,9 +17,10 @@
 //      Wb s [2E rows]  —  8 D H flops per edge instead of 12 D H for the concatenated form, and the
 //      [2E, 3D+1] input is never materialised                                      -> gemm*.hip
 //      then one wave per edge sums the terms, LayerNorm + GELU                    -> k_state_combine
-//   5. state_net.4 (GEMM) -> score_head + 2-way softmax combine                    -> k_score_combine
-//      When the caller does not ask for edge features (EviRetrieverOutput.edge_features == NULL) the
-//      head is folded, logit = (W2^T w) . h1 + (w . b2 + b), and state_net.4 is never formed.
+//   5. score_head after state_net.4 is one linear map of the normalised row, so the head is FOLDED:
+//      logit_dir = (W2^T w) . y_dir + (w . b2 + b), and the 2-way softmax combine happens in k_state_combine.
+//      Edge features (EviRetrieverOutput.edge_features), when asked for, are w_f f_f + w_b f_b = W2 (w_f y_f + w_b y_b) + b2:
+//      ONE state_net.4 GEMM over E combined rows, written straight into the output (not 2E rows + a combine pass).
 // Bound: MFMA (steps 1, 4, 5: 2*(4DH + 2H^2) flops per edge); steps 2-3 are gathers.
 #include "common.hpp"
 
@@ -317,9 +318,11 @@ __global__ void k_fold_head_final(const float* __restrict__ partial, const float
 }
 
 // One wave per edge: h1_dir = nav_dir * PA[e] + SB[dir, e] + sign_dir * (HcN[head] - HcN[tail]) + RC[e]
-// + wd * (-dist_dir)   (SB already holds state_net.0.bias), then LayerNorm + exact GELU.
-// FOLD == 0: the normalised rows go to h1n [(dirs) * e_count, H] for state_net.4.
-// FOLD == 1: logit_dir = v . row + v[H] and the 2-way softmax combine (retriever.py:369-381) right here.
+// + wd * (-dist_dir)   (SB already holds state_net.0.bias), then LayerNorm + exact GELU = y_dir.
+// The head is folded: logit_dir = v . y_dir + v[H] with v = W2^T w (score_head after state_net.4 is one linear map of
+// y_dir), and the 2-way softmax combine (retriever.py:369-381) happens right here.  When the caller wants the edge features
+// (RetrieverOutput.edge_embeddings = w_f f_f + w_b f_b with f_dir = W2 y_dir + b2 and w_f + w_b = 1), linearity gives
+// features = W2 (w_f y_f + w_b y_b) + b2: the combined row goes to h1c [e_count, H] and state_net.4 runs on E rows, not 2E.
 struct CombineArgs {
     const int64_t* edge_index;
     int64_t E, e_begin, e_count;
@@ -332,7 +335,7 @@ struct CombineArgs {
     const float* ln_w;
     const float* ln_b;
     int H, dir_fwd, dir_bwd;
-    float* h1n;
+    float* h1c;      // [e_count, H] combined normalised rows, or null (logits only)
     const float* v;  // [H + 1] folded head
     const float* edge_bias;  // [E] or null
     float* logits;
@@ -340,7 +343,7 @@ struct CombineArgs {
     float* logits_bwd;
 };
 
-template <int C4, int FOLD>
+template <int C4>
 __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -368,9 +371,12 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
         }
     }
     float lg[2] = {0.f, 0.f};
+    f4 y[2][C4];  // the normalised rows of both directions (kept for the combined row)
     int out_row = 0;
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
+#pragma unroll
+        for (int i = 0; i < C4; ++i) y[dir][i] = z4;
         if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
         const int64_t row = (int64_t)out_row * a.e_count + le;
         const float nav = a.aux[row * 2], negdist = a.aux[row * 2 + 1];
@@ -405,87 +411,38 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
         for (int i = 0; i < C4; ++i) {
             const int d = 4 * lane + 256 * i;
             if (d < H) {
-                f4 y;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) y[c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
-                if (FOLD) {
-                    const f4 vh = ld4(a.v + d);
-                    dot += hsum4(vh * y);
-                } else {
-                    st4(a.h1n + row * H + d, y);
-                }
+                for (int c = 0; c < 4; ++c) y[dir][i][c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
+                dot += hsum4(ld4(a.v + d) * y[dir][i]);
             }
         }
-        if (FOLD) lg[dir] = wsum(dot) + a.v[H];
+        lg[dir] = wsum(dot) + a.v[H];
         ++out_row;
     }
-    if (FOLD && lane == 0) {
-        const float eb = a.edge_bias ? a.edge_bias[e] : 0.f;
-        const float lf = lg[0] + eb, lb = lg[1] + eb;
-        float out = lf;
-        if (a.dir_fwd && a.dir_bwd) {
-            const float m = fmaxf(lf, lb);
-            const float ef = expf(lf - m), eb = expf(lb - m);
-            out = (ef * lf + eb * lb) / (ef + eb);
-        } else if (a.dir_bwd) {
-            out = lb;
-        }
+    const float eb = a.edge_bias ? a.edge_bias[e] : 0.f;
+    const float lf = lg[0] + eb, lb = lg[1] + eb;
+    float wf = 1.f, wb = 0.f, out = lf;
+    if (a.dir_fwd && a.dir_bwd) {
+        const float m = fmaxf(lf, lb);
+        const float ef = expf(lf - m), ebk = expf(lb - m);
+        wf = ef / (ef + ebk);
+        wb = ebk / (ef + ebk);
+        out = wf * lf + wb * lb;
+    } else if (a.dir_bwd) {
+        wf = 0.f;
+        wb = 1.f;
+        out = lb;
+    }
+    if (lane == 0) {
         a.logits[e] = out;
         if (a.logits_fwd && a.dir_fwd) a.logits_fwd[e] = lf;
         if (a.logits_bwd && a.dir_bwd) a.logits_bwd[e] = lb;
     }
-}
-
-// score_head + directional combine (retriever.py:369-381, 482-483), one wave per edge.
-template <int C4>
-__global__ __launch_bounds__(256) void k_score_combine(
-    const float* __restrict__ feats, int64_t e_begin, int64_t e_count, int H, int dir_fwd, int dir_bwd,
-    const float* __restrict__ score_w, const float* __restrict__ score_b, const float* __restrict__ edge_bias,
-    float* __restrict__ logits, float* __restrict__ logits_fwd, float* __restrict__ logits_bwd,
-    float* __restrict__ edge_features) {
-    const int lane = threadIdx.x & 63;
-    const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (le >= e_count) return;
-    const int64_t e = e_begin + le;
-    const float* ff = feats + le * H;
-    const float* fb = feats + ((dir_fwd ? e_count : 0) + le) * H;
-    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f4 vf[C4], vb[C4];
-    float af = 0.f, ab = 0.f;
-#pragma unroll
-    for (int i = 0; i < C4; ++i) {
-        const int d = 4 * lane + 256 * i;
-        vf[i] = (d < H && dir_fwd) ? ld4(ff + d) : z4;
-        vb[i] = (d < H && dir_bwd) ? ld4(fb + d) : z4;
-        const f4 w = d < H ? ld4(score_w + d) : z4;
-        af += hsum4(vf[i] * w);
-        ab += hsum4(vb[i] * w);
-    }
-    const float eb = edge_bias ? edge_bias[e] : 0.f;
-    const float lf = wsum(af) + score_b[0] + eb;
-    const float lb = wsum(ab) + score_b[0] + eb;
-    float wf = 1.f, wb = 0.f, lg = lf;
-    if (dir_fwd && dir_bwd) {
-        const float m = fmaxf(lf, lb);
-        const float ef = expf(lf - m), eb = expf(lb - m);
-        wf = ef / (ef + eb);
-        wb = eb / (ef + eb);
-        lg = wf * lf + wb * lb;
-    } else if (dir_bwd) {
-        wf = 0.f;
-        wb = 1.f;
-        lg = lb;
-    }
-    if (lane == 0) {
-        logits[e] = lg;
-        if (logits_fwd && dir_fwd) logits_fwd[e] = lf;
-        if (logits_bwd && dir_bwd) logits_bwd[e] = lb;
-    }
-    if (edge_features) {
+    if (a.h1c) {  // edge features requested: state_net.4 is linear, so it runs ONCE on the combined normalised row
 #pragma unroll
         for (int i = 0; i < C4; ++i) {
             const int d = 4 * lane + 256 * i;
-            if (d < H) st4(edge_features + e * H + d, (dir_fwd && dir_bwd) ? wf * vf[i] + wb * vb[i] : (dir_fwd ? vf[i] : vb[i]));
+            if (d < H) st4(a.h1c + le * H + d, wf * y[0][i] + wb * y[1][i]);
         }
     }
 }
@@ -558,7 +515,7 @@ static int dpl_for(int d) {
 struct FwdLayout {
     size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
         in_eid, out_ptr, out_nbr, out_eid, csr_ws, wa, wb, wc, wd, vhead, fold, wt, wsplit, hcn, P, RCX, XS, aux, PA, RC, SB,
-        h1n, feats, total;
+        h1n, total;
     int64_t ec;
     int dedupe;
 };
@@ -608,8 +565,7 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.PA = take((size_t)L.ec * H * f);
     L.RC = take((size_t)L.ec * H * f);
     L.SB = take((size_t)dirs * L.ec * H * f);
-    L.h1n = take((size_t)dirs * L.ec * H * f);
-    L.feats = take((size_t)dirs * L.ec * H * f);
+    L.h1n = take((size_t)L.ec * H * f);  // combined normalised rows (input of state_net.4 when features are wanted)
     L.total = off;
     return L;
 }
@@ -762,8 +718,7 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         hipLaunchKernelGGL(k_transpose, dim3((F * D + 255) / 256), dim3(256), 0, st, w->struct_w, D, F, wt);
         EVI_LAUNCH_CHECK();
     }
-    const bool fold = out->edge_features == nullptr;  // logits only: the head is folded into one vector
-    if (fold && !prep) {
+    if (!prep) {  // the folded head v = W2^T w, v[H] = w . b2 + b
         float* partial = F32(L.fold);
         hipLaunchKernelGGL(k_fold_head_partial, dim3((H + 255) / 256, kFoldSlices), dim3(256), 0, st, w->state4_w,
                            w->score_w, H, partial);
@@ -838,26 +793,19 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
         c.H = H;
         c.dir_fwd = dir_fwd;
         c.dir_bwd = dir_bwd;
-        c.h1n = F32(L.h1n);
+        c.h1c = out->edge_features ? F32(L.h1n) : nullptr;
         c.v = vhead;
         c.edge_bias = b->edge_bias;
         c.logits = out->logits;
         c.logits_fwd = out->logits_fwd;
         c.logits_bwd = out->logits_bwd;
         const dim3 cgrid((unsigned)((ec + 3) / 4));
-        if (fold) {
-            EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, 1>), cgrid, dim3(256), 0, st, c));
-            EVI_LAUNCH_CHECK();
-            continue;
-        }
-        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, 0>), cgrid, dim3(256), 0, st, c));
+        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL>), cgrid, dim3(256), 0, st, c));
         EVI_LAUNCH_CHECK();
-        if ((rc = scorer_gemm(F32(L.h1n), M, H, H, w->state4_w, H, H, w->state4_b, 0, F32(L.feats), H, wsplit, st, planes(PL.p_s4)))) return rc;
-        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL(k_score_combine<DPL>, dim3((unsigned)((ec + 3) / 4)), dim3(256), 0, st,
-                                                   F32(L.feats), e0, ec, H, dir_fwd, dir_bwd, w->score_w, w->score_b,
-                                                   b->edge_bias, out->logits, out->logits_fwd, out->logits_bwd,
-                                                   out->edge_features));
-        EVI_LAUNCH_CHECK();
+        if (out->edge_features)  // state_net.4 on the combined rows, straight into the caller's [E, H] output
+            if ((rc = scorer_gemm(F32(L.h1n), ec, H, H, w->state4_w, H, H, w->state4_b, 0, out->edge_features + e0 * H, H, wsplit,
+                                  st, planes(PL.p_s4))))
+                return rc;
     }
     return EVI_OK;
 }
