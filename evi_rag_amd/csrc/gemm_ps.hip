@@ -20,6 +20,7 @@
 #include "common.hpp"
 
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 namespace evi {
 
@@ -37,12 +38,13 @@ __device__ inline float act_ps(float v, int act) {
 
 __device__ inline int slot_ps(int r, int c) { return r * 4 + (c ^ ((r >> 2) & 3)); }
 
+template <int AUX = 0>
 __device__ inline void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
-template <int ACT>
+template <int ACT, int DBG = 0>
 __global__ __launch_bounds__(kPsThreads) void k_gemm_ps_bf16x3(
     const __bf16* __restrict__ Ahi, const __bf16* __restrict__ Alo, int64_t M, int Kp, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc) {
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(kPsThreads) void k_gemm_ps_bf16x3(
         const int plane = p >> 1, half = p & 1;
         const __bf16* base = plane == 0 ? Ahi : (plane == 1 ? Alo : (plane == 2 ? Whi : Wlo));
         const int64_t off = (plane < 2 ? a_off[half] : w_off[half]) + k0;
-        glds16(base + off, &smem[stage][plane][half * 512 + wave * 64]);
+        glds16<0>(base + off, &smem[stage][plane][half * 512 + wave * 64]);
     };
 
     f32x16 acc[4][2];
@@ -123,13 +125,24 @@ __global__ __launch_bounds__(kPsThreads) void k_gemm_ps_bf16x3(
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbl[ks][j], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbh[ks][j], c, 0, 0, 0);
             }
-            stage_piece(cur ^ 1, g, kn);  // one DMA instruction behind each MFMA group
+            if (DBG != 2) stage_piece(cur ^ 1, g, kn);  // one DMA instruction behind each MFMA group
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // every wave's DMA has landed (vmcnt(0)) and every read of `cur` is done
         cur ^= 1;
     }
 
+    if (DBG == 1 || DBG == 2) {  // timing experiments: keep the accumulators alive, store one value per lane
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) C[tid] = t;
+        return;
+    }
     if (m0 + PM <= M && n0 + PN <= N) {  // interior tile
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -195,6 +208,14 @@ int launch_gemm_ps_bf16x3(const void* Ahi, const void* Alo, int64_t M, int Kp, c
     hipLaunchKernelGGL((k_gemm_ps_bf16x3<ACT>), grid, dim3(kPsThreads), 0, st, static_cast<const __bf16*>(Ahi),        \
                        static_cast<const __bf16*>(Alo), M, Kp, static_cast<const __bf16*>(Whi),                         \
                        static_cast<const __bf16*>(Wlo), N, bias, C, ldc)
+    // EVI_GEMM_PS_DEBUG = 1 / 2: ablation builds for timing only (wrong results): no epilogue stores / no stores and no DMA
+    // in the k-loop.  Measured at M = 131 072, K = N = 768 (profiles/r02_gemm_ablation.txt): 0.444 ms as shipped,
+    // 0.395 without the f32 stores, 0.324 without stores and DMA — the LDS-fed MFMA loop alone runs at 0.57 of the bf16
+    // peak, the L2 -> LDS traffic costs 18 %, the f32 output stores 11 %.  Non-temporal A loads (-7 %) and non-temporal
+    // C stores (+-0) were tried and dropped.
+    static const int dbg = [] { const char* e = getenv("EVI_GEMM_PS_DEBUG"); return e ? atoi(e) : 0; }();
+    if (dbg == 1) { hipLaunchKernelGGL((k_gemm_ps_bf16x3<0, 1>), grid, dim3(kPsThreads), 0, st, static_cast<const __bf16*>(Ahi), static_cast<const __bf16*>(Alo), M, Kp, static_cast<const __bf16*>(Whi), static_cast<const __bf16*>(Wlo), N, bias, C, ldc); timing_end(tok, st); return EVI_OK; }
+    if (dbg == 2) { hipLaunchKernelGGL((k_gemm_ps_bf16x3<0, 2>), grid, dim3(kPsThreads), 0, st, static_cast<const __bf16*>(Ahi), static_cast<const __bf16*>(Alo), M, Kp, static_cast<const __bf16*>(Whi), static_cast<const __bf16*>(Wlo), N, bias, C, ldc); timing_end(tok, st); return EVI_OK; }
     switch (act) {
         case 1: EVI_LAUNCH_PSX(1); break;
         case 2: EVI_LAUNCH_PSX(2); break;
