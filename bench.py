@@ -181,8 +181,9 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     coll = M.RetrieverMetricCollection(K_WINDOW)
     target = batch.labels > 0.5
     E, N, H = sb.num_edges, sb.num_nodes, D
-    # projections + Wc node_repr + per edge (Wa p, Wc r_ctx: E rows; Wb s, state_net.4: 2E rows) — DESIGN.md §4
-    gemm_flops = 2.0 * D * D * (N + 1 + 3 * graphs + relations) + 2.0 * N * D * H + 8.0 * E * D * H + 4.0 * E * H * H
+    # projections + Wc node_repr + per edge (Wa p, Wc r_ctx: E rows; Wb s: 2E rows; state_net.4: E rows — it runs once on the
+    # softmax-combined row, the head is folded) — DESIGN.md §4
+    gemm_flops = 2.0 * D * D * (N + 1 + 3 * graphs + relations) + 2.0 * N * D * H + 8.0 * E * D * H + 2.0 * E * H * H
 
     def one():
         out = model(batch)
