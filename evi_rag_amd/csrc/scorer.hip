@@ -447,6 +447,10 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
     }
 }
 
+}  // namespace evi
+#include "scorer_bwd.hpp"
+namespace evi {
+
 static bool use_f32_gemm() {
     const char* v = getenv("EVI_SCORER_GEMM");
     return v && v[0] == 'f';
@@ -618,9 +622,167 @@ extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, in
     return fwd_layout(N, E, B, D, H, F, num_relations, 2).total;
 }
 
-extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
-                                     const EviRetrieverOutput* out, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+// Backward context of retriever_run (null: forward only).  Gradients use the weights struct's layout (float* written).
+struct BwdCtx {
+    const float* dlogits;          // [E]
+    const EviRetrieverWeights* g;  // gradient buffers, same shapes as the weights
+    const int64_t* rel_perm;       // [E] edge ids grouped by relation id (stable), or null when relations are not de-duplicated
+    const int64_t* rel_ptr;        // [R + 1] segment bounds into rel_perm
+    char* ws;                      // backward workspace (evi_retriever_backward_workspace_bytes)
+};
+
+struct BwdLayout {
+    size_t DZ, DPA, DRC, daux, dP, dRCX, dXS, DU, SX, partC, partE, DDF, DH, DT, DRR, DGQ, DBQ, dNR, dHcN, tmpN, dRRu, dGQ, dBQ, dQP,
+        dnt, WaT, WbT, WcT, WgT, WbqT, WeT, gWa, gWb, gWc, gwd, ysum, ssum, At, Bt, tnpart, wsplit2, colpart, total;
+    int64_t kmax;
+    int gridC, gridE, wavesE;
+};
+constexpr int kTnSlice = 8192;
+constexpr int kTnMaxSlices = 64;
+
+static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, int64_t R, int64_t ec) {
+    BwdLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t f = sizeof(float);
+    const int mx = D > H ? D : H;
+    const size_t e1 = (size_t)(E > 0 ? E : 1), n1 = (size_t)(N > 0 ? N : 1);
+    L.gridC = (int)((ec + 3) / 4 < 1024 ? (ec + 3) / 4 : 1024);
+    if (L.gridC < 1) L.gridC = 1;
+    // waves per workgroup of the edge backward: what is left of the LDS after the struct weights, at most 4
+    const int64_t lds_left = (int64_t)160 * 1024 - (int64_t)(F + 4) * D * 4 - 256;
+    int wv = (int)(lds_left / ((int64_t)3 * D * 4 + 4));
+    L.wavesE = wv > 4 ? 4 : (wv < 1 ? 1 : wv);
+    L.gridE = (int)((ec + L.wavesE - 1) / L.wavesE < 512 ? (ec + L.wavesE - 1) / L.wavesE : 512);
+    if (L.gridE < 1) L.gridE = 1;
+    L.DZ = take((size_t)2 * ec * H * f);
+    L.DPA = take((size_t)ec * H * f);
+    L.DRC = take((size_t)ec * H * f);
+    L.daux = take((size_t)2 * ec * 2 * f);
+    L.dP = take((size_t)ec * D * f);
+    L.dRCX = take((size_t)ec * D * f);
+    L.dXS = take((size_t)2 * ec * D * f);
+    L.DU = take((size_t)2 * ec * D * f);
+    L.SX = take((size_t)2 * ec * F * f);
+    L.partC = take(((size_t)L.gridC * 5 * H + L.gridC) * f);
+    L.partE = take(((size_t)L.gridE * 3 * D + L.gridE) * f);
+    L.DDF = take(e1 * H * f);
+    L.DH = take(e1 * D * f);
+    L.DT = take(e1 * D * f);
+    L.DRR = take(e1 * D * f);
+    L.DGQ = take(e1 * D * f);
+    L.DBQ = take(e1 * D * f);
+    L.dNR = take(n1 * D * f);
+    L.dHcN = take(n1 * H * f);
+    L.tmpN = take(n1 * D * f);
+    L.dRRu = take((size_t)(R > 0 ? R : 1) * D * f);
+    L.dGQ = take((size_t)B * D * f);
+    L.dBQ = take((size_t)B * D * f);
+    L.dQP = take((size_t)B * D * f * 2);
+    L.dnt = take((size_t)D * f * 2);
+    L.WaT = take((size_t)D * H * f);
+    L.WbT = take((size_t)D * H * f);
+    L.WcT = take((size_t)D * H * f);
+    L.WgT = take((size_t)D * D * f);
+    L.WbqT = take((size_t)D * D * f);
+    L.WeT = take((size_t)D * D * f);
+    L.gWa = take((size_t)H * D * f);
+    L.gWb = take((size_t)H * D * f);
+    L.gWc = take((size_t)H * D * f);
+    L.gwd = take((size_t)H * f);
+    L.ysum = take((size_t)H * f);
+    L.ssum = take(256);
+    int64_t kmax = 2 * ec;
+    if ((int64_t)N > kmax) kmax = N;
+    if (E > kmax && R <= 0) kmax = E;
+    if (R > kmax) kmax = R;
+    if (B > kmax) kmax = B;
+    kmax = (kmax + 31) / 32 * 32;
+    L.kmax = kmax;
+    L.At = take((size_t)mx * kmax * f);
+    L.Bt = take((size_t)mx * kmax * f);
+    L.tnpart = take((size_t)kTnMaxSlices * mx * mx * f);
+    L.wsplit2 = take(gemm_bf16x3_workspace_bytes(mx, kTnSlice + 32));
+    L.colpart = take(((size_t)(kmax + 1023) / 1024 + 8) * mx * f);  // also the scratch row of the five / three column vectors
+    L.total = off;
+    return L;
+}
+
+// C [M, N] (+)= A^T B with A [K, M], B [K, N] row-major and K large: explicit transposes, split-K NT GEMMs (scorer_gemm), and an
+// ordered reduction of the slice results.  Correct and deterministic; the transposes cost two extra passes over A and B.
+static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, float* C, int accumulate, const BwdLayout& L,
+                   char* ws, hipStream_t st) {
+    if (K <= 0) {
+        if (!accumulate) hipLaunchKernelGGL(k_zero_f32, dim3(64), dim3(256), 0, st, C, (int64_t)M * N);
+        return EVI_OK;
+    }
+    const int64_t Kp = (K + 31) / 32 * 32;
+    float* At = reinterpret_cast<float*>(ws + L.At);
+    float* Bt = reinterpret_cast<float*>(ws + L.Bt);
+    float* part = reinterpret_cast<float*>(ws + L.tnpart);
+    const dim3 ga((unsigned)((Kp + 31) / 32), (unsigned)((M + 31) / 32)), gb((unsigned)((Kp + 31) / 32), (unsigned)((N + 31) / 32));
+    hipLaunchKernelGGL(k_transpose_pad, ga, dim3(256), 0, st, A, K, M, (int64_t)M, At, Kp);
+    hipLaunchKernelGGL(k_transpose_pad, gb, dim3(256), 0, st, Bm, K, N, (int64_t)N, Bt, Kp);
+    EVI_LAUNCH_CHECK();
+    int64_t S = (Kp + kTnSlice - 1) / kTnSlice;
+    if (S > kTnMaxSlices) S = kTnMaxSlices;
+    int64_t Ks = ((Kp + S - 1) / S + 31) / 32 * 32;
+    if (Ks > kTnSlice + 32) {  // very long K: more than kTnMaxSlices slices of kTnSlice — run them in rounds that accumulate
+        Ks = kTnSlice;
+    }
+    int used = 0;
+    int first_round = 1;
+    for (int64_t k0 = 0; k0 < Kp; k0 += Ks) {
+        const int64_t kl = Kp - k0 < Ks ? Kp - k0 : Ks;
+        int rc = scorer_gemm(At + k0, M, (int)kl, Kp, Bt + k0, N, Kp, nullptr, 0, part + (int64_t)used * M * N, N, ws + L.wsplit2, st);
+        if (rc) return rc;
+        if (++used == kTnMaxSlices || k0 + Ks >= Kp) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, part, used,
+                               (int64_t)M * N, C, (accumulate || !first_round) ? 1 : 0);
+            EVI_LAUNCH_CHECK();
+            used = 0;
+            first_round = 0;
+        }
+    }
+    return EVI_OK;
+}
+
+// out[cols] (+)= column sums of X [rows, cols]
+static int colsum_into(const float* X, int64_t rows, int cols, float* out, int accumulate, const BwdLayout& L, char* ws,
+                       hipStream_t st) {
+    if (rows <= 0) return EVI_OK;
+    float* part = reinterpret_cast<float*>(ws + L.colpart);
+    const int nb = (int)((rows + 1023) / 1024);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(256), 0, st, X, rows, cols, part);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, nb, (int64_t)cols, out, accumulate);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+// state_net.0.weight gradient [H, 3D+1] from its column blocks
+__global__ void k_merge_state0(const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc,
+                               const float* __restrict__ gd, int H, int D, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    float* dst = out + (int64_t)r * (3 * D + 1);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        dst[d] = ga[(int64_t)r * D + d];
+        dst[D + d] = gb[(int64_t)r * D + d];
+        dst[2 * D + d] = gc[(int64_t)r * D + d];
+    }
+    if (threadIdx.x == 0) dst[3 * D] = gd[r];
+}
+
+static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
+                         const EviRetrieverOutput* out, void* workspace, size_t workspace_bytes, void* stream,
+                         const BwdCtx* bw) {
     EVI_REQUIRE(w && b && out, "evi_retriever_forward: null struct pointer");
     const int D = w->emb_dim, H = w->hidden_dim;
     const int64_t N = b->num_nodes, E = b->num_edges;
@@ -729,6 +891,39 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     if ((rc = scorer_gemm(node_repr, N, D, D, wc, H, D, nullptr, 0, hcn, H, wsplit, st, planes(PL.p_wc)))) return rc;
     const int dpl_d = dpl_for(D), dpl_h = dpl_for(H);
     const size_t feat_lds = (size_t)(F + 4) * D * sizeof(float);
+    // ---- backward: set-up ----------------------------------------------------------------------------------------
+    BwdLayout BL{};
+    char* bws = nullptr;
+    auto G = [&](const float* p) { return const_cast<float*>(p); };  // gradient buffers live in a weights-shaped struct
+    auto BF = [&](size_t off) { return reinterpret_cast<float*>(bws + off); };
+    auto zero = [&](float* p, int64_t n) {
+        if (n > 0) hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st, p, n);
+    };
+    auto transpose = [&](const float* src, int R_, int C_, float* dst) {  // dst [C_, R_] = src[R_, C_]^T
+        hipLaunchKernelGGL(k_transpose_pad, dim3((unsigned)((R_ + 31) / 32), (unsigned)((C_ + 31) / 32)), dim3(256), 0, st, src,
+                           (int64_t)R_, C_, (int64_t)C_, dst, (int64_t)R_);
+    };
+    if (bw) {
+        BL = bwd_layout(N, E, B, D, H, F, L.dedupe ? b->num_relations : 0, L.ec);
+        bws = bw->ws;
+        const EviRetrieverWeights* g = bw->g;
+        zero(G(g->entity_w), (int64_t)D * D); zero(G(g->entity_b), D); zero(G(g->relation_w), (int64_t)D * D); zero(G(g->relation_b), D);
+        zero(G(g->query_w), (int64_t)D * D); zero(G(g->query_b), D); zero(G(g->non_text_emb), D);
+        zero(G(g->q_gate_w), (int64_t)D * D); zero(G(g->q_gate_b), D); zero(G(g->q_bias_w), (int64_t)D * D); zero(G(g->q_bias_b), D);
+        zero(G(g->struct_w), (int64_t)D * F); zero(G(g->struct_b), D); zero(G(g->struct_ln_w), D); zero(G(g->struct_ln_b), D);
+        zero(G(g->struct_gate_w), D); zero(G(g->struct_gate_b), 1);
+        zero(G(g->state0_w), (int64_t)H * (3 * D + 1)); zero(G(g->state0_b), H); zero(G(g->state_ln_w), H); zero(G(g->state_ln_b), H);
+        zero(G(g->state4_w), (int64_t)H * H); zero(G(g->state4_b), H); zero(G(g->score_w), H); zero(G(g->score_b), 1);
+        zero(BF(BL.gWa), (int64_t)H * D); zero(BF(BL.gWb), (int64_t)H * D); zero(BF(BL.gWc), (int64_t)H * D); zero(BF(BL.gwd), H);
+        zero(BF(BL.ysum), H); zero(BF(BL.ssum), 1);
+        transpose(wa, H, D, BF(BL.WaT));
+        transpose(wb, H, D, BF(BL.WbT));
+        transpose(wc, H, D, BF(BL.WcT));
+        transpose(w->q_gate_w, D, D, BF(BL.WgT));
+        transpose(w->q_bias_w, D, D, BF(BL.WbqT));
+        transpose(w->entity_w, D, D, BF(BL.WeT));
+        EVI_LAUNCH_CHECK();
+    }
     for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
         const int64_t ec = (E - e0) < L.ec ? (E - e0) : L.ec;
         EdgeFeatArgs a;
@@ -806,6 +1001,186 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
             if ((rc = scorer_gemm(F32(L.h1n), ec, H, H, w->state4_w, H, H, w->state4_b, 0, out->edge_features + e0 * H, H, wsplit,
                                   st, planes(PL.p_s4))))
                 return rc;
+        if (!bw) continue;
+        // ---- backward of this chunk (scorer_bwd.hpp) ----------------------------------------------------------------
+        const EviRetrieverWeights* g = bw->g;
+        CombineBwdArgs cb;
+        cb.f = c;
+        cb.dlogits = bw->dlogits;
+        cb.DZ = BF(BL.DZ);
+        cb.DPA = BF(BL.DPA);
+        cb.DRC = BF(BL.DRC);
+        cb.DDF = BF(BL.DDF);
+        cb.daux = BF(BL.daux);
+        cb.part = BF(BL.partC);
+        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_combine_bwd<DPL>), dim3(BL.gridC), dim3(256), 0, st, cb));
+        EVI_LAUNCH_CHECK();
+        {   // column partials: [gridC][5][H] then [gridC] — reduce each of the five vectors and S (accumulating over chunks)
+            float* dst5[5] = {G(g->state_ln_w), G(g->state_ln_b), BF(BL.ysum), BF(BL.gwd), G(g->state0_b)};
+            // the partial rows interleave the five vectors: reduce them as one [gridC][5H] table into a scratch row first
+            float* tmp = BF(BL.colpart);
+            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((5 * H + 255) / 256)), dim3(256), 0, st, BF(BL.partC), BL.gridC,
+                               (int64_t)5 * H, tmp, 0);
+            for (int q = 0; q < 5; ++q)
+                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, dst5[q], tmp + (int64_t)q * H, (int64_t)H);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, BF(BL.partC) + (int64_t)BL.gridC * 5 * H, BL.gridC, (int64_t)1,
+                               BF(BL.ssum), 1);
+            EVI_LAUNCH_CHECK();
+        }
+        // d(state_net.0 inputs): dP = dPA Wa, dRCX = dRC Wc, dXS = dz Wb   (NT GEMMs against the transposed blocks)
+        if ((rc = scorer_gemm(BF(BL.DPA), ec, H, H, BF(BL.WaT), D, H, nullptr, 0, BF(BL.dP), D, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(BF(BL.DRC), ec, H, H, BF(BL.WcT), D, H, nullptr, 0, BF(BL.dRCX), D, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(BF(BL.DZ), M, H, H, BF(BL.WbT), D, H, nullptr, 0, BF(BL.dXS), D, wsplit, st))) return rc;
+        // weight blocks of state_net.0: dWa += dPA^T P, dWc += dRC^T RCX, dWb += dz^T XS
+        if ((rc = tn_gemm(BF(BL.DPA), H, F32(L.P), D, ec, BF(BL.gWa), 1, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(BF(BL.DRC), H, F32(L.RCX), D, ec, BF(BL.gWc), 1, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(BF(BL.DZ), H, F32(L.XS), D, M, BF(BL.gWb), 1, BL, bws, st))) return rc;
+        EdgeBwdArgs eb;
+        eb.f = a;
+        eb.dP = BF(BL.dP);
+        eb.dRCX = BF(BL.dRCX);
+        eb.dXS = BF(BL.dXS);
+        eb.daux = BF(BL.daux);
+        eb.DH = BF(BL.DH);
+        eb.DT = BF(BL.DT);
+        eb.DRR = BF(BL.DRR);
+        eb.DGQ = BF(BL.DGQ);
+        eb.DBQ = BF(BL.DBQ);
+        eb.DU = BF(BL.DU);
+        eb.SX = BF(BL.SX);
+        eb.part = BF(BL.partE);
+        {
+            const size_t lds = ((size_t)(F + 4) * D + (size_t)BL.wavesE * 3 * D + BL.wavesE) * sizeof(float);
+            EVI_DPL_DISPATCH(dpl_d, {
+                static thread_local bool attr = false;
+                if (!attr) {
+                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features_bwd<DPL>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr = true;
+                }
+                hipLaunchKernelGGL(k_edge_features_bwd<DPL>, dim3(BL.gridE), dim3(BL.wavesE * 64), lds, st, eb);
+            });
+            EVI_LAUNCH_CHECK();
+            float* tmp = BF(BL.colpart);
+            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((3 * D + 255) / 256)), dim3(256), 0, st, BF(BL.partE), BL.gridE,
+                               (int64_t)3 * D, tmp, 0);
+            float* dst3[3] = {G(g->struct_ln_w), G(g->struct_ln_b), G(g->struct_gate_w)};
+            for (int q = 0; q < 3; ++q)
+                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, dst3[q], tmp + (int64_t)q * D, (int64_t)D);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, BF(BL.partE) + (int64_t)BL.gridE * 3 * D, BL.gridE, (int64_t)1,
+                               G(g->struct_gate_b), 1);
+            EVI_LAUNCH_CHECK();
+        }
+        // struct_proj.0: weight [D, F] += dU^T SX, bias += column sums of dU
+        if ((rc = tn_gemm(BF(BL.DU), D, BF(BL.SX), F, M, G(g->struct_w), 1, BL, bws, st))) return rc;
+        if ((rc = colsum_into(BF(BL.DU), M, D, G(g->struct_b), 1, BL, bws, st))) return rc;
+    }
+    if (!bw) return EVI_OK;
+    // ---- backward: once per batch ----------------------------------------------------------------------------------
+    {
+        const EviRetrieverWeights* g = bw->g;
+        auto blocks_of = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+        // nodes: gather the per-edge gradients through the CSR, add the Wc path (HcN = node_repr Wc^T)
+        hipLaunchKernelGGL(k_node_gather_grad, dim3((unsigned)N), dim3(256), 0, st, I32(L.in_ptr), I32(L.in_eid), I32(L.out_ptr),
+                           I32(L.out_eid), BF(BL.DH), BF(BL.DT), D, BF(BL.DDF), H, BF(BL.dNR), BF(BL.dHcN));
+        EVI_LAUNCH_CHECK();
+        if ((rc = scorer_gemm(BF(BL.dHcN), N, H, H, BF(BL.WcT), D, H, nullptr, 0, BF(BL.tmpN), D, wsplit, st))) return rc;
+        hipLaunchKernelGGL(k_add_inplace, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), BF(BL.tmpN), N * D);
+        if ((rc = tn_gemm(BF(BL.dHcN), H, node_repr, D, N, BF(BL.gWc), 1, BL, bws, st))) return rc;
+        hipLaunchKernelGGL(k_merge_state0, dim3(H), dim3(256), 0, st, BF(BL.gWa), BF(BL.gWb), BF(BL.gWc), BF(BL.gwd), H, D,
+                           G(g->state0_w));
+        // the non-text embedding: its projection replaced every node row with embedding id 0
+        float* dnt = BF(BL.dnt);
+        hipLaunchKernelGGL(k_keep_zero_id_rows, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), b->node_embedding_ids, N, D, BF(BL.tmpN));
+        if ((rc = colsum_into(BF(BL.tmpN), N, D, dnt, 0, BL, bws, st))) return rc;
+        hipLaunchKernelGGL(k_act_bwd, blocks_of(D), dim3(256), 0, st, dnt, non_text, (int64_t)1, D, 1, (const int64_t*)nullptr);
+        EVI_LAUNCH_CHECK();
+        if ((rc = scorer_gemm(dnt, 1, D, D, BF(BL.WeT), D, D, nullptr, 0, G(g->non_text_emb), D, wsplit, st))) return rc;
+        // entity_proj: dpre = dNR (1 - NR^2), rows with id 0 dropped
+        hipLaunchKernelGGL(k_act_bwd, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), node_repr, N, D, 1, b->node_embedding_ids);
+        EVI_LAUNCH_CHECK();
+        if ((rc = tn_gemm(BF(BL.dNR), D, b->node_embeddings, D, N, G(g->entity_w), 0, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(dnt, D, w->non_text_emb, D, 1, G(g->entity_w), 1, BL, bws, st))) return rc;
+        if ((rc = colsum_into(BF(BL.dNR), N, D, G(g->entity_b), 0, BL, bws, st))) return rc;
+        hipLaunchKernelGGL(k_add_inplace, blocks_of(D), dim3(256), 0, st, G(g->entity_b), dnt, (int64_t)D);
+        // relation_proj
+        if (L.dedupe) {
+            const int64_t R = b->num_relations;
+            hipLaunchKernelGGL(k_segment_rowsum, dim3((unsigned)R, (unsigned)((D + 63) / 64)), dim3(256), 0, st, BF(BL.DRR), D, bw->rel_ptr, bw->rel_perm, BF(BL.dRRu));
+            hipLaunchKernelGGL(k_act_bwd, blocks_of(R * D), dim3(256), 0, st, BF(BL.dRRu), rel_repr, R, D, 1, (const int64_t*)nullptr);
+            EVI_LAUNCH_CHECK();
+            if ((rc = tn_gemm(BF(BL.dRRu), D, F32(L.rel_rows), D, R, G(g->relation_w), 0, BL, bws, st))) return rc;
+            if ((rc = colsum_into(BF(BL.dRRu), R, D, G(g->relation_b), 0, BL, bws, st))) return rc;
+        } else {
+            hipLaunchKernelGGL(k_act_bwd, blocks_of(E * D), dim3(256), 0, st, BF(BL.DRR), rel_repr, E, D, 1, (const int64_t*)nullptr);
+            EVI_LAUNCH_CHECK();
+            if ((rc = tn_gemm(BF(BL.DRR), D, b->edge_embeddings, D, E, G(g->relation_w), 0, BL, bws, st))) return rc;
+            if ((rc = colsum_into(BF(BL.DRR), E, D, G(g->relation_b), 0, BL, bws, st))) return rc;
+        }
+        // question side: gate (sigmoid) and bias (tanh) of the projected question, then query_proj (tanh)
+        hipLaunchKernelGGL(k_segment_rowsum, dim3(B, (unsigned)((D + 63) / 64)), dim3(256), 0, st, BF(BL.DGQ), D, b->edge_ptr, (const int64_t*)nullptr, BF(BL.dGQ));
+        hipLaunchKernelGGL(k_segment_rowsum, dim3(B, (unsigned)((D + 63) / 64)), dim3(256), 0, st, BF(BL.DBQ), D, b->edge_ptr, (const int64_t*)nullptr, BF(BL.dBQ));
+        hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, BF(BL.dGQ), gate_q, (int64_t)B, D, 2, (const int64_t*)nullptr);
+        hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, BF(BL.dBQ), bias_q, (int64_t)B, D, 1, (const int64_t*)nullptr);
+        EVI_LAUNCH_CHECK();
+        if ((rc = tn_gemm(BF(BL.dGQ), D, q_proj, D, B, G(g->q_gate_w), 0, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(BF(BL.dBQ), D, q_proj, D, B, G(g->q_bias_w), 0, BL, bws, st))) return rc;
+        if ((rc = colsum_into(BF(BL.dGQ), B, D, G(g->q_gate_b), 0, BL, bws, st))) return rc;
+        if ((rc = colsum_into(BF(BL.dBQ), B, D, G(g->q_bias_b), 0, BL, bws, st))) return rc;
+        float* dQP = BF(BL.dQP);
+        float* dQP2 = dQP + (int64_t)B * D;
+        if ((rc = scorer_gemm(BF(BL.dGQ), B, D, D, BF(BL.WgT), D, D, nullptr, 0, dQP, D, wsplit, st))) return rc;
+        if ((rc = scorer_gemm(BF(BL.dBQ), B, D, D, BF(BL.WbqT), D, D, nullptr, 0, dQP2, D, wsplit, st))) return rc;
+        hipLaunchKernelGGL(k_add_inplace, blocks_of((int64_t)B * D), dim3(256), 0, st, dQP, dQP2, (int64_t)B * D);
+        hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, dQP, q_proj, (int64_t)B, D, 1, (const int64_t*)nullptr);
+        EVI_LAUNCH_CHECK();
+        if ((rc = tn_gemm(dQP, D, b->question_emb, D, B, G(g->query_w), 0, BL, bws, st))) return rc;
+        if ((rc = colsum_into(dQP, B, D, G(g->query_b), 0, BL, bws, st))) return rc;
+        // the head
+        hipLaunchKernelGGL(k_head_grads, dim3(H), dim3(256), 0, st, w->state4_w, w->state4_b, w->score_w, BF(BL.ysum), BF(BL.ssum), H,
+                           G(g->state4_w), G(g->state4_b), G(g->score_w), G(g->score_b));
+        EVI_LAUNCH_CHECK();
     }
     return EVI_OK;
+}
+
+extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
+                                     const EviRetrieverOutput* out, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return retriever_run(w, b, direction_mode, out, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
+                                                         int dde_reverse_rounds, int64_t num_relations) {
+    if (N < 0 || E < 0 || B < 1 || D < 1 || H < 1) return 0;
+    const int F = 2 * 2 * (1 + dde_rounds + dde_reverse_rounds);
+    const FwdLayout L = fwd_layout(N, E, B, D, H, F, num_relations, 2);
+    return align_up(L.total, 256) + bwd_layout(N, E, B, D, H, F, L.dedupe ? num_relations : 0, L.ec).total + align_up((size_t)(E > 0 ? E : 1) * 3 * 4, 256);
+}
+
+extern "C" int evi_retriever_backward(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
+                                      const float* dlogits, const EviRetrieverWeights* grads, const int64_t* rel_perm,
+                                      const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, void* stream) {
+    EVI_REQUIRE(w && b && grads && dlogits, "evi_retriever_backward: null pointer");
+    EVI_REQUIRE(!w->prepared, "evi_retriever_backward: pass the weights without a prepared buffer (training changes them every step)");
+    const int64_t N = b->num_nodes, E = b->num_edges;
+    const int D = w->emb_dim, H = w->hidden_dim;
+    EVI_REQUIRE(b->num_graphs >= 1 && D >= 1 && H >= 1, "evi_retriever_backward: bad sizes");
+    if (E == 0) return EVI_OK;
+    const int F = 2 * 2 * (1 + w->dde_rounds + w->dde_reverse_rounds);
+    const FwdLayout L = fwd_layout(N, E, b->num_graphs, D, H, F, b->num_relations, 2);
+    EVI_REQUIRE(!L.dedupe || (rel_perm && rel_ptr), "evi_retriever_backward: rel_perm / rel_ptr are required when num_relations is given");
+    const size_t need = evi_retriever_backward_workspace_bytes(N, E, b->num_graphs, D, H, w->dde_rounds, w->dde_reverse_rounds, b->num_relations);
+    EVI_REQUIRE(workspace, "evi_retriever_backward: null workspace");
+    if (workspace_bytes < need) return fail(EVI_ERR_NOMEM, "evi_retriever_backward: workspace %zu B < %zu B", workspace_bytes, need);
+    char* base = static_cast<char*>(workspace);
+    const size_t fwd_bytes = align_up(L.total, 256);
+    const BwdLayout BL = bwd_layout(N, E, b->num_graphs, D, H, F, L.dedupe ? b->num_relations : 0, L.ec);
+    float* scratch_logits = reinterpret_cast<float*>(base + fwd_bytes + BL.total);  // the recomputed logits (3 x [E])
+    EviRetrieverOutput o{};
+    o.logits = scratch_logits;
+    o.logits_fwd = scratch_logits + E;
+    o.logits_bwd = scratch_logits + 2 * E;
+    BwdCtx ctx{dlogits, grads, rel_perm, rel_ptr, base + fwd_bytes};
+    return retriever_run(w, b, direction_mode, &o, base, fwd_bytes, stream, &ctx);
 }

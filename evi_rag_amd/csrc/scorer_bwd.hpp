@@ -1,0 +1,615 @@
+// Backward of the edge scorer: gradients of a scalar loss with respect to every Retriever parameter, given
+// dL/dlogits — the autograd of src/models/components/retriever.py:195-289, 403-507 in eval-mode arithmetic (dropout and the
+// hide-and-seek bias are the identity / absent, as in the forward this library implements).  Included by scorer.hip (it
+// needs the forward's device helpers and argument structs); everything is inside namespace evi.
+//
+// Structure.  The forward is RECOMPUTED chunk by chunk (no tensors are kept from the forward call), then per chunk:
+//   k_combine_bwd        logits -> pre-LayerNorm state rows:  dz_dir [2 Ec, H], and what the factored state_net.0 needs
+//                        (dPA = nav_f dz_f + nav_b dz_b, dRC = dz_f + dz_b, dDiff = dz_f - dz_b, dnav, d(-dist)), plus the
+//                        column sums behind d state_net.1.{weight,bias}, d wd, d state_net.0.bias and the folded head
+//   three NT GEMMs       dP = dPA Wa, dRCX = dRC Wc, dXS = dz Wb        (weights transposed once: [D, H] row-major)
+//   k_edge_features_bwd  -> per-edge dh, dt, d rel_repr row, d gate_q / d bias_q contributions, d struct pre-activation rows
+//   TN products          dWa += dPA^T P, dWc += dRC^T RCX, dWb += dz^T XS, dWs += dU^T struct   (tn_gemm: explicit
+//                        transposes + split-K NT GEMMs + an ordered reduction — correct first, not yet fast)
+// and once per batch: node / relation / graph segment sums (f64, CSR- or sort-ordered: no float atomics), the tanh / sigmoid
+// backward of the projections and their TN products.  All reductions run in a fixed order for a given batch shape.
+//
+// state_net.4 and score_head need no GEMM: with the folded head, d score_w = W2 ysum + b2 S, d score_b = S,
+// d W2 = w (x) ysum, d b2 = w S, where ysum = sum_{e,dir} dlg_dir y_dir and S = sum dlg_dir.
+#pragma once
+
+namespace evi {
+
+__device__ inline float gelu_erf_grad(float x) {
+    // d/dx [0.5 x (1 + erf(x / sqrt2))] = 0.5 (1 + erf(x / sqrt2)) + x phi(x)
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
+    return fmaf(x, 0.3989422804014327f * __expf(-0.5f * x * x), cdf);
+}
+
+// ---- generic pieces ---------------------------------------------------------------------------------
+__global__ void k_zero_f32(float* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// dst[c][r] = src[r][c] for r < R, c < C; dst rows are Rp long, columns R..Rp-1 zero.  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__ src, int64_t R, int C, int64_t ld_src,
+                                                       float* __restrict__ dst, int64_t Rp) {
+    __shared__ float tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t r = r0 + i;
+        const int c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const int64_t r = r0 + tx;
+        if (c < C && r < Rp) dst[(int64_t)c * Rp + r] = tile[tx][i];
+    }
+}
+
+// out[i] (+)= sum_s part[s * len + i], s ascending
+__global__ void k_reduce_partials(const float* __restrict__ part, int S, int64_t len, float* __restrict__ out, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float acc = accumulate ? out[i] : 0.f;
+    for (int s = 0; s < S; ++s) acc += part[(int64_t)s * len + i];
+    out[i] = acc;
+}
+
+// out[s][:] = sum over rows p in [ptr[s], ptr[s+1]) of X[perm ? perm[p] : p][:]   (f64 accumulation in a fixed order).
+// Block = (segment, 64 columns); its four waves take every fourth row and their partial sums are added in wave order.
+__global__ __launch_bounds__(256) void k_segment_rowsum(const float* __restrict__ X, int D, const int64_t* __restrict__ ptr,
+                                                        const int64_t* __restrict__ perm, float* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int64_t s = blockIdx.x;
+    const int d = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    const int64_t b = ptr[s], e = ptr[s + 1];
+    double acc = 0.0;
+    if (d < D)
+        for (int64_t p = b + grp; p < e; p += 4) acc += (double)X[(perm ? perm[p] : p) * D + d];
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && d < D) out[s * D + d] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+// node gradients through the CSR: dNR[v] = sum_{out edges} DH[e] + sum_{in edges} DT[e]   (v is head / tail of e),
+// dHcN[v] = sum_{out} DDF[e] - sum_{in} DDF[e].  One workgroup per node, f64 sums in CSR row order.
+__global__ __launch_bounds__(256) void k_node_gather_grad(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_eid,
+                                                          const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_eid,
+                                                          const float* __restrict__ DH, const float* __restrict__ DT, int D,
+                                                          const float* __restrict__ DDF, int H, float* __restrict__ dNR,
+                                                          float* __restrict__ dHcN) {
+    const int64_t v = blockIdx.x;
+    const int ob = out_ptr[v], oe = out_ptr[v + 1], ib = in_ptr[v], ie = in_ptr[v + 1];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        double acc = 0.0;
+        for (int p = ob; p < oe; ++p) acc += (double)DH[(int64_t)out_eid[p] * D + d];
+        for (int p = ib; p < ie; ++p) acc += (double)DT[(int64_t)in_eid[p] * D + d];
+        dNR[v * D + d] = (float)acc;
+    }
+    for (int d = threadIdx.x; d < H; d += blockDim.x) {
+        double acc = 0.0;
+        for (int p = ob; p < oe; ++p) acc += (double)DDF[(int64_t)out_eid[p] * H + d];
+        for (int p = ib; p < ie; ++p) acc -= (double)DDF[(int64_t)in_eid[p] * H + d];
+        dHcN[v * H + d] = (float)acc;
+    }
+}
+
+// dpre = dY * f'(pre) written in place of dY, from the activation's OUTPUT y: tanh: 1 - y^2, sigmoid: y (1 - y).
+// skip_ids != null: rows whose id is 0 get dpre = 0 (their output was overwritten by the non-text embedding).
+__global__ void k_act_bwd(float* __restrict__ dY, const float* __restrict__ Y, int64_t rows, int cols, int act,
+                          const int64_t* __restrict__ skip_ids) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const float y = Y[i];
+    float g = dY[i] * (act == 1 ? 1.0f - y * y : y * (1.0f - y));
+    if (skip_ids && skip_ids[r] == 0) g = 0.f;
+    dY[i] = g;
+}
+
+// dst = src where ids[row] == 0, else 0: the rows whose projection was replaced by the non-text embedding (their column sum
+// is that embedding's gradient)
+__global__ void k_keep_zero_id_rows(const float* __restrict__ src, const int64_t* __restrict__ ids, int64_t N, int D,
+                                    float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    dst[i] = ids[i / D] == 0 ? src[i] : 0.f;
+}
+
+// column sums of X [rows, cols] into out[cols] (+)=, two ordered stages: partial per block of 1024 rows, then the blocks
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t rows, int cols, float* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * 1024;
+    const int64_t r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float acc = 0.f;
+        for (int64_t r = r0; r < r1; ++r) acc += X[r * cols + c];
+        part[(int64_t)blockIdx.x * cols + c] = acc;
+    }
+}
+
+// ---- the head: state_net.4 and score_head from ysum [H] and S ---------------------------------------------
+__global__ void k_head_grads(const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ score_w,
+                             const float* __restrict__ ysum, const float* __restrict__ ssum, int H, float* __restrict__ dW2,
+                             float* __restrict__ db2, float* __restrict__ dscore_w, float* __restrict__ dscore_b) {
+    const int i = blockIdx.x;  // output row of W2
+    const float S = ssum[0];
+    const float wi = score_w[i];
+    float dot = 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        dW2[(int64_t)i * H + j] = wi * ysum[j];
+        dot = fmaf(W2[(int64_t)i * H + j], ysum[j], dot);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = dot;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dscore_w[i] = red[0] + b2[i] * S;
+        db2[i] = wi * S;
+        if (i == 0) dscore_b[0] = S;
+    }
+}
+
+// ---- logits -> state rows -----------------------------------------------------------------------------
+struct CombineBwdArgs {
+    CombineArgs f;          // the forward's arguments for this chunk (h1c unused)
+    const float* dlogits;   // [E]
+    float* DZ;              // [dirs * e_count, H]
+    float* DPA;             // [e_count, H]
+    float* DRC;             // [e_count, H]
+    float* DDF;             // [E, H] (global rows): dz_f - dz_b
+    float* daux;            // [dirs * e_count, 2]: (dnav, d(-dist))
+    float* part;            // [gridDim.x][5][H] column partials: d ln_w, d ln_b, ysum, d wd, d state0_b; then [gridDim.x] S partials
+};
+
+template <int C4>
+__global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
+    const CombineArgs& a = b.f;
+    __shared__ float red[4][5 * 1280 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = a.H;
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f4 c_lnw[C4], c_lnb[C4], c_ys[C4], c_wd[C4], c_b1[C4];
+#pragma unroll
+    for (int i = 0; i < C4; ++i) c_lnw[i] = c_lnb[i] = c_ys[i] = c_wd[i] = c_b1[i] = z4;
+    float c_S = 0.f;
+    f4 wdv[C4], lnw[C4], lnb[C4], vh[C4];
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int d = 4 * lane + 256 * i;
+        if (d < H) {
+            wdv[i] = ld4(a.wd + d);
+            lnw[i] = ld4(a.ln_w + d);
+            lnb[i] = ld4(a.ln_b + d);
+            vh[i] = ld4(a.v + d);
+        } else {
+            wdv[i] = lnw[i] = lnb[i] = vh[i] = z4;
+        }
+    }
+    const float invH = 1.0f / (float)H;
+    for (int64_t le = (int64_t)blockIdx.x * 4 + wave; le < a.e_count; le += (int64_t)gridDim.x * 4) {
+        const int64_t e = a.e_begin + le;
+        const float* pa = a.PA + le * H;
+        const float* rc = a.RC + le * H;
+        const float* hh = a.HcN + a.edge_index[e] * H;
+        const float* ht = a.HcN + a.edge_index[a.E + e] * H;
+        f4 base[C4], diff[C4], pav[C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < H) {
+                pav[i] = ld4(pa + d);
+                base[i] = ld4(rc + d);
+                diff[i] = ld4(hh + d) - ld4(ht + d);
+            } else {
+                pav[i] = base[i] = diff[i] = z4;
+            }
+        }
+        f4 zh[2][C4], av[2][C4];  // normalised pre-activation and the affine LayerNorm output per direction
+        float rstd[2] = {0.f, 0.f}, lg[2] = {0.f, 0.f}, navv[2] = {0.f, 0.f}, ndv[2] = {0.f, 0.f};
+        int out_row = 0;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+#pragma unroll
+            for (int i = 0; i < C4; ++i) zh[dir][i] = av[dir][i] = z4;
+            if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
+            const int64_t row = (int64_t)out_row * a.e_count + le;
+            const float nav = a.aux[row * 2], negdist = a.aux[row * 2 + 1];
+            navv[dir] = nav;
+            ndv[dir] = negdist;
+            const float* sb = a.SB + row * H;
+            f4 v[C4];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < H) {
+                    f4 x = nav * pav[i] + ld4(sb + d);
+                    x += dir == 0 ? diff[i] : -diff[i];
+                    x += base[i];
+                    x += wdv[i] * negdist;
+                    v[i] = x;
+                    sum += hsum4(x);
+                } else {
+                    v[i] = z4;
+                }
+            }
+            const float mean = wsum(sum) * invH;
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i)
+                if (4 * lane + 256 * i < H) {
+                    const f4 c = v[i] - mean;
+                    var += hsum4(c * c);
+                }
+            rstd[dir] = 1.0f / sqrtf(wsum(var) * invH + kLnEps);
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < H) {
+                    zh[dir][i] = (v[i] - mean) * rstd[dir];
+                    av[dir][i] = zh[dir][i] * lnw[i] + lnb[i];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dot = fmaf(vh[i][c], gelu_erf(av[dir][i][c]), dot);
+                }
+            }
+            lg[dir] = wsum(dot) + a.v[H];
+            ++out_row;
+        }
+        const float eb = a.edge_bias ? a.edge_bias[e] : 0.f;
+        const float lf = lg[0] + eb, lb = lg[1] + eb;
+        float wf = 1.f, wb = 0.f, logit = lf;
+        if (a.dir_fwd && a.dir_bwd) {
+            const float m = fmaxf(lf, lb);
+            const float ef = expf(lf - m), ebk = expf(lb - m);
+            wf = ef / (ef + ebk);
+            wb = ebk / (ef + ebk);
+            logit = wf * lf + wb * lb;
+        } else if (a.dir_bwd) {
+            wf = 0.f;
+            wb = 1.f;
+            logit = lb;
+        }
+        const float gl = b.dlogits[e];
+        // logit = sum_i w_i l_i with w = softmax(l):  d logit / d l_i = w_i (1 + l_i - logit)
+        float dlg[2];
+        dlg[0] = a.dir_fwd ? gl * wf * ((a.dir_fwd && a.dir_bwd) ? 1.0f + lf - logit : 1.0f) : 0.f;
+        dlg[1] = a.dir_bwd ? gl * wb * ((a.dir_fwd && a.dir_bwd) ? 1.0f + lb - logit : 1.0f) : 0.f;
+        c_S += dlg[0] + dlg[1];
+        f4 dzv[2][C4];
+        out_row = 0;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+#pragma unroll
+            for (int i = 0; i < C4; ++i) dzv[dir][i] = z4;
+            if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
+            const int64_t row = (int64_t)out_row * a.e_count + le;
+            f4 g[C4];
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                g[i] = z4;
+                if (d < H) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float y = gelu_erf(av[dir][i][c]);
+                        const float da = dlg[dir] * vh[i][c] * gelu_erf_grad(av[dir][i][c]);
+                        c_ys[i][c] = fmaf(dlg[dir], y, c_ys[i][c]);
+                        c_lnw[i][c] = fmaf(da, zh[dir][i][c], c_lnw[i][c]);
+                        c_lnb[i][c] += da;
+                        g[i][c] = da * lnw[i][c];
+                    }
+                    m1 += hsum4(g[i]);
+                    m2 += hsum4(g[i] * zh[dir][i]);
+                }
+            }
+            m1 = wsum(m1) * invH;
+            m2 = wsum(m2) * invH;
+            float dnav = 0.f, dnd = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < H) {
+                    const f4 dz = rstd[dir] * (g[i] - m1 - zh[dir][i] * m2);
+                    dzv[dir][i] = dz;
+                    st4(b.DZ + row * H + d, dz);
+                    dnav += hsum4(dz * pav[i]);
+                    dnd += hsum4(dz * wdv[i]);
+                    c_wd[i] += dz * ndv[dir];
+                    c_b1[i] += dz;
+                }
+            }
+            dnav = wsum(dnav);
+            dnd = wsum(dnd);
+            if (lane == 0) {
+                b.daux[row * 2] = dnav;
+                b.daux[row * 2 + 1] = dnd;
+            }
+            ++out_row;
+        }
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < H) {
+                st4(b.DPA + le * H + d, navv[0] * dzv[0][i] + navv[1] * dzv[1][i]);
+                st4(b.DRC + le * H + d, dzv[0][i] + dzv[1][i]);
+                st4(b.DDF + e * H + d, dzv[0][i] - dzv[1][i]);
+            }
+        }
+    }
+    // the four waves' column sums, added in wave order; one partial row set per workgroup
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int d = 4 * lane + 256 * i;
+        if (d < H) {
+            st4(&red[wave][0 * 1280 + d], c_lnw[i]);
+            st4(&red[wave][1 * 1280 + d], c_lnb[i]);
+            st4(&red[wave][2 * 1280 + d], c_ys[i]);
+            st4(&red[wave][3 * 1280 + d], c_wd[i]);
+            st4(&red[wave][4 * 1280 + d], c_b1[i]);
+        }
+    }
+    if (lane == 0) red[wave][5 * 1280] = c_S;  // wave-uniform: every lane holds the same sum
+    __syncthreads();
+    float* prow = b.part + (int64_t)blockIdx.x * 5 * H;
+    for (int k = threadIdx.x; k < 5 * H; k += blockDim.x) {
+        const int which = k / H, d = k - which * H;
+        prow[k] = ((red[0][which * 1280 + d] + red[1][which * 1280 + d]) + red[2][which * 1280 + d]) + red[3][which * 1280 + d];
+    }
+    if (threadIdx.x == 0)
+        b.part[(int64_t)gridDim.x * 5 * H + blockIdx.x] = ((red[0][5 * 1280] + red[1][5 * 1280]) + red[2][5 * 1280]) + red[3][5 * 1280];
+}
+
+// ---- state-row inputs -> per-edge gradients ------------------------------------------------------------------
+struct EdgeBwdArgs {
+    EdgeFeatArgs f;       // the forward's arguments for this chunk (P / RCX / XS / aux are read, not written)
+    const float* dP;      // [e_count, D]
+    const float* dRCX;    // [e_count, D]
+    const float* dXS;     // [dirs * e_count, D]
+    const float* daux;    // [dirs * e_count, 2]
+    float* DH;            // [E, D] (global rows)
+    float* DT;            // [E, D]
+    float* DRR;           // [E, D]  d rel_repr row of the edge  (drc * gate_q)
+    float* DGQ;           // [E, D]  drc * rel_repr row
+    float* DBQ;           // [E, D]  drc
+    float* DU;            // [dirs * e_count, D]  d (struct_proj.0 output)
+    float* SX;            // [dirs * e_count, F]  struct_proj.0 input rows
+    float* part;          // [gridDim.x][3][D]: d struct_ln_w, d struct_ln_b, d struct_gate_w; then [gridDim.x] d struct_gate_b
+};
+
+template <int C4>
+__global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
+    const EdgeFeatArgs& a = b.f;
+    extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D], then the waves' column partials [16][3][D]
+    const int D = a.D, F = a.F;
+    for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds_wt[i] = a.struct_wt[i];
+    float* l_b = lds_wt + F * D;
+    float* l_lw = l_b + D;
+    float* l_lb = l_lw + D;
+    float* l_gw = l_lb + D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        l_b[i] = a.struct_b[i];
+        l_lw[i] = a.struct_ln_w[i];
+        l_lb[i] = a.struct_ln_b[i];
+        l_gw[i] = a.struct_gate_w[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const float gate_b = a.struct_gate_b[0];
+    const int half = F >> 1;
+    const float inv_d = 1.0f / (float)D;
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f4 c_lw[C4], c_lb[C4], c_gw[C4];
+#pragma unroll
+    for (int i = 0; i < C4; ++i) c_lw[i] = c_lb[i] = c_gw[i] = z4;
+    float c_gb = 0.f;
+
+    for (int64_t le = (int64_t)blockIdx.x * waves + wave; le < a.e_count; le += (int64_t)gridDim.x * waves) {
+        const int64_t e = a.e_begin + le;
+        const int64_t hv = __builtin_amdgcn_readfirstlane((int)a.edge_index[e]);
+        const int64_t tv = __builtin_amdgcn_readfirstlane((int)a.edge_index[a.E + e]);
+        const int64_t g = __builtin_amdgcn_readfirstlane((int)a.edge_batch[e]);
+        int64_t rrow = a.rel_by_edge ? e : (int64_t)__builtin_amdgcn_readfirstlane((int)a.edge_attr[e]);
+        if (!a.rel_by_edge) rrow = rrow < 0 ? 0 : (rrow >= a.R ? a.R - 1 : rrow);
+        const float* hp = a.node_repr + hv * D;
+        const float* tp = a.node_repr + tv * D;
+        const float* rp = a.rel_repr + rrow * D;
+        const float* gp = a.gate_q + g * D;
+        const float* bp = a.bias_q + g * D;
+        f4 h[C4], t[C4], rr[C4], gq[C4], rc[C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < D) {
+                h[i] = ld4(hp + d);
+                t[i] = ld4(tp + d);
+                rr[i] = ld4(rp + d);
+                gq[i] = ld4(gp + d);
+                rc[i] = rr[i] * gq[i] + ld4(bp + d);
+            } else {
+                h[i] = t[i] = rr[i] = gq[i] = rc[i] = z4;
+            }
+        }
+        const float* nsh = a.node_struct + hv * half;
+        const float* nst = a.node_struct + tv * half;
+        f4 s2[2][C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            s2[0][i] = s2[1][i] = d < D ? ld4(l_b + d) : z4;
+        }
+        for (int j = 0; j < half; ++j) {
+            const float xh = nsh[j], xt = nst[j];
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < D) {
+                    const f4 w1 = ld4(lds_wt + j * D + d), w2 = ld4(lds_wt + (half + j) * D + d);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s2[0][i][c] = fmaf(w2[c], xt, fmaf(w1[c], xh, s2[0][i][c]));
+                        s2[1][i][c] = fmaf(w2[c], xh, fmaf(w1[c], xt, s2[1][i][c]));
+                    }
+                }
+            }
+        }
+        f4 dh[C4], dt[C4], drc[C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < D) {
+                const f4 dp = ld4(b.dP + le * D + d);
+                dh[i] = dp * rc[i] * t[i];
+                dt[i] = dp * h[i] * rc[i];
+                drc[i] = dp * h[i] * t[i] + ld4(b.dRCX + le * D + d);
+            } else {
+                dh[i] = dt[i] = drc[i] = z4;
+            }
+        }
+        int out_row = 0;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
+            const int64_t row = (int64_t)out_row * a.e_count + le;
+            // recompute LayerNorm + GELU of the struct MLP
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) sum += (4 * lane + 256 * i < D) ? hsum4(s2[dir][i]) : 0.f;
+            const float mean = wsum(sum) * inv_d;
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i)
+                if (4 * lane + 256 * i < D) {
+                    const f4 c = s2[dir][i] - mean;
+                    var += hsum4(c * c);
+                }
+            const float rstd = 1.0f / sqrtf(wsum(var) * inv_d + kLnEps);
+            f4 uh[C4], av[C4], sv[C4];
+            float gacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                uh[i] = av[i] = sv[i] = z4;
+                if (d < D) {
+                    const f4 lw = ld4(l_lw + d), lb = ld4(l_lb + d), gw = ld4(l_gw + d);
+                    uh[i] = (s2[dir][i] - mean) * rstd;
+                    av[i] = uh[i] * lw + lb;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sv[i][c] = gelu_erf(av[i][c]);
+                        gacc = fmaf(gw[c], sv[i][c], gacc);
+                    }
+                }
+            }
+            const float nav = sigmoidf_(wsum(gacc) + gate_b);
+            // translation error and its norm
+            float dsq = 0.f;
+            f4 err[C4];
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                err[i] = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
+                if (4 * lane + 256 * i < D) dsq += hsum4(err[i] * err[i]);
+            }
+            const float nrm = sqrtf(wsum(dsq));
+            const float dnav = b.daux[row * 2], dnd = b.daux[row * 2 + 1];
+            // -dist = -||err||:  d err = dnd * (-err / ||err||)   (0 at err == 0, like torch.norm's subgradient)
+            const float kerr = nrm > 0.f ? -dnd / nrm : 0.f;
+            const float dpre = dnav * nav * (1.0f - nav);
+            c_gb += dpre;  // same value on every lane: counted once below
+            f4 gg[C4];
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                gg[i] = z4;
+                if (d < D) {
+                    const f4 de = kerr * err[i];
+                    if (dir == 0) {
+                        dh[i] += de;
+                        dt[i] -= de;
+                    } else {
+                        dt[i] += de;
+                        dh[i] -= de;
+                    }
+                    drc[i] += de;
+                    const f4 lw = ld4(l_lw + d), gw = ld4(l_gw + d);
+                    const f4 ds = ld4(b.dXS + row * D + d) + dpre * gw;
+                    c_gw[i] += dpre * sv[i];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float da = ds[c] * gelu_erf_grad(av[i][c]);
+                        c_lw[i][c] = fmaf(da, uh[i][c], c_lw[i][c]);
+                        c_lb[i][c] += da;
+                        gg[i][c] = da * lw[c];
+                    }
+                    m1 += hsum4(gg[i]);
+                    m2 += hsum4(gg[i] * uh[i]);
+                }
+            }
+            m1 = wsum(m1) * inv_d;
+            m2 = wsum(m2) * inv_d;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < D) st4(b.DU + row * D + d, rstd * (gg[i] - m1 - uh[i] * m2));
+            }
+            // the struct MLP's input row (wave-uniform values): [ns[a] | ns[b]] with (a, b) = (head, tail) / (tail, head)
+            if (lane < F) {
+                const int j = lane < half ? lane : lane - half;
+                const bool first = lane < half;
+                b.SX[row * F + lane] = (first == (dir == 0)) ? nsh[j] : nst[j];
+            }
+            ++out_row;
+        }
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < D) {
+                st4(b.DH + e * D + d, dh[i]);
+                st4(b.DT + e * D + d, dt[i]);
+                st4(b.DRR + e * D + d, drc[i] * gq[i]);
+                st4(b.DGQ + e * D + d, drc[i] * rr[i]);
+                st4(b.DBQ + e * D + d, drc[i]);
+            }
+        }
+    }
+    // column partials: the waves' sums added in wave order
+    float* red = lds_wt + (F + 4) * D;  // [waves][3][D] + [waves]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < C4; ++i) {
+        const int d = 4 * lane + 256 * i;
+        if (d < D) {
+            st4(red + ((int64_t)wave * 3 + 0) * D + d, c_lw[i]);
+            st4(red + ((int64_t)wave * 3 + 1) * D + d, c_lb[i]);
+            st4(red + ((int64_t)wave * 3 + 2) * D + d, c_gw[i]);
+        }
+    }
+    if (lane == 0) red[(int64_t)waves * 3 * D + wave] = c_gb;
+    __syncthreads();
+    float* prow = b.part + (int64_t)blockIdx.x * 3 * D;
+    for (int k = threadIdx.x; k < 3 * D; k += blockDim.x) {
+        const int which = k / D, d = k - which * D;
+        float acc = 0.f;
+        for (int w = 0; w < waves; ++w) acc += red[((int64_t)w * 3 + which) * D + d];
+        prow[k] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int w = 0; w < waves; ++w) acc += red[(int64_t)waves * 3 * D + w];
+        b.part[(int64_t)gridDim.x * 3 * D + blockIdx.x] = acc;
+    }
+}
+
+}  // namespace evi

@@ -131,6 +131,9 @@ class Retriever(nn.Module):
         # (logits-only evaluation, e.g. predict_step drops edge_embeddings anyway: retriever_module.py:277-285)
         self.emit_edge_embeddings = bool(emit_edge_embeddings)
         self.cache_prepared_weights = True  # eval mode: keep the weight-derived pieces of the forward across calls
+        # None: the forward is a differentiable autograd node in train() mode only (evaluation never builds a graph, whatever
+        # torch.is_grad_enabled() says); True / False force it — True gives eval-mode gradients (the parity tests use that)
+        self.differentiable: Optional[bool] = None
         self.emb_dim = int(emb_dim)
         self.hidden_dim = int(hidden_dim)
         self.use_topic_pe = bool(topic_pe)
@@ -231,6 +234,101 @@ class Retriever(nn.Module):
         self._prep_cache = (key, buf)
         return buf
 
+    def _param_fields(self):
+        """(EviRetrieverWeights field, parameter) in the struct's order — also the order of the autograd inputs."""
+        out = []
+        for name, mod in (("entity", self.entity_proj), ("relation", self.relation_proj), ("query", self.query_proj)):
+            out += [(f"{name}_w", mod.network[0].weight), (f"{name}_b", mod.network[0].bias)]
+        out += [("non_text_emb", self.non_text_entity_emb.weight),
+                ("q_gate_w", self.q_gate[0].weight), ("q_gate_b", self.q_gate[0].bias),
+                ("q_bias_w", self.q_bias[0].weight), ("q_bias_b", self.q_bias[0].bias),
+                ("struct_w", self.struct_proj[0].weight), ("struct_b", self.struct_proj[0].bias),
+                ("struct_ln_w", self.struct_proj[1].weight), ("struct_ln_b", self.struct_proj[1].bias),
+                ("struct_gate_w", self.struct_gate_net[0].weight), ("struct_gate_b", self.struct_gate_net[0].bias),
+                ("state0_w", self.state_net[0].weight), ("state0_b", self.state_net[0].bias),
+                ("state_ln_w", self.state_net[1].weight), ("state_ln_b", self.state_net[1].bias),
+                ("state4_w", self.state_net[4].weight), ("state4_b", self.state_net[4].bias),
+                ("score_w", self.score_head.weight), ("score_b", self.score_head.bias)]
+        return out
+
+    def _batch_struct(self, pack) -> "_lib.EviRetrieverBatch":
+        b = _lib.EviRetrieverBatch()
+        b.num_nodes, b.num_edges, b.num_graphs = pack["N"], pack["E"], pack["B"]
+        b.edge_index, b.node_ptr = pack["edge_index"].data_ptr(), pack["node_ptr"].data_ptr()
+        b.edge_ptr, b.edge_batch = pack["edge_ptr"].data_ptr(), pack["edge_batch"].data_ptr()
+        b.question_emb, b.node_embeddings = pack["question_emb"].data_ptr(), pack["node_embeddings"].data_ptr()
+        b.node_embedding_ids, b.edge_embeddings = pack["node_embedding_ids"].data_ptr(), pack["edge_embeddings"].data_ptr()
+        b.edge_attr, b.num_relations = pack["edge_attr"].data_ptr(), pack["num_relations"]
+        b.topic_one_hot, b.topic_stride = pack["topic_one_hot"].data_ptr(), int(pack["topic_one_hot"].size(1))
+        b.edge_bias = pack["edge_bias"].data_ptr() if pack["edge_bias"] is not None else None
+        return b
+
+    def _launch_forward(self, pack):
+        """One evi_retriever_forward call: (logits, logits_fwd, logits_bwd, features-or-None), device tensors."""
+        lib = _lib.load()
+        dev, E, N, B = pack["dev"], pack["E"], pack["N"], pack["B"]
+        D, H = self.emb_dim, self.hidden_dim
+        logits = torch.empty(E, dtype=torch.float32, device=dev)
+        both = self.direction_mode == "bidirectional"
+        logits_fwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "backward" else None
+        logits_bwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "forward" else None
+        features = torch.empty((E, H), dtype=torch.float32, device=dev) if pack["want_features"] else None
+        w = self._weights_struct()
+        prep = self._prepared_weights(w, dev)
+        w.prepared = prep.data_ptr() if prep is not None else None
+        b = self._batch_struct(pack)
+        o = _lib.EviRetrieverOutput()
+        o.logits = logits.data_ptr()
+        o.logits_fwd = logits_fwd.data_ptr() if logits_fwd is not None else None
+        o.logits_bwd = logits_bwd.data_ptr() if logits_bwd is not None else None
+        o.edge_features = features.data_ptr() if features is not None else None
+        o.node_struct = None
+        # sticky flag for relation ids outside the stated num_relations (no read-back here: check_deferred())
+        st = getattr(self, "_deferred_status", None)
+        if st is None or st.device != dev:
+            st = self._deferred_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        o.status = st.data_ptr()
+        need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,
+                                                             self.dde.num_reverse_rounds, pack["num_relations"]))
+        ws = ops._workspace(dev, "retriever_forward", need)
+        _lib.check(lib.evi_retriever_forward(ctypes.byref(w), ctypes.byref(b), _DIRECTION_CODE[self.direction_mode],
+                                             ctypes.byref(o), ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream(dev).cuda_stream))
+        if not both:
+            pass
+        return logits, logits_fwd, logits_bwd, features
+
+    def _launch_backward(self, pack, dlogits: torch.Tensor):
+        """evi_retriever_backward: the gradient tensors of every parameter, in `_param_fields()` order."""
+        lib = _lib.load()
+        dev, E, N, B = pack["dev"], pack["E"], pack["N"], pack["B"]
+        D, H = self.emb_dim, self.hidden_dim
+        fields = self._param_fields()
+        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for _, p in fields]
+        w = self._weights_struct()
+        g = _lib.EviRetrieverWeights()
+        g.emb_dim, g.hidden_dim, g.num_topics = w.emb_dim, w.hidden_dim, w.num_topics
+        g.dde_rounds, g.dde_reverse_rounds = w.dde_rounds, w.dde_reverse_rounds
+        for (name, _), t in zip(fields, grads):
+            setattr(g, name, t.data_ptr())
+        g.prepared = None
+        R = pack["num_relations"]
+        perm = ptr = None
+        if R > 0:  # edges grouped by relation id (stable), for the ordered segment sums of the relation rows' gradients
+            attr = pack["edge_attr"].clamp(0, R - 1)
+            perm = torch.argsort(attr, stable=True)
+            ptr = torch.zeros(R + 1, dtype=torch.long, device=dev)
+            ptr[1:] = torch.cumsum(torch.bincount(attr, minlength=R), 0)
+        need = int(lib.evi_retriever_backward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds, self.dde.num_reverse_rounds, R))
+        ws = ops._workspace(dev, "retriever_backward", need)
+        dl = dlogits.detach().to(device=dev, dtype=torch.float32).contiguous().view(-1)
+        b = self._batch_struct(pack)
+        _lib.check(lib.evi_retriever_backward(ctypes.byref(w), ctypes.byref(b), _DIRECTION_CODE[self.direction_mode], dl.data_ptr(),
+                                              ctypes.byref(g), perm.data_ptr() if perm is not None else None,
+                                              ptr.data_ptr() if ptr is not None else None, ws.data_ptr(), ws.numel(),
+                                              torch.cuda.current_stream(dev).cuda_stream))
+        return grads
+
     def _empty_output(self, head_idx: torch.Tensor, return_features: bool):
         dev = head_idx.device
         empty = torch.empty(0, device=dev, dtype=torch.float32)
@@ -272,10 +370,11 @@ class Retriever(nn.Module):
         return torch.where(drop, bias, torch.zeros_like(bias)).to(torch.float32).contiguous()
 
     def _forward_impl(self, batch: Any, *, return_features: bool):
-        if self.training:
+        if self.training and (float(self.state_net[3].p) > 0.0 or self.hide_seek_enabled):
             raise NotImplementedError(
-                "evi_rag_amd.Retriever implements the evaluation path only; call .eval() "
-                "(training / hide-and-seek / backward are out of scope for this build)."
+                "evi_rag_amd.Retriever differentiates the deterministic (eval-mode) graph only: the training-time dropout "
+                "inside state_net and the random hide-and-seek bias are not implemented.  Use .eval(), or construct the "
+                "module with dropout_p=0 and hide_seek_cfg={'enabled': False}."
             )
         param = self.score_head.weight
         dev = param.device
@@ -371,49 +470,48 @@ class Retriever(nn.Module):
                 if num_relations > E or int(edge_attr.min().item()) < 0:
                     num_relations = 0
 
-        lib = _lib.load()
-        logits = torch.empty(E, dtype=torch.float32, device=dev)
+        pack = dict(N=N, E=E, B=B, dev=dev, edge_index=edge_index, node_ptr=node_ptr, edge_ptr=edge_ptr, edge_batch=edge_batch,
+                    question_emb=question_emb, node_embeddings=node_embeddings, node_embedding_ids=node_embedding_ids,
+                    edge_embeddings=edge_embeddings, edge_attr=edge_attr, num_relations=num_relations,
+                    topic_one_hot=topic_one_hot,
+                    edge_bias=self._compute_hide_seek_bias(batch, edge_index=edge_index),  # None unless apply_in_eval
+                    want_features=return_features or self.emit_edge_embeddings)
         both = self.direction_mode == "bidirectional"
-        logits_fwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "backward" else None
-        logits_bwd = torch.empty(E, dtype=torch.float32, device=dev) if self.direction_mode != "forward" else None
-        want_features = return_features or self.emit_edge_embeddings
-        features = torch.empty((E, H), dtype=torch.float32, device=dev) if want_features else None
-        w = self._weights_struct()
-        prep = self._prepared_weights(w, dev)
-        w.prepared = prep.data_ptr() if prep is not None else None
-        b = _lib.EviRetrieverBatch()
-        b.num_nodes, b.num_edges, b.num_graphs = N, E, B
-        b.edge_index, b.node_ptr, b.edge_ptr, b.edge_batch = (edge_index.data_ptr(), node_ptr.data_ptr(),
-                                                             edge_ptr.data_ptr(), edge_batch.data_ptr())
-        b.question_emb, b.node_embeddings = question_emb.data_ptr(), node_embeddings.data_ptr()
-        b.node_embedding_ids, b.edge_embeddings = node_embedding_ids.data_ptr(), edge_embeddings.data_ptr()
-        b.edge_attr, b.num_relations = edge_attr.data_ptr(), num_relations
-        b.topic_one_hot, b.topic_stride = topic_one_hot.data_ptr(), int(topic_one_hot.size(1))
-        edge_bias = self._compute_hide_seek_bias(batch, edge_index=edge_index)  # None unless apply_in_eval
-        b.edge_bias = edge_bias.data_ptr() if edge_bias is not None else None
-        o = _lib.EviRetrieverOutput()
-        o.logits = logits.data_ptr()
-        o.logits_fwd = logits_fwd.data_ptr() if logits_fwd is not None else None
-        o.logits_bwd = logits_bwd.data_ptr() if logits_bwd is not None else None
-        o.edge_features = features.data_ptr() if features is not None else None
-        o.node_struct = None
-        # sticky flag for relation ids outside the stated num_relations (no read-back here: check_deferred())
-        st = getattr(self, "_deferred_status", None)
-        if st is None or st.device != dev:
-            st = self._deferred_status = torch.zeros(1, dtype=torch.int32, device=dev)
-        o.status = st.data_ptr()
-        need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,
-                                                             self.dde.num_reverse_rounds, num_relations))
-        ws = ops._workspace(dev, "retriever_forward", need)
-        _lib.check(lib.evi_retriever_forward(ctypes.byref(w), ctypes.byref(b), _DIRECTION_CODE[self.direction_mode],
-                                             ctypes.byref(o), ws.data_ptr(), ws.numel(),
-                                             torch.cuda.current_stream(dev).cuda_stream))
+        params = [p for _, p in self._param_fields()]
+        differentiable = self.training if self.differentiable is None else bool(self.differentiable)
+        if differentiable and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # the differentiable form: gradients with respect to the parameters come from
+            # evi_retriever_backward; logits_fwd / logits_bwd / edge_embeddings are returned detached
+            logits, logits_fwd, logits_bwd, features = _RetrieverFunction.apply(self, pack, *params)
+        else:
+            logits, logits_fwd, logits_bwd, features = self._launch_forward(pack)
         if not both:  # single-direction modes: logits IS the directional logit (:267-276)
             logits_fwd = logits if self.direction_mode == "forward" else None
             logits_bwd = logits if self.direction_mode == "backward" else None
         output = RetrieverOutput(logits=logits, query_ids=edge_batch, relation_ids=getattr(batch, "edge_attr", None),
                                  logits_fwd=logits_fwd, logits_bwd=logits_bwd, edge_embeddings=features)
         return output, (features if return_features else None)
+
+
+class _RetrieverFunction(torch.autograd.Function):
+    """Retriever.forward as one autograd node: forward = evi_retriever_forward, backward = evi_retriever_backward (which
+    recomputes the forward chunk by chunk, so nothing but the batch is kept between the two)."""
+
+    @staticmethod
+    def forward(ctx, module, pack, *params):
+        logits, logits_fwd, logits_bwd, features = module._launch_forward(pack)
+        ctx.module, ctx.pack = module, pack
+        extra = [t for t in (logits_fwd, logits_bwd, features) if t is not None]
+        if extra:
+            ctx.mark_non_differentiable(*extra)
+        return logits, logits_fwd, logits_bwd, features
+
+    @staticmethod
+    def backward(ctx, dlogits, *_unused):
+        if dlogits is None:
+            return (None, None) + tuple(None for _ in ctx.module._param_fields())
+        grads = ctx.module._launch_backward(ctx.pack, dlogits)
+        return (None, None) + tuple(grads)
 
 
 def _check_deferred(self) -> None:

@@ -608,6 +608,20 @@ int evi_retriever_forward(const EviRetrieverWeights* weights, const EviRetriever
                           int direction_mode, const EviRetrieverOutput* out, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Backward of evi_retriever_forward: the gradient of a scalar loss with respect to every parameter,
+ * given dL/dlogits [E] — the autograd of Retriever._forward_impl (src/models/components/retriever.py:195-289, 403-507) in the
+ * arithmetic of the forward above (eval-mode graph: no dropout, no hide-and-seek bias).  `grads` has the weights struct's
+ * layout with every pointer a caller-owned OUTPUT buffer of the parameter's shape (overwritten; `prepared` ignored).
+ * The forward is recomputed inside (nothing is kept from a forward call).  When batch.num_relations is given (relation rows
+ * de-duplicated), rel_perm [E] lists the edge ids grouped by relation id (stable order) and rel_ptr [R+1] the group bounds.
+ * Reductions run in a fixed order (f64 segment sums along the CSR / the relation grouping; no float atomics).  Gradients
+ * with respect to the batch's embeddings are not produced (the reference's tables are frozen inputs). */
+size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
+                                              int dde_reverse_rounds, int64_t num_relations);
+int evi_retriever_backward(const EviRetrieverWeights* weights, const EviRetrieverBatch* batch, int direction_mode,
+                           const float* dlogits, const EviRetrieverWeights* grads, const int64_t* rel_perm,
+                           const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -240,7 +240,15 @@ def gen_retriever(name, D, H, batch, seed, rounds=(2, 2), direction="bidirection
         out = model(ns)
         node_struct = model._build_node_structure_features(ns, edge_index=ns.edge_index, num_nodes=batch.num_nodes)
         feats = model.extract_edge_tokens(ns)
+    # §8f-4 pin: the reference's autograd through the same (eval-mode) graph — d(sum_e g_e logit_e)/d(parameter) for a fixed g
+    gen = torch.Generator().manual_seed(1000 + seed)
+    gvec = torch.randn(out.logits.numel(), generator=gen)
+    model.zero_grad()
+    (model(ns).logits * gvec).sum().backward()
     arrays = batch_arrays(batch, "b_")
+    arrays["gvec"] = gvec.numpy()
+    for p_name, p in model.named_parameters():
+        arrays["g_" + p_name] = p.grad.detach().numpy().copy()
     sd = model.state_dict()
     for k, v in sd.items():
         arrays["w_" + k] = v.numpy()

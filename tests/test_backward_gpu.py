@@ -1,0 +1,148 @@
+"""GPU: backward of the edge scorer against the REFERENCE's autograd.
+
+tests/golden/retriever_{toy,mid,fwd,bwd}.npz hold, next to the forward outputs, d(sum_e g_e logit_e)/d(parameter) for every
+parameter of the reference Retriever (eval-mode graph, fixed g) as its own autograd computed it
+(tests/golden/make_golden.py:gen_retriever).  evi_retriever_backward must reproduce all 25 gradients — for the bidirectional
+toy (one chunk, relations de-duplicated), the mid batch (D != H, 3 + 1 DDE rounds), and the single-direction modes —
+with the exact-f32 GEMMs to ~1e-5 and with the default split-bf16 GEMMs to ~1e-4 of each gradient's scale.
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from evi_rag_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _batch_from(z, dev, prefix="b_"):
+    b = types.SimpleNamespace()
+    for k in z.files:
+        if k.startswith(prefix):
+            setattr(b, k[len(prefix):], torch.from_numpy(z[k]).to(dev))
+    b.num_graphs = int(b.ptr.numel() - 1)
+    b.num_nodes = int(b.ptr[-1].item())
+    b._slice_dict = {"edge_index": b.edge_ptr}
+    return b
+
+
+def _model_from(z, dev, **kw):
+    from evi_rag_amd.retriever import Retriever
+
+    rounds = z["rounds"].tolist()
+    m = Retriever(emb_dim=int(z["D"]), hidden_dim=int(z["H"]), dde_cfg={"num_rounds": rounds[0], "num_reverse_rounds": rounds[1]},
+                  direction_mode=str(z["direction"]), **kw)
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")}, strict=True)
+    return m.to(dev).eval()
+
+
+def _check_grads(model, z, rel_tol):
+    worst = {}
+    for name, p in model.named_parameters():
+        want = z["g_" + name]
+        assert p.grad is not None, name
+        got = p.grad.detach().cpu().numpy()
+        assert got.shape == want.shape, name
+        scale = max(float(np.abs(want).max()), 1e-6)
+        err = float(np.abs(got - want).max()) / scale
+        worst[name] = err
+        assert err <= rel_tol, (name, err, scale)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["retriever_toy", "retriever_mid", "retriever_fwd", "retriever_bwd"])
+@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("default", 2e-4)])
+def test_parameter_gradients_match_the_reference_autograd(dev, name, gemm, tol, monkeypatch):
+    if gemm == "f32":
+        monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
+    else:
+        monkeypatch.delenv("EVI_SCORER_GEMM", raising=False)
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    model = _model_from(z, dev)
+    model.differentiable = True  # eval-mode graph (the reference's gradients were taken in eval mode: no dropout RNG)
+    batch = _batch_from(z, dev)
+    gvec = torch.from_numpy(z["gvec"]).to(dev)
+    out = model(batch)
+    assert out.logits.requires_grad
+    np.testing.assert_allclose(out.logits.detach().cpu().numpy(), z["logits"], rtol=0, atol=2e-4)
+    (out.logits * gvec).sum().backward()
+    torch.cuda.synchronize()
+    _check_grads(model, z, tol)
+    # a second backward pass gives the same bits (fixed reduction orders, no float atomics)
+    first = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+    (model(batch).logits * gvec).sum().backward()
+    for n, p in model.named_parameters():
+        assert torch.equal(p.grad, first[n]), n
+
+
+def test_backward_without_relation_dedupe_and_through_the_loss(dev):
+    """(a) dedupe_relations=False (relation rows projected per edge): same gradients as the de-duplicated path;
+    (b) the training-shaped use: RetrieverLoss on the differentiable forward, loss.backward(), every parameter gets a finite
+    gradient, and train() mode with dropout_p = 0 takes the same path while dropout_p > 0 is refused."""
+    from evi_rag_amd.loss import RetrieverLoss
+    from evi_rag_amd.retriever import Retriever
+
+    z = np.load(os.path.join(GOLD, "retriever_mid.npz"), allow_pickle=False)
+    batch = _batch_from(z, dev)
+    gvec = torch.from_numpy(z["gvec"]).to(dev)
+    grads = {}
+    for dedupe in (True, False):
+        m = _model_from(z, dev, dedupe_relations=dedupe)
+        m.differentiable = True
+        (m(batch).logits * gvec).sum().backward()
+        grads[dedupe] = {n: p.grad.clone() for n, p in m.named_parameters()}
+        _check_grads(m, z, 2e-4)
+    for n in grads[True]:
+        scale = float(grads[True][n].abs().max()) + 1e-6
+        assert float((grads[True][n] - grads[False][n]).abs().max()) / scale < 2e-4, n
+
+    m = _model_from(z, dev, dropout_p=0.0, hide_seek_cfg={"enabled": False})
+    m.train()
+    out = m(batch)
+    loss = RetrieverLoss(infonce_temperature=0.07)(out, batch.labels, edge_batch=out.query_ids, num_graphs=batch.num_graphs)
+    loss.loss.backward()
+    for n, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    assert float(m.state_net[0].weight.grad.abs().max()) > 0
+    bad = _model_from(z, dev)  # dropout_p = 0.1 (the reference default)
+    bad.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        bad(batch)
+
+
+def test_backward_multi_chunk_batch_matches_finite_differences(dev, monkeypatch):
+    """More than one 65 536-edge chunk (weight gradients accumulate over chunks) at D = H = 32: the directional derivative
+    along a random parameter direction equals the central finite difference of the (f32-GEMM) forward."""
+    from evi_rag_amd.retriever import Retriever
+
+    monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
+    D = H = 32
+    sb = synthetic.make_batch(24, nodes_per_graph=900, edges_per_graph=3000, emb_dim=D, num_relations=50, seed=12)
+    assert sb.num_edges > 65536
+    batch = synthetic.as_namespace(sb, device=dev)
+    torch.manual_seed(5)
+    model = Retriever(emb_dim=D, hidden_dim=H).to(dev).eval()
+    model.differentiable = True
+    g = torch.randn(sb.num_edges, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) / sb.num_edges ** 0.5
+    (model(batch).logits * g).sum().backward()
+    direction = {n: torch.randn_like(p) for n, p in model.named_parameters()}
+    analytic = sum(float((p.grad.double() * direction[n].double()).sum()) for n, p in model.named_parameters())
+    model.differentiable = False
+    eps = 1e-3
+
+    def f(sign):
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.add_(sign * eps * direction[n])
+            val = float((model(batch).logits.double() * g.double()).sum())
+            for n, p in model.named_parameters():
+                p.sub_(sign * eps * direction[n])
+        return val
+
+    numeric = (f(+1) - f(-1)) / (2 * eps)
+    assert abs(analytic - numeric) <= 2e-3 * max(1.0, abs(numeric)), (analytic, numeric)
