@@ -69,6 +69,15 @@ struct GemmFilter {
     int cap, cnt_stride;
 };
 // W [N, K] -> bf16 hi / lo planes in wsplit (once); then C = A W^T with the planes, or the filter epilogue.
+// gridDim.y-batched K-slices of one product (split-K); count <= 1: a plain GEMM
+struct GemmBatch {
+    int count = 1;
+    int64_t c_stride = 0;  // floats between the slices' outputs
+    int64_t k_total = 0;   // padded K of the whole operands
+    int64_t w_ld = 0;      // row stride of the W planes (elements)
+};
+int launch_gemm_nt_bf16x3_splitk(const float* A, int64_t M, int64_t Ktot, int64_t lda, const float* W, int N, int64_t ldw, int Ks,
+                                 int S, float* Cparts, void* wsplit, hipStream_t st);
 int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st);
 // a_f16: 0 = A is f32, 1 = A stored as f16, 2 = A is a bf16 copy (implies single);
 // single: one product (hi * hi, plain bf16 accuracy) instead of three

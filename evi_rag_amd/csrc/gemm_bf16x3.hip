@@ -50,6 +50,18 @@ __global__ void k_split_weight(const float* __restrict__ W, int N, int K, int64_
     lo[i] = (__bf16)(x - (float)h);
 }
 
+// the same for very long rows (64-bit element count): the W operand of a split-K batch
+__global__ void k_split_weight_long(const float* __restrict__ W, int N, int64_t K, int64_t ldw, int64_t Kp,
+                                    __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Kp) return;
+    const int64_t n = i / Kp, k = i % Kp;
+    const float x = k < K ? W[n * ldw + k] : 0.f;
+    const __bf16 h = (__bf16)x;
+    hi[i] = h;
+    lo[i] = (__bf16)(x - (float)h);
+}
+
 // MF = 0: v_mfma_f32_32x32x16_bf16 (eight 32x32 accumulators per wave); MF = 1: v_mfma_f32_16x16x32_bf16
 // (thirty-two 16x16 accumulators) — same LDS image, same number of fragment reads and MFMA cycles per
 // k-tile; the chip holds a higher clock on the 16x16 shape (MI355X_MICROARCH.md, DVFS item 7).
@@ -63,7 +75,21 @@ template <int ACT, int MF, int AH = 0, int P1 = 0>
 __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
-    int64_t ldc, GemmFilter flt) {
+    int64_t ldc, GemmFilter flt, GemmBatch bt) {
+    // gridDim.y > 1: independent products of K-slices of the same operands (split-K of a TN product): slice s multiplies
+    // columns [s * K, s * K + K) of A and of the W planes (row stride bt.w_ld) into C + s * bt.c_stride
+    if (bt.count > 1) {
+        const int sl = blockIdx.y;
+        const int64_t k_begin = (int64_t)sl * K;
+        A += k_begin;
+        Whi += k_begin;
+        Wlo += k_begin;
+        C += (int64_t)sl * bt.c_stride;
+        const int64_t left = bt.k_total - k_begin;
+        K = left < K ? (int)(left > 0 ? left : 0) : K;
+    }
+    const int64_t w_ld = bt.count > 1 ? bt.w_ld : (int64_t)Kp;
+    if (bt.count > 1) Kp = (K + XK - 1) / XK * XK;
     __shared__ uint4 sAhi[2][XM * 4], sWhi[2][XN * 4];                                     // 2 stages x 16 KiB each
     __shared__ uint4 sAlo[P1 ? 1 : 2][P1 ? 1 : XM * 4], sWlo[P1 ? 1 : 2][P1 ? 1 : XN * 4];  // lo planes (absent when P1)
     const int tid = threadIdx.x;
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const int wr = n0 + r;
         const int k = k0 + c * 8;
         const bool ok = wr < N && k < Kp;
-        const int64_t off = ok ? (int64_t)wr * Kp + k : 0;
+        const int64_t off = ok ? (int64_t)wr * w_ld + k : 0;
         rwh[set][i] = *reinterpret_cast<const u32x4*>(Whi + off);
         if (!P1) rwl[set][i] = *reinterpret_cast<const u32x4*>(Wlo + off);
     };
@@ -399,7 +425,7 @@ int launch_gemm_bf16_presplit(const void* A, int a_f16, int single, int64_t M, i
     const int tok = timing_begin(kTimeGemm, st);
 #define EVI_LAUNCH_PS(AHV, P1V)                                                                                          \
     hipLaunchKernelGGL((k_gemm_nt_bf16x3<0, 0, AHV, P1V>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A), M, K, lda, \
-                       hi, lo, N, Kp, static_cast<const float*>(nullptr), C, ldc, flt)
+                       hi, lo, N, Kp, static_cast<const float*>(nullptr), C, ldc, flt, GemmBatch{})
     if (a_f16 == 2) EVI_LAUNCH_PS(2, 1);
     else if (a_f16 && single) EVI_LAUNCH_PS(1, 1);
     else if (a_f16) EVI_LAUNCH_PS(1, 0);
@@ -421,7 +447,7 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, i
     const int tok = timing_begin(kTimeGemm, st);
 #define EVI_LAUNCH_FL(AHV, P1V)                                                                                          \
     hipLaunchKernelGGL((k_gemm_nt_bf16x3<3, 0, AHV, P1V>), grid, dim3(kXThreads), 0, st, static_cast<const float*>(A), M, K, lda, \
-                       hi, lo, N, Kp, static_cast<const float*>(nullptr), static_cast<float*>(nullptr), (int64_t)0, flt)
+                       hi, lo, N, Kp, static_cast<const float*>(nullptr), static_cast<float*>(nullptr), (int64_t)0, flt, GemmBatch{})
     if (a_f16 == 2) EVI_LAUNCH_FL(2, 1);
     else if (a_f16 && single) EVI_LAUNCH_FL(1, 1);
     else if (a_f16) EVI_LAUNCH_FL(1, 0);
@@ -458,15 +484,44 @@ int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda,
     }();
 #define EVI_LAUNCH_X3(ACT)                                                                                              \
     if (mfma16)                                                                                                         \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt); \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
     else                                                                                                                \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt);
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{});
     switch (act) {
         case 1: EVI_LAUNCH_X3(1) break;
         case 2: EVI_LAUNCH_X3(2) break;
         default: EVI_LAUNCH_X3(0)
     }
 #undef EVI_LAUNCH_X3
+    timing_end(tok, st);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+// Split-K batch: C_s [M, N] = A[:, s Ks : (s+1) Ks] W[:, same]^T for s < S in ONE launch (gridDim.y = S), A [M, Ktot] f32 with row
+// stride lda, W [N, Ktot] f32 split here into planes of row stride Kp_tot (wsplit: gemm_bf16x3_workspace_bytes(N, Ktot)).
+// Ks a multiple of 32.  Used by the TN products of the scorer's backward, whose output is only a few tiles.
+int launch_gemm_nt_bf16x3_splitk(const float* A, int64_t M, int64_t Ktot, int64_t lda, const float* W, int N, int64_t ldw, int Ks,
+                                 int S, float* Cparts, void* wsplit, hipStream_t st) {
+    if (M == 0 || N == 0 || S == 0) return EVI_OK;
+    const int64_t Kp_tot = (Ktot + XK - 1) / XK * XK;
+    __bf16* hi = static_cast<__bf16*>(wsplit);
+    __bf16* lo = reinterpret_cast<__bf16*>(static_cast<char*>(wsplit) + align_up((size_t)N * Kp_tot * 2, 256));
+    {
+        const int64_t total = (int64_t)N * Kp_tot;
+        hipLaunchKernelGGL(k_split_weight_long, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, Ktot, ldw, Kp_tot, hi, lo);
+        EVI_LAUNCH_CHECK();
+    }
+    const GemmFilter flt{};
+    GemmBatch bt;
+    bt.count = S;
+    bt.c_stride = M * (int64_t)N;
+    bt.k_total = Kp_tot;
+    bt.w_ld = Kp_tot;
+    const dim3 grid((unsigned)(((M + XM - 1) / XM) * ((N + XN - 1) / XN)), (unsigned)S);
+    const int tok = timing_begin(kTimeGemm, st);
+    hipLaunchKernelGGL((k_gemm_nt_bf16x3<0, 0>), grid, dim3(kXThreads), 0, st, A, M, Ks, lda, hi, lo, N, Ks, static_cast<const float*>(nullptr),
+                       Cparts, (int64_t)N, flt, bt);
     timing_end(tok, st);
     EVI_LAUNCH_CHECK();
     return EVI_OK;

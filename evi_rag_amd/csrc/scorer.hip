@@ -653,10 +653,7 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     const size_t e1 = (size_t)(E > 0 ? E : 1), n1 = (size_t)(N > 0 ? N : 1);
     L.gridC = (int)((ec + 3) / 4 < 1024 ? (ec + 3) / 4 : 1024);
     if (L.gridC < 1) L.gridC = 1;
-    // waves per workgroup of the edge backward: what is left of the LDS after the struct weights, at most 4
-    const int64_t lds_left = (int64_t)160 * 1024 - (int64_t)(F + 4) * D * 4 - 256;
-    int wv = (int)(lds_left / ((int64_t)3 * D * 4 + 4));
-    L.wavesE = wv > 4 ? 4 : (wv < 1 ? 1 : wv);
+    L.wavesE = 16;  // like the forward: 1024-thread workgroups, LDS holds the struct weights only
     L.gridE = (int)((ec + L.wavesE - 1) / L.wavesE < 512 ? (ec + L.wavesE - 1) / L.wavesE : 512);
     if (L.gridE < 1) L.gridE = 1;
     L.DZ = take((size_t)2 * ec * H * f);
@@ -669,7 +666,7 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.DU = take((size_t)2 * ec * D * f);
     L.SX = take((size_t)2 * ec * F * f);
     L.partC = take(((size_t)L.gridC * 5 * H + L.gridC) * f);
-    L.partE = take(((size_t)L.gridE * 3 * D + L.gridE) * f);
+    L.partE = take(((size_t)L.gridE * L.wavesE * 3 * D + (size_t)L.gridE * L.wavesE) * f);
     L.DDF = take(e1 * H * f);
     L.DH = take(e1 * D * f);
     L.DT = take(e1 * D * f);
@@ -706,8 +703,8 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.At = take((size_t)mx * kmax * f);
     L.Bt = take((size_t)mx * kmax * f);
     L.tnpart = take((size_t)kTnMaxSlices * mx * mx * f);
-    L.wsplit2 = take(gemm_bf16x3_workspace_bytes(mx, kTnSlice + 32));
-    L.colpart = take(((size_t)(kmax + 1023) / 1024 + 8) * mx * f);  // also the scratch row of the five / three column vectors
+    L.wsplit2 = take(gemm_bf16x3_workspace_bytes(mx, (int)kmax));  // planes of a whole transposed operand (split-K batch)
+    L.colpart = take(((size_t)(kmax + kColsumRows - 1) / kColsumRows + 16) * 5 * mx * f);  // also the scratch row of the five / three column vectors
     L.total = off;
     return L;
 }
@@ -728,12 +725,26 @@ static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, flo
     hipLaunchKernelGGL(k_transpose_pad, ga, dim3(256), 0, st, A, K, M, (int64_t)M, At, Kp);
     hipLaunchKernelGGL(k_transpose_pad, gb, dim3(256), 0, st, Bm, K, N, (int64_t)N, Bt, Kp);
     EVI_LAUNCH_CHECK();
+    if (!use_f32_gemm()) {
+        // one launch: the K-slices ride in gridDim.y (the output is only (M / 256) x (N / 256) tiles: slices fill the chip)
+        const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+        int64_t S = (768 + tiles - 1) / tiles;  // ~3 workgroups per CU
+        if (S > kTnMaxSlices) S = kTnMaxSlices;
+        int64_t Ks = ((Kp + S - 1) / S + 31) / 32 * 32;
+        if (Ks < 256) Ks = 256;
+        S = (Kp + Ks - 1) / Ks;
+        int rc = launch_gemm_nt_bf16x3_splitk(At, M, Kp, Kp, Bt, N, Kp, (int)Ks, (int)S, part, ws + L.wsplit2, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, part, (int)S,
+                           (int64_t)M * N, C, accumulate ? 1 : 0);
+        EVI_LAUNCH_CHECK();
+        return EVI_OK;
+    }
+    // exact-f32 mode (tests): slice by slice through the f32 GEMM
     int64_t S = (Kp + kTnSlice - 1) / kTnSlice;
     if (S > kTnMaxSlices) S = kTnMaxSlices;
     int64_t Ks = ((Kp + S - 1) / S + 31) / 32 * 32;
-    if (Ks > kTnSlice + 32) {  // very long K: more than kTnMaxSlices slices of kTnSlice — run them in rounds that accumulate
-        Ks = kTnSlice;
-    }
+    if (Ks > kTnSlice + 32) Ks = kTnSlice;
     int used = 0;
     int first_round = 1;
     for (int64_t k0 = 0; k0 < Kp; k0 += Ks) {
@@ -756,7 +767,7 @@ static int colsum_into(const float* X, int64_t rows, int cols, float* out, int a
                        hipStream_t st) {
     if (rows <= 0) return EVI_OK;
     float* part = reinterpret_cast<float*>(ws + L.colpart);
-    const int nb = (int)((rows + 1023) / 1024);
+    const int nb = (int)((rows + kColsumRows - 1) / kColsumRows);
     hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(256), 0, st, X, rows, cols, part);
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, nb, (int64_t)cols, out, accumulate);
     EVI_LAUNCH_CHECK();
@@ -1018,14 +1029,12 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         {   // column partials: [gridC][5][H] then [gridC] — reduce each of the five vectors and S (accumulating over chunks)
             float* dst5[5] = {G(g->state_ln_w), G(g->state_ln_b), BF(BL.ysum), BF(BL.gwd), G(g->state0_b)};
             // the partial rows interleave the five vectors: reduce them as one [gridC][5H] table into a scratch row first
-            float* tmp = BF(BL.colpart);
-            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((5 * H + 255) / 256)), dim3(256), 0, st, BF(BL.partC), BL.gridC,
-                               (int64_t)5 * H, tmp, 0);
+            float* tmp = BF(BL.colpart) + ((BL.gridC + kColsumRows - 1) / kColsumRows + 1) * 5 * H;  // behind colsum_into's scratch
+            if ((rc = colsum_into(BF(BL.partC), BL.gridC, 5 * H, tmp, 0, BL, bws, st))) return rc;
             for (int q = 0; q < 5; ++q)
                 hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, dst5[q], tmp + (int64_t)q * H, (int64_t)H);
-            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, BF(BL.partC) + (int64_t)BL.gridC * 5 * H, BL.gridC, (int64_t)1,
-                               BF(BL.ssum), 1);
             EVI_LAUNCH_CHECK();
+            if ((rc = colsum_into(BF(BL.partC) + (int64_t)BL.gridC * 5 * H, BL.gridC, 1, BF(BL.ssum), 1, BL, bws, st))) return rc;
         }
         // d(state_net.0 inputs): dP = dPA Wa, dRCX = dRC Wc, dXS = dz Wb   (NT GEMMs against the transposed blocks)
         if ((rc = scorer_gemm(BF(BL.DPA), ec, H, H, BF(BL.WaT), D, H, nullptr, 0, BF(BL.dP), D, wsplit, st))) return rc;
@@ -1050,7 +1059,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         eb.SX = BF(BL.SX);
         eb.part = BF(BL.partE);
         {
-            const size_t lds = ((size_t)(F + 4) * D + (size_t)BL.wavesE * 3 * D + BL.wavesE) * sizeof(float);
+            const size_t lds = (size_t)(F + 4) * D * sizeof(float);
             EVI_DPL_DISPATCH(dpl_d, {
                 static thread_local bool attr = false;
                 if (!attr) {
@@ -1061,15 +1070,15 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                 hipLaunchKernelGGL(k_edge_features_bwd<DPL>, dim3(BL.gridE), dim3(BL.wavesE * 64), lds, st, eb);
             });
             EVI_LAUNCH_CHECK();
-            float* tmp = BF(BL.colpart);
-            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((3 * D + 255) / 256)), dim3(256), 0, st, BF(BL.partE), BL.gridE,
-                               (int64_t)3 * D, tmp, 0);
+            // the per-wave partial table [gridE * waves][3 D] -> one row (two ordered stages), then into the three gradients
+            const int64_t prow = (int64_t)BL.gridE * BL.wavesE;
+            float* tmp = BF(BL.colpart) + ((prow + kColsumRows - 1) / kColsumRows + 1) * 3 * D;  // behind colsum_into's own scratch
+            hipLaunchKernelGGL(k_zero_f32, dim3(8), dim3(256), 0, st, tmp, (int64_t)3 * D);
+            if ((rc = colsum_into(BF(BL.partE), prow, 3 * D, tmp, 0, BL, bws, st))) return rc;
             float* dst3[3] = {G(g->struct_ln_w), G(g->struct_ln_b), G(g->struct_gate_w)};
             for (int q = 0; q < 3; ++q)
                 hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, dst3[q], tmp + (int64_t)q * D, (int64_t)D);
-            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, BF(BL.partE) + (int64_t)BL.gridE * 3 * D, BL.gridE, (int64_t)1,
-                               G(g->struct_gate_b), 1);
-            EVI_LAUNCH_CHECK();
+            if ((rc = colsum_into(BF(BL.partE) + prow * 3 * D, prow, 1, G(g->struct_gate_b), 1, BL, bws, st))) return rc;
         }
         // struct_proj.0: weight [D, F] += dU^T SX, bias += column sums of dU
         if ((rc = tn_gemm(BF(BL.DU), D, BF(BL.SX), F, M, G(g->struct_w), 1, BL, bws, st))) return rc;

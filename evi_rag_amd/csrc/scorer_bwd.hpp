@@ -122,10 +122,11 @@ __global__ void k_keep_zero_id_rows(const float* __restrict__ src, const int64_t
     dst[i] = ids[i / D] == 0 ? src[i] : 0.f;
 }
 
-// column sums of X [rows, cols] into out[cols] (+)=, two ordered stages: partial per block of 1024 rows, then the blocks
+// column sums of X [rows, cols] into out[cols] (+)=, two ordered stages: partial per block of kColsumRows rows, then the blocks
+constexpr int kColsumRows = 256;
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t rows, int cols, float* __restrict__ part) {
-    const int64_t r0 = (int64_t)blockIdx.x * 1024;
-    const int64_t r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
+    const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
+    const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
     for (int c = threadIdx.x; c < cols; c += blockDim.x) {
         float acc = 0.f;
         for (int64_t r = r0; r < r1; ++r) acc += X[r * cols + c];
@@ -385,13 +386,13 @@ struct EdgeBwdArgs {
     float* DBQ;           // [E, D]  drc
     float* DU;            // [dirs * e_count, D]  d (struct_proj.0 output)
     float* SX;            // [dirs * e_count, F]  struct_proj.0 input rows
-    float* part;          // [gridDim.x][3][D]: d struct_ln_w, d struct_ln_b, d struct_gate_w; then [gridDim.x] d struct_gate_b
+    float* part;          // [gridDim.x * waves][3][D]: d struct_ln_w, d struct_ln_b, d struct_gate_w; then [gridDim.x * waves] d struct_gate_b
 };
 
 template <int C4>
 __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
     const EdgeFeatArgs& a = b.f;
-    extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D], then the waves' column partials [16][3][D]
+    extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
     for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds_wt[i] = a.struct_wt[i];
     float* l_b = lds_wt + F * D;
@@ -584,32 +585,20 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
             }
         }
     }
-    // column partials: the waves' sums added in wave order
-    float* red = lds_wt + (F + 4) * D;  // [waves][3][D] + [waves]
-    __syncthreads();
+    // column partials: one row set per WAVE ([gridDim.x * waves][3][D] then [gridDim.x * waves] scalars); the host reduces the
+    // table in two ordered stages
+    const int64_t prow_id = (int64_t)blockIdx.x * waves + wave;
+    float* prow = b.part + prow_id * 3 * D;
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
         const int d = 4 * lane + 256 * i;
         if (d < D) {
-            st4(red + ((int64_t)wave * 3 + 0) * D + d, c_lw[i]);
-            st4(red + ((int64_t)wave * 3 + 1) * D + d, c_lb[i]);
-            st4(red + ((int64_t)wave * 3 + 2) * D + d, c_gw[i]);
+            st4(prow + 0 * D + d, c_lw[i]);
+            st4(prow + 1 * D + d, c_lb[i]);
+            st4(prow + 2 * D + d, c_gw[i]);
         }
     }
-    if (lane == 0) red[(int64_t)waves * 3 * D + wave] = c_gb;
-    __syncthreads();
-    float* prow = b.part + (int64_t)blockIdx.x * 3 * D;
-    for (int k = threadIdx.x; k < 3 * D; k += blockDim.x) {
-        const int which = k / D, d = k - which * D;
-        float acc = 0.f;
-        for (int w = 0; w < waves; ++w) acc += red[((int64_t)w * 3 + which) * D + d];
-        prow[k] = acc;
-    }
-    if (threadIdx.x == 0) {
-        float acc = 0.f;
-        for (int w = 0; w < waves; ++w) acc += red[(int64_t)waves * 3 * D + w];
-        b.part[(int64_t)gridDim.x * 3 * D + blockIdx.x] = acc;
-    }
+    if (lane == 0) b.part[(int64_t)gridDim.x * waves * 3 * D + prow_id] = c_gb;
 }
 
 }  // namespace evi

@@ -19,7 +19,24 @@ def main():
     batch.num_relations = 4096
     torch.manual_seed(0)
     model = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
-    model.emit_edge_embeddings = not (len(sys.argv) > 1 and sys.argv[1] == "lite")
+    model.emit_edge_embeddings = not (len(sys.argv) > 1 and sys.argv[1] in ("lite", "bwd"))
+    if len(sys.argv) > 1 and sys.argv[1] == "bwd":  # forward + backward (evi_retriever_backward recomputes the forward inside)
+        model.differentiable = True
+        g = torch.randn(sb.num_edges, device=dev)
+        for _ in range(2):
+            model.zero_grad()
+            (model(batch).logits * g).sum().backward()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 5
+        for _ in range(n):
+            model.zero_grad()
+            (model(batch).logits * g).sum().backward()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"forward + backward: {e0.elapsed_time(e1) / n:.3f} ms per batch, E={sb.num_edges} N={sb.num_nodes}")
+        return
     for _ in range(3):
         model(batch)
     torch.cuda.synchronize()
