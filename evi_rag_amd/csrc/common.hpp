@@ -69,9 +69,9 @@ struct GemmFilter {
     int cap, cnt_stride;
 };
 // W [N, K] -> bf16 hi / lo planes in wsplit (once); then C = A W^T with the planes, or the filter epilogue.
-// gridDim.y-batched K-slices of one product (split-K); count <= 1: a plain GEMM
+// gridDim.y-batched K-slices of one product (split-K); count == 0: a plain GEMM
 struct GemmBatch {
-    int count = 1;
+    int count = 0;
     int64_t c_stride = 0;  // floats between the slices' outputs
     int64_t k_total = 0;   // padded K of the whole operands
     int64_t w_ld = 0;      // row stride of the W planes (elements)

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
     const __bf16* __restrict__ Wlo, int N, int Kp, const float* __restrict__ bias, float* __restrict__ C,
     int64_t ldc, GemmFilter flt, GemmBatch bt) {
-    // gridDim.y > 1: independent products of K-slices of the same operands (split-K of a TN product): slice s multiplies
+    // bt.count > 0 (split-K batch, gridDim.y = bt.count): independent products of K-slices of the same operands (split-K of a TN product): slice s multiplies
     // columns [s * K, s * K + K) of A and of the W planes (row stride bt.w_ld) into C + s * bt.c_stride
-    if (bt.count > 1) {
+    if (bt.count > 0) {
         const int sl = blockIdx.y;
         const int64_t k_begin = (int64_t)sl * K;
         A += k_begin;
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const int64_t left = bt.k_total - k_begin;
         K = left < K ? (int)(left > 0 ? left : 0) : K;
     }
-    const int64_t w_ld = bt.count > 1 ? bt.w_ld : (int64_t)Kp;
-    if (bt.count > 1) Kp = (K + XK - 1) / XK * XK;
+    const int64_t w_ld = bt.count > 0 ? bt.w_ld : (int64_t)Kp;
+    if (bt.count > 0) Kp = (K + XK - 1) / XK * XK;
     __shared__ uint4 sAhi[2][XM * 4], sWhi[2][XN * 4];                                     // 2 stages x 16 KiB each
     __shared__ uint4 sAlo[P1 ? 1 : 2][P1 ? 1 : XM * 4], sWlo[P1 ? 1 : 2][P1 ? 1 : XN * 4];  // lo planes (absent when P1)
     const int tid = threadIdx.x;
