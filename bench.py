@@ -220,6 +220,29 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     model.emit_edge_embeddings = True
     gemm_ms = ms[2] / iters
     tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # training-shaped step (§8f-4): differentiable forward -> RetrieverLoss -> backward (evi_retriever_backward recomputes the
+    # forward inside); eval-mode graph (no dropout), gradients of all 25 parameters
+    from evi_rag_amd.loss import RetrieverLoss
+
+    loss_fn = RetrieverLoss(infonce_temperature=0.07)
+    model.differentiable = True
+    model.emit_edge_embeddings = False
+
+    def train_step():
+        model.zero_grad(set_to_none=True)
+        o = model(batch)
+        loss_fn(o, batch.labels, edge_batch=o.query_ids, num_graphs=graphs).loss.backward()
+
+    train_step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(4):
+        train_step()
+    torch.cuda.synchronize(dev)
+    t_train = (time.perf_counter() - t0) / 4
+    model.differentiable = None
+    model.emit_edge_embeddings = True
+    model.zero_grad(set_to_none=True)
     exact = os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
     # split-bf16: three bf16 MFMAs per algorithmic product -> executed flops = 3 x algorithmic
     executed_tf, peak, kname = (tf, 157.3, "k_gemm_nt (f32 MFMA 32x32x2)") if exact else \
@@ -239,6 +262,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         "forward_ms_per_batch": t_fwd * 1e3,
         "forward_logits_only_ms_per_batch": t_lite * 1e3,
         "metrics_ms_per_batch": t_met * 1e3,
+        "train_step_ms_per_batch": t_train * 1e3,
         "queries_per_s": graphs / (t_fwd + t_met),
         "edges_per_s": E / t_fwd,
         "roofline": {"bound": "mfma", "achieved": executed_tf, "peak": peak, "unit": "TFLOP/s", "frac": executed_tf / peak,

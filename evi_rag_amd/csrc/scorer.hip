@@ -768,7 +768,7 @@ static int colsum_into(const float* X, int64_t rows, int cols, float* out, int a
     if (rows <= 0) return EVI_OK;
     float* part = reinterpret_cast<float*>(ws + L.colpart);
     const int nb = (int)((rows + kColsumRows - 1) / kColsumRows);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(256), 0, st, X, rows, cols, part);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part);
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, nb, (int64_t)cols, out, accumulate);
     EVI_LAUNCH_CHECK();
     return EVI_OK;

@@ -124,14 +124,24 @@ __global__ void k_keep_zero_id_rows(const float* __restrict__ src, const int64_t
 
 // column sums of X [rows, cols] into out[cols] (+)=, two ordered stages: partial per block of kColsumRows rows, then the blocks
 constexpr int kColsumRows = 256;
+// block = (kColsumRows rows, 256 columns): a thread sums its column over the rows eight at a time (eight loads in flight,
+// added in a fixed order)
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t rows, int cols, float* __restrict__ part) {
     const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
     const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-        float acc = 0.f;
-        for (int64_t r = r0; r < r1; ++r) acc += X[r * cols + c];
-        part[(int64_t)blockIdx.x * cols + c] = acc;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.f;
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = X[(r + u) * cols + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
     }
+    for (; r < r1; ++r) acc += X[r * cols + c];
+    part[(int64_t)blockIdx.x * cols + c] = acc;
 }
 
 // ---- the head: state_net.4 and score_head from ysum [H] and S ---------------------------------------------
