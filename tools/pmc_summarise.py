@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
     ap.add_argument("--kernel", default="k_cosine_score")
-    ap.add_argument("--steps", type=int, required=True, help="steps the profiled command ran (warmup + timed)")
+    ap.add_argument("--steps", type=int, default=0, help="steps the profiled command ran (warmup + timed + ramp); 0 = infer from the "
+                                                         "dispatch count (--launches-per-step dispatches of the kernel per step)")
+    ap.add_argument("--launches-per-step", type=int, default=3)
     ap.add_argument("--method", default="scan")
     ap.add_argument("--rows", type=int, required=True)
     ap.add_argument("--dim", type=int, required=True)
@@ -44,6 +46,10 @@ def main():
     w_kb, nw = counter_sum(a.write, a.kernel, "WRITE_SIZE")
     if nf == 0 or nw == 0:
         raise SystemExit(f"no {a.kernel} dispatches with the counters found (fetch {nf}, write {nw})")
+    if a.steps <= 0:
+        if nf != nw or nf % a.launches_per_step:
+            raise SystemExit(f"cannot infer the step count: {nf} fetch / {nw} write dispatches, {a.launches_per_step} launches per step")
+        a.steps = nf // a.launches_per_step
     fetch = 2.0 * f_kb * 1024.0 / a.steps
     write = w_kb * 1024.0 / a.steps
     out = {
