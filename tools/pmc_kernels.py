@@ -33,7 +33,11 @@ def main():
     for k, counters in sorted(per.items()):
         mean = {c: sum(v) / len(v) for c, v in counters.items()}
         entry = {"dispatches": max(len(v) for v in counters.values()), "per_dispatch_mean": mean}
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and mean.get("SQ_BUSY_CU_CYCLES", 0) > 0:
+        # a 32-bit accumulate that pins at 2^31 is a saturated counter, not a measurement
+        sat = sorted(c for c, v in counters.items() if any(x >= 2147483648.0 for x in v))
+        if sat:
+            entry["saturated"] = sat
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "SQ_VALU_MFMA_BUSY_CYCLES" not in sat and mean.get("SQ_BUSY_CU_CYCLES", 0) > 0:
             # SQ_BUSY_CU_CYCLES sums 256 CUs; MFMA busy sums 1024 SIMDs -> busy per SIMD = mfma / (4 * busy_cu)
             entry["mfma_busy_fraction_per_simd"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * mean["SQ_BUSY_CU_CYCLES"])
         if mean.get("SQ_WAVE_CYCLES", 0) > 0:
