@@ -52,7 +52,8 @@ class EviRetrieverOutput(Structure):
     """Mirror of `EviRetrieverOutput` in include/evi_hip.h."""
 
     _fields_ = [("logits", c_void_p), ("logits_fwd", c_void_p), ("logits_bwd", c_void_p),
-                ("edge_features", c_void_p), ("node_struct", c_void_p), ("status", c_void_p)]
+                ("edge_features", c_void_p), ("node_struct", c_void_p), ("status", c_void_p),
+                ("saved", c_void_p), ("saved_bytes", c_size_t)]
 
 
 # name -> (restype, argtypes)
@@ -121,7 +122,8 @@ _SIGNATURES = {
     "evi_retriever_prepare_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "evi_retriever_prepare": (c_int, [_P, _P, c_size_t, _P]),
     "evi_retriever_backward_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64]),
-    "evi_retriever_backward": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "evi_retriever_saved_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "evi_retriever_backward": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P, c_size_t, _P]),
     "evi_retriever_forward_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "evi_retriever_forward": (c_int, [POINTER(EviRetrieverWeights), POINTER(EviRetrieverBatch), c_int,
                                       POINTER(EviRetrieverOutput), _P, c_size_t, _P]),

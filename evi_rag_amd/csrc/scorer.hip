@@ -629,6 +629,8 @@ struct BwdCtx {
     const int64_t* rel_perm;       // [E] edge ids grouped by relation id (stable), or null when relations are not de-duplicated
     const int64_t* rel_ptr;        // [R + 1] segment bounds into rel_perm
     char* ws;                      // backward workspace (evi_retriever_backward_workspace_bytes)
+    const char* saved;             // the forward's per-edge intermediates (EviRetrieverOutput.saved), or null: recompute them
+    size_t saved_bytes;
 };
 
 struct BwdLayout {
@@ -653,8 +655,8 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     const size_t e1 = (size_t)(E > 0 ? E : 1), n1 = (size_t)(N > 0 ? N : 1);
     L.gridC = (int)((ec + 3) / 4 < 1024 ? (ec + 3) / 4 : 1024);
     if (L.gridC < 1) L.gridC = 1;
-    L.wavesE = 16;  // like the forward: 1024-thread workgroups, LDS holds the struct weights only
-    L.gridE = (int)((ec + L.wavesE - 1) / L.wavesE < 512 ? (ec + L.wavesE - 1) / L.wavesE : 512);
+    L.wavesE = 6;  // 384-thread workgroups: ~150 registers per lane and (F + 4) D floats of LDS -> two workgroups, 12 waves per CU
+    L.gridE = (int)((ec + L.wavesE - 1) / L.wavesE < 1024 ? (ec + L.wavesE - 1) / L.wavesE : 1024);
     if (L.gridE < 1) L.gridE = 1;
     L.DZ = take((size_t)2 * ec * H * f);
     L.DPA = take((size_t)ec * H * f);
@@ -774,6 +776,23 @@ static int colsum_into(const float* X, int64_t rows, int cols, float* out, int a
     return EVI_OK;
 }
 
+// out[s][:] = sum of the rows of X in segment s (k_segment_rowsum); long segments are cut into slices summed in order afterwards
+static int segment_rowsum_into(const float* X, int D, const int64_t* ptr, const int64_t* perm, int64_t S, int64_t rows_total,
+                               float* out, const BwdLayout& L, char* ws, hipStream_t st) {
+    if (S <= 0) return EVI_OK;
+    int64_t Z = (rows_total / S + 255) / 256;
+    if (Z < 1) Z = 1;
+    if (Z > 32) Z = 32;
+    const size_t cap = (size_t)kTnMaxSlices * (D > 1 ? D : 1) * (D > 1 ? D : 1);  // floats in the TN partial buffer (>= mx * mx per slice)
+    while (Z > 1 && (size_t)Z * S * D > cap) --Z;
+    float* dst = Z == 1 ? out : reinterpret_cast<float*>(ws + L.tnpart);
+    hipLaunchKernelGGL(k_segment_rowsum, dim3((unsigned)S, (unsigned)((D + 255) / 256), (unsigned)Z), dim3(256), 0, st, X, D, ptr, perm, dst, S);
+    if (Z > 1)
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((S * D + 255) / 256)), dim3(256), 0, st, dst, (int)Z, S * D, out, 0);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -790,6 +809,11 @@ __global__ void k_merge_state0(const float* __restrict__ ga, const float* __rest
     }
     if (threadIdx.x == 0) dst[3 * D] = gd[r];
 }
+
+// Per-edge intermediates a training forward keeps for the backward (EviRetrieverOutput.saved): for the chunk starting at edge
+// e0, at float offset e0 * saved_floats_per_edge: P [ec, D], RCX [ec, D], XS [dirs ec, D], PA [ec, H], RC [ec, H],
+// SB [dirs ec, H], aux [dirs ec, 2] — the chunk workspace's own layout, kept for all chunks.
+static inline size_t saved_floats_per_edge(int D, int H, int dirs) { return (size_t)(2 + dirs) * D + (size_t)(2 + dirs) * H + 2 * (size_t)dirs; }
 
 static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
                          const EviRetrieverOutput* out, void* workspace, size_t workspace_bytes, void* stream,
@@ -935,6 +959,15 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         transpose(w->entity_w, D, D, BF(BL.WeT));
         EVI_LAUNCH_CHECK();
     }
+    // training: the forward writes its per-edge intermediates into the caller's `saved` buffer and the backward replays them
+    // instead of recomputing the per-edge forward (edge features, three GEMMs, the combine)
+    float* saved = bw ? reinterpret_cast<float*>(const_cast<char*>(bw->saved)) : static_cast<float*>(out->saved);
+    const bool replay = bw && bw->saved;
+    if (saved) {
+        const size_t need = (size_t)E * saved_floats_per_edge(D, H, dirs) * sizeof(float);
+        const size_t have = bw ? bw->saved_bytes : out->saved_bytes;
+        if (have < need) return fail(EVI_ERR_NOMEM, "evi_retriever: saved buffer %zu B < %zu B", have, need);
+    }
     for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
         const int64_t ec = (E - e0) < L.ec ? (E - e0) : L.ec;
         EdgeFeatArgs a;
@@ -961,12 +994,25 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         a.e_count = ec;
         a.dir_fwd = dir_fwd;
         a.dir_bwd = dir_bwd;
-        a.P = F32(L.P);
-        a.RCX = F32(L.RCX);
-        a.XS = F32(L.XS);
-        a.aux = F32(L.aux);
+        const int64_t M = (int64_t)dirs * ec;
+        float *pP = F32(L.P), *pRCX = F32(L.RCX), *pXS = F32(L.XS), *pAux = F32(L.aux), *pPA = F32(L.PA), *pRC = F32(L.RC), *pSB = F32(L.SB);
+        if (saved) {
+            float* q = saved + (size_t)e0 * saved_floats_per_edge(D, H, dirs);
+            pP = q, q += ec * D;
+            pRCX = q, q += ec * D;
+            pXS = q, q += M * D;
+            pPA = q, q += ec * H;
+            pRC = q, q += ec * H;
+            pSB = q, q += M * H;
+            pAux = q;
+        }
+        a.P = pP;
+        a.RCX = pRCX;
+        a.XS = pXS;
+        a.aux = pAux;
         int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
         if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS: 32 waves per CU hide the gather latency
+        if (!replay) {
         const int tok = timing_begin(kTimeEdge, st);
         EVI_DPL_DISPATCH(dpl_d, {
             static thread_local bool attr = false;
@@ -979,20 +1025,20 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
-        const int64_t M = (int64_t)dirs * ec;
-        if ((rc = scorer_gemm(F32(L.P), ec, D, D, wa, H, D, nullptr, 0, F32(L.PA), H, wsplit, st, planes(PL.p_wa)))) return rc;
-        if ((rc = scorer_gemm(F32(L.RCX), ec, D, D, wc, H, D, nullptr, 0, F32(L.RC), H, wsplit, st, planes(PL.p_wc)))) return rc;
-        if ((rc = scorer_gemm(F32(L.XS), M, D, D, wb, H, D, w->state0_b, 0, F32(L.SB), H, wsplit, st, planes(PL.p_wb)))) return rc;
+        if ((rc = scorer_gemm(pP, ec, D, D, wa, H, D, nullptr, 0, pPA, H, wsplit, st, planes(PL.p_wa)))) return rc;
+        if ((rc = scorer_gemm(pRCX, ec, D, D, wc, H, D, nullptr, 0, pRC, H, wsplit, st, planes(PL.p_wc)))) return rc;
+        if ((rc = scorer_gemm(pXS, M, D, D, wb, H, D, w->state0_b, 0, pSB, H, wsplit, st, planes(PL.p_wb)))) return rc;
+        }
         CombineArgs c;
         c.edge_index = b->edge_index;
         c.E = E;
         c.e_begin = e0;
         c.e_count = ec;
-        c.PA = F32(L.PA);
-        c.RC = F32(L.RC);
-        c.SB = F32(L.SB);
+        c.PA = pPA;
+        c.RC = pRC;
+        c.SB = pSB;
         c.HcN = hcn;
-        c.aux = F32(L.aux);
+        c.aux = pAux;
         c.wd = wd;
         c.ln_w = w->state_ln_w;
         c.ln_b = w->state_ln_b;
@@ -1006,9 +1052,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         c.logits_fwd = out->logits_fwd;
         c.logits_bwd = out->logits_bwd;
         const dim3 cgrid((unsigned)((ec + 3) / 4));
-        EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL>), cgrid, dim3(256), 0, st, c));
+        if (!replay) EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL>), cgrid, dim3(256), 0, st, c));
         EVI_LAUNCH_CHECK();
-        if (out->edge_features)  // state_net.4 on the combined rows, straight into the caller's [E, H] output
+        if (out->edge_features && !replay)  // state_net.4 on the combined rows, straight into the caller's [E, H] output
             if ((rc = scorer_gemm(F32(L.h1n), ec, H, H, w->state4_w, H, H, w->state4_b, 0, out->edge_features + e0 * H, H, wsplit,
                                   st, planes(PL.p_s4))))
                 return rc;
@@ -1041,9 +1087,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         if ((rc = scorer_gemm(BF(BL.DRC), ec, H, H, BF(BL.WcT), D, H, nullptr, 0, BF(BL.dRCX), D, wsplit, st))) return rc;
         if ((rc = scorer_gemm(BF(BL.DZ), M, H, H, BF(BL.WbT), D, H, nullptr, 0, BF(BL.dXS), D, wsplit, st))) return rc;
         // weight blocks of state_net.0: dWa += dPA^T P, dWc += dRC^T RCX, dWb += dz^T XS
-        if ((rc = tn_gemm(BF(BL.DPA), H, F32(L.P), D, ec, BF(BL.gWa), 1, BL, bws, st))) return rc;
-        if ((rc = tn_gemm(BF(BL.DRC), H, F32(L.RCX), D, ec, BF(BL.gWc), 1, BL, bws, st))) return rc;
-        if ((rc = tn_gemm(BF(BL.DZ), H, F32(L.XS), D, M, BF(BL.gWb), 1, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(BF(BL.DPA), H, pP, D, ec, BF(BL.gWa), 1, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(BF(BL.DRC), H, pRCX, D, ec, BF(BL.gWc), 1, BL, bws, st))) return rc;
+        if ((rc = tn_gemm(BF(BL.DZ), H, pXS, D, M, BF(BL.gWb), 1, BL, bws, st))) return rc;
         EdgeBwdArgs eb;
         eb.f = a;
         eb.dP = BF(BL.dP);
@@ -1063,11 +1109,13 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
             EVI_DPL_DISPATCH(dpl_d, {
                 static thread_local bool attr = false;
                 if (!attr) {
-                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features_bwd<DPL>),
+                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_struct_bwd<DPL>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     attr = true;
                 }
-                hipLaunchKernelGGL(k_edge_features_bwd<DPL>, dim3(BL.gridE), dim3(BL.wavesE * 64), lds, st, eb);
+                hipLaunchKernelGGL(k_edge_struct_bwd<DPL>, dim3(BL.gridE), dim3(BL.wavesE * 64), lds, st, eb);
+                const unsigned gt = (unsigned)((ec + 3) / 4 < 8192 ? (ec + 3) / 4 : 8192);
+                hipLaunchKernelGGL(k_edge_translate_bwd<DPL>, dim3(gt > 0 ? gt : 1), dim3(256), 0, st, eb);
             });
             EVI_LAUNCH_CHECK();
             // the per-wave partial table [gridE * waves][3 D] -> one row (two ordered stages), then into the three gradients
@@ -1090,8 +1138,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         const EviRetrieverWeights* g = bw->g;
         auto blocks_of = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
         // nodes: gather the per-edge gradients through the CSR, add the Wc path (HcN = node_repr Wc^T)
-        hipLaunchKernelGGL(k_node_gather_grad, dim3((unsigned)N), dim3(256), 0, st, I32(L.in_ptr), I32(L.in_eid), I32(L.out_ptr),
-                           I32(L.out_eid), BF(BL.DH), BF(BL.DT), D, BF(BL.DDF), H, BF(BL.dNR), BF(BL.dHcN));
+        hipLaunchKernelGGL(k_node_gather_grad, dim3((unsigned)((N * ((D + 255) / 256 + (H + 255) / 256) + 3) / 4)), dim3(256), 0, st, I32(L.in_ptr), I32(L.in_eid), I32(L.out_ptr),
+                           I32(L.out_eid), BF(BL.DH), BF(BL.DT), D, BF(BL.DDF), H, BF(BL.dNR), BF(BL.dHcN), (int64_t)N);
         EVI_LAUNCH_CHECK();
         if ((rc = scorer_gemm(BF(BL.dHcN), N, H, H, BF(BL.WcT), D, H, nullptr, 0, BF(BL.tmpN), D, wsplit, st))) return rc;
         hipLaunchKernelGGL(k_add_inplace, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), BF(BL.tmpN), N * D);
@@ -1115,7 +1163,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         // relation_proj
         if (L.dedupe) {
             const int64_t R = b->num_relations;
-            hipLaunchKernelGGL(k_segment_rowsum, dim3((unsigned)R, (unsigned)((D + 63) / 64)), dim3(256), 0, st, BF(BL.DRR), D, bw->rel_ptr, bw->rel_perm, BF(BL.dRRu));
+            if ((rc = segment_rowsum_into(BF(BL.DRR), D, bw->rel_ptr, bw->rel_perm, R, E, BF(BL.dRRu), BL, bws, st))) return rc;
             hipLaunchKernelGGL(k_act_bwd, blocks_of(R * D), dim3(256), 0, st, BF(BL.dRRu), rel_repr, R, D, 1, (const int64_t*)nullptr);
             EVI_LAUNCH_CHECK();
             if ((rc = tn_gemm(BF(BL.dRRu), D, F32(L.rel_rows), D, R, G(g->relation_w), 0, BL, bws, st))) return rc;
@@ -1127,8 +1175,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
             if ((rc = colsum_into(BF(BL.DRR), E, D, G(g->relation_b), 0, BL, bws, st))) return rc;
         }
         // question side: gate (sigmoid) and bias (tanh) of the projected question, then query_proj (tanh)
-        hipLaunchKernelGGL(k_segment_rowsum, dim3(B, (unsigned)((D + 63) / 64)), dim3(256), 0, st, BF(BL.DGQ), D, b->edge_ptr, (const int64_t*)nullptr, BF(BL.dGQ));
-        hipLaunchKernelGGL(k_segment_rowsum, dim3(B, (unsigned)((D + 63) / 64)), dim3(256), 0, st, BF(BL.DBQ), D, b->edge_ptr, (const int64_t*)nullptr, BF(BL.dBQ));
+        if ((rc = segment_rowsum_into(BF(BL.DGQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dGQ), BL, bws, st))) return rc;
+        if ((rc = segment_rowsum_into(BF(BL.DBQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dBQ), BL, bws, st))) return rc;
         hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, BF(BL.dGQ), gate_q, (int64_t)B, D, 2, (const int64_t*)nullptr);
         hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, BF(BL.dBQ), bias_q, (int64_t)B, D, 1, (const int64_t*)nullptr);
         EVI_LAUNCH_CHECK();
@@ -1159,6 +1207,11 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
     return retriever_run(w, b, direction_mode, out, workspace, workspace_bytes, stream, nullptr);
 }
 
+extern "C" size_t evi_retriever_saved_bytes(int64_t E, int D, int H, int direction_mode) {
+    if (E < 0 || D < 1 || H < 1 || direction_mode < 0 || direction_mode > 2) return 0;
+    return (size_t)(E > 0 ? E : 1) * saved_floats_per_edge(D, H, direction_mode == 0 ? 2 : 1) * sizeof(float);
+}
+
 extern "C" size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                                          int dde_reverse_rounds, int64_t num_relations) {
     if (N < 0 || E < 0 || B < 1 || D < 1 || H < 1) return 0;
@@ -1169,7 +1222,8 @@ extern "C" size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, i
 
 extern "C" int evi_retriever_backward(const EviRetrieverWeights* w, const EviRetrieverBatch* b, int direction_mode,
                                       const float* dlogits, const EviRetrieverWeights* grads, const int64_t* rel_perm,
-                                      const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, void* stream) {
+                                      const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, const void* saved,
+                                      size_t saved_bytes, void* stream) {
     EVI_REQUIRE(w && b && grads && dlogits, "evi_retriever_backward: null pointer");
     EVI_REQUIRE(!w->prepared, "evi_retriever_backward: pass the weights without a prepared buffer (training changes them every step)");
     const int64_t N = b->num_nodes, E = b->num_edges;
@@ -1190,6 +1244,6 @@ extern "C" int evi_retriever_backward(const EviRetrieverWeights* w, const EviRet
     o.logits = scratch_logits;
     o.logits_fwd = scratch_logits + E;
     o.logits_bwd = scratch_logits + 2 * E;
-    BwdCtx ctx{dlogits, grads, rel_perm, rel_ptr, base + fwd_bytes};
+    BwdCtx ctx{dlogits, grads, rel_perm, rel_ptr, base + fwd_bytes, static_cast<const char*>(saved), saved_bytes};
     return retriever_run(w, b, direction_mode, &o, base, fwd_bytes, stream, &ctx);
 }

@@ -8,7 +8,8 @@
 //                        (dPA = nav_f dz_f + nav_b dz_b, dRC = dz_f + dz_b, dDiff = dz_f - dz_b, dnav, d(-dist)), plus the
 //                        column sums behind d state_net.1.{weight,bias}, d wd, d state_net.0.bias and the folded head
 //   three NT GEMMs       dP = dPA Wa, dRCX = dRC Wc, dXS = dz Wb        (weights transposed once: [D, H] row-major)
-//   k_edge_features_bwd  -> per-edge dh, dt, d rel_repr row, d gate_q / d bias_q contributions, d struct pre-activation rows
+//   k_edge_translate_bwd -> per-edge dh, dt, d rel_repr row, d gate_q / d bias_q contributions
+//   k_edge_struct_bwd    -> d struct pre-activation rows (dU), the struct MLP's input rows, its LayerNorm / gate column partials
 //   TN products          dWa += dPA^T P, dWc += dRC^T RCX, dWb += dz^T XS, dWs += dU^T struct   (tn_gemm: explicit
 //                        transposes + split-K NT GEMMs + an ordered reduction — correct first, not yet fast)
 // and once per batch: node / relation / graph segment sums (f64, CSR- or sort-ordered: no float atomics), the tanh / sigmoid
@@ -60,43 +61,97 @@ __global__ void k_reduce_partials(const float* __restrict__ part, int S, int64_t
     out[i] = acc;
 }
 
-// out[s][:] = sum over rows p in [ptr[s], ptr[s+1]) of X[perm ? perm[p] : p][:]   (f64 accumulation in a fixed order).
-// Block = (segment, 64 columns); its four waves take every fourth row and their partial sums are added in wave order.
+// out[z][s][:] = sum over the z-th of gridDim.z equal slices of the rows p in [ptr[s], ptr[s+1]) of X[perm ? perm[p] : p][:]
+// (f64 accumulation in a fixed order; the caller adds the slices in ascending z).  Block = (segment, 256 columns, slice): a lane
+// owns four consecutive columns, the four waves take every fourth row (four rows in flight per wave) and their sums are added
+// in wave order.
 __global__ __launch_bounds__(256) void k_segment_rowsum(const float* __restrict__ X, int D, const int64_t* __restrict__ ptr,
-                                                        const int64_t* __restrict__ perm, float* __restrict__ out) {
-    __shared__ double red[4][64];
+                                                        const int64_t* __restrict__ perm, float* __restrict__ out, int64_t S) {
+    __shared__ double red[4][256];
     const int64_t s = blockIdx.x;
-    const int d = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int grp = threadIdx.x >> 6;
-    const int64_t b = ptr[s], e = ptr[s + 1];
-    double acc = 0.0;
-    if (d < D)
-        for (int64_t p = b + grp; p < e; p += 4) acc += (double)X[(perm ? perm[p] : p) * D + d];
-    red[grp][threadIdx.x & 63] = acc;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int d = blockIdx.y * 256 + 4 * lane;
+    const int64_t b0 = ptr[s], e0 = ptr[s + 1];
+    const int64_t per = (e0 - b0 + gridDim.z - 1) / gridDim.z;
+    const int64_t b = b0 + per * blockIdx.z;
+    const int64_t e = b + per < e0 ? b + per : e0;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (d < D) {
+        int64_t p = b + grp;
+        for (; p + 12 < e; p += 16) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4(X + (perm ? perm[p + 4 * u] : p + 4 * u) * D + d);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += (double)v[u][c];
+        }
+        for (; p < e; p += 4) {
+            const f4 v = ld4(X + (perm ? perm[p] : p) * D + d);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += (double)v[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[grp][4 * lane + c] = acc[c];
     __syncthreads();
-    if (grp == 0 && d < D) out[s * D + d] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+    const int dc = blockIdx.y * 256 + threadIdx.x;
+    if (dc < D)
+        out[((int64_t)blockIdx.z * S + s) * D + dc] =
+            (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+// sum over the CSR row [eb, ee) of +-rows of a [*, W] matrix into f64 accumulators (edge order = CSR order), eight rows in flight
+__device__ inline void csr_rows_accumulate(const int32_t* __restrict__ eid, int eb, int ee, const float* __restrict__ M, int W, int d,
+                                           double sign, double (&acc)[4]) {
+    int p = eb;
+    for (; p + 8 <= ee; p += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld4(M + (int64_t)eid[p + u] * W + d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += sign * (double)v[u][c];
+    }
+    for (; p < ee; ++p) {
+        const f4 v = ld4(M + (int64_t)eid[p] * W + d);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += sign * (double)v[c];
+    }
 }
 
 // node gradients through the CSR: dNR[v] = sum_{out edges} DH[e] + sum_{in edges} DT[e]   (v is head / tail of e),
-// dHcN[v] = sum_{out} DDF[e] - sum_{in} DDF[e].  One workgroup per node, f64 sums in CSR row order.
+// dHcN[v] = sum_{out} DDF[e] - sum_{in} DDF[e].  One WAVE per (node, 256-column block of dNR or dHcN) — a hub's column
+// blocks run on different waves; a lane owns four consecutive columns; f64 sums in CSR row order.
 __global__ __launch_bounds__(256) void k_node_gather_grad(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_eid,
                                                           const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_eid,
                                                           const float* __restrict__ DH, const float* __restrict__ DT, int D,
                                                           const float* __restrict__ DDF, int H, float* __restrict__ dNR,
-                                                          float* __restrict__ dHcN) {
-    const int64_t v = blockIdx.x;
+                                                          float* __restrict__ dHcN, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    const int ud = (D + 255) / 256, uh = (H + 255) / 256;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t v = task / (ud + uh);
+    const int u = (int)(task - v * (ud + uh));
+    if (v >= N) return;
     const int ob = out_ptr[v], oe = out_ptr[v + 1], ib = in_ptr[v], ie = in_ptr[v + 1];
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        double acc = 0.0;
-        for (int p = ob; p < oe; ++p) acc += (double)DH[(int64_t)out_eid[p] * D + d];
-        for (int p = ib; p < ie; ++p) acc += (double)DT[(int64_t)in_eid[p] * D + d];
-        dNR[v * D + d] = (float)acc;
-    }
-    for (int d = threadIdx.x; d < H; d += blockDim.x) {
-        double acc = 0.0;
-        for (int p = ob; p < oe; ++p) acc += (double)DDF[(int64_t)out_eid[p] * H + d];
-        for (int p = ib; p < ie; ++p) acc -= (double)DDF[(int64_t)in_eid[p] * H + d];
-        dHcN[v * H + d] = (float)acc;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (u < ud) {
+        const int d = 4 * lane + 256 * u;
+        if (d >= D) return;
+        csr_rows_accumulate(out_eid, ob, oe, DH, D, d, 1.0, acc);
+        csr_rows_accumulate(in_eid, ib, ie, DT, D, d, 1.0, acc);
+        const f4 r = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+        st4(dNR + v * D + d, r);
+    } else {
+        const int d = 4 * lane + 256 * (u - ud);
+        if (d >= H) return;
+        csr_rows_accumulate(out_eid, ob, oe, DDF, H, d, 1.0, acc);
+        csr_rows_accumulate(in_eid, ib, ie, DDF, H, d, -1.0, acc);
+        const f4 r = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+        st4(dHcN + v * H + d, r);
     }
 }
 
@@ -399,8 +454,11 @@ struct EdgeBwdArgs {
     float* part;          // [gridDim.x * waves][3][D]: d struct_ln_w, d struct_ln_b, d struct_gate_w; then [gridDim.x * waves] d struct_gate_b
 };
 
+// Two kernels (one would need ~400 registers per lane: it spilled).
+// (1) the struct MLP side: per (edge, direction) recompute struct_proj.0 -> LayerNorm -> GELU -> gate from the 2 x half
+//     node_struct values, then dU (gradient of the struct_proj.0 output row), the MLP's input row SX and the column partials.
 template <int C4>
-__global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
+__global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
     const EdgeFeatArgs& a = b.f;
     extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
@@ -425,84 +483,47 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
 #pragma unroll
     for (int i = 0; i < C4; ++i) c_lw[i] = c_lb[i] = c_gw[i] = z4;
     float c_gb = 0.f;
+    const int dirs = (a.dir_fwd ? 1 : 0) + (a.dir_bwd ? 1 : 0);
 
     for (int64_t le = (int64_t)blockIdx.x * waves + wave; le < a.e_count; le += (int64_t)gridDim.x * waves) {
         const int64_t e = a.e_begin + le;
         const int64_t hv = __builtin_amdgcn_readfirstlane((int)a.edge_index[e]);
         const int64_t tv = __builtin_amdgcn_readfirstlane((int)a.edge_index[a.E + e]);
-        const int64_t g = __builtin_amdgcn_readfirstlane((int)a.edge_batch[e]);
-        int64_t rrow = a.rel_by_edge ? e : (int64_t)__builtin_amdgcn_readfirstlane((int)a.edge_attr[e]);
-        if (!a.rel_by_edge) rrow = rrow < 0 ? 0 : (rrow >= a.R ? a.R - 1 : rrow);
-        const float* hp = a.node_repr + hv * D;
-        const float* tp = a.node_repr + tv * D;
-        const float* rp = a.rel_repr + rrow * D;
-        const float* gp = a.gate_q + g * D;
-        const float* bp = a.bias_q + g * D;
-        f4 h[C4], t[C4], rr[C4], gq[C4], rc[C4];
-#pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int d = 4 * lane + 256 * i;
-            if (d < D) {
-                h[i] = ld4(hp + d);
-                t[i] = ld4(tp + d);
-                rr[i] = ld4(rp + d);
-                gq[i] = ld4(gp + d);
-                rc[i] = rr[i] * gq[i] + ld4(bp + d);
-            } else {
-                h[i] = t[i] = rr[i] = gq[i] = rc[i] = z4;
-            }
-        }
         const float* nsh = a.node_struct + hv * half;
         const float* nst = a.node_struct + tv * half;
-        f4 s2[2][C4];
-#pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int d = 4 * lane + 256 * i;
-            s2[0][i] = s2[1][i] = d < D ? ld4(l_b + d) : z4;
-        }
-        for (int j = 0; j < half; ++j) {
-            const float xh = nsh[j], xt = nst[j];
+#pragma unroll 1
+        for (int out_row = 0; out_row < dirs; ++out_row) {
+            const int dir = a.dir_fwd ? out_row : 1;
+            const int64_t row = (int64_t)out_row * a.e_count + le;
+            const float* na = dir == 0 ? nsh : nst;  // first half of the MLP input
+            const float* nb = dir == 0 ? nst : nsh;
+            f4 s2[C4];
 #pragma unroll
             for (int i = 0; i < C4; ++i) {
                 const int d = 4 * lane + 256 * i;
-                if (d < D) {
-                    const f4 w1 = ld4(lds_wt + j * D + d), w2 = ld4(lds_wt + (half + j) * D + d);
+                s2[i] = d < D ? ld4(l_b + d) : z4;
+            }
+            for (int j = 0; j < half; ++j) {
+                const float xa = na[j], xb = nb[j];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        s2[0][i][c] = fmaf(w2[c], xt, fmaf(w1[c], xh, s2[0][i][c]));
-                        s2[1][i][c] = fmaf(w2[c], xh, fmaf(w1[c], xt, s2[1][i][c]));
+                for (int i = 0; i < C4; ++i) {
+                    const int d = 4 * lane + 256 * i;
+                    if (d < D) {
+                        const f4 w1 = ld4(lds_wt + j * D + d), w2 = ld4(lds_wt + (half + j) * D + d);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) s2[i][c] = fmaf(w2[c], xb, fmaf(w1[c], xa, s2[i][c]));
                     }
                 }
             }
-        }
-        f4 dh[C4], dt[C4], drc[C4];
-#pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int d = 4 * lane + 256 * i;
-            if (d < D) {
-                const f4 dp = ld4(b.dP + le * D + d);
-                dh[i] = dp * rc[i] * t[i];
-                dt[i] = dp * h[i] * rc[i];
-                drc[i] = dp * h[i] * t[i] + ld4(b.dRCX + le * D + d);
-            } else {
-                dh[i] = dt[i] = drc[i] = z4;
-            }
-        }
-        int out_row = 0;
-#pragma unroll
-        for (int dir = 0; dir < 2; ++dir) {
-            if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
-            const int64_t row = (int64_t)out_row * a.e_count + le;
-            // recompute LayerNorm + GELU of the struct MLP
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < C4; ++i) sum += (4 * lane + 256 * i < D) ? hsum4(s2[dir][i]) : 0.f;
+            for (int i = 0; i < C4; ++i) sum += (4 * lane + 256 * i < D) ? hsum4(s2[i]) : 0.f;
             const float mean = wsum(sum) * inv_d;
             float var = 0.f;
 #pragma unroll
             for (int i = 0; i < C4; ++i)
                 if (4 * lane + 256 * i < D) {
-                    const f4 c = s2[dir][i] - mean;
+                    const f4 c = s2[i] - mean;
                     var += hsum4(c * c);
                 }
             const float rstd = 1.0f / sqrtf(wsum(var) * inv_d + kLnEps);
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
                 uh[i] = av[i] = sv[i] = z4;
                 if (d < D) {
                     const f4 lw = ld4(l_lw + d), lb = ld4(l_lb + d), gw = ld4(l_gw + d);
-                    uh[i] = (s2[dir][i] - mean) * rstd;
+                    uh[i] = (s2[i] - mean) * rstd;
                     av[i] = uh[i] * lw + lb;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -524,19 +545,7 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
                 }
             }
             const float nav = sigmoidf_(wsum(gacc) + gate_b);
-            // translation error and its norm
-            float dsq = 0.f;
-            f4 err[C4];
-#pragma unroll
-            for (int i = 0; i < C4; ++i) {
-                err[i] = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
-                if (4 * lane + 256 * i < D) dsq += hsum4(err[i] * err[i]);
-            }
-            const float nrm = sqrtf(wsum(dsq));
-            const float dnav = b.daux[row * 2], dnd = b.daux[row * 2 + 1];
-            // -dist = -||err||:  d err = dnd * (-err / ||err||)   (0 at err == 0, like torch.norm's subgradient)
-            const float kerr = nrm > 0.f ? -dnd / nrm : 0.f;
-            const float dpre = dnav * nav * (1.0f - nav);
+            const float dpre = b.daux[row * 2] * nav * (1.0f - nav);
             c_gb += dpre;  // same value on every lane: counted once below
             f4 gg[C4];
             float m1 = 0.f, m2 = 0.f;
@@ -545,15 +554,6 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
                 const int d = 4 * lane + 256 * i;
                 gg[i] = z4;
                 if (d < D) {
-                    const f4 de = kerr * err[i];
-                    if (dir == 0) {
-                        dh[i] += de;
-                        dt[i] -= de;
-                    } else {
-                        dt[i] += de;
-                        dh[i] -= de;
-                    }
-                    drc[i] += de;
                     const f4 lw = ld4(l_lw + d), gw = ld4(l_gw + d);
                     const f4 ds = ld4(b.dXS + row * D + d) + dpre * gw;
                     c_gw[i] += dpre * sv[i];
@@ -576,23 +576,7 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
                 if (d < D) st4(b.DU + row * D + d, rstd * (gg[i] - m1 - uh[i] * m2));
             }
             // the struct MLP's input row (wave-uniform values): [ns[a] | ns[b]] with (a, b) = (head, tail) / (tail, head)
-            if (lane < F) {
-                const int j = lane < half ? lane : lane - half;
-                const bool first = lane < half;
-                b.SX[row * F + lane] = (first == (dir == 0)) ? nsh[j] : nst[j];
-            }
-            ++out_row;
-        }
-#pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int d = 4 * lane + 256 * i;
-            if (d < D) {
-                st4(b.DH + e * D + d, dh[i]);
-                st4(b.DT + e * D + d, dt[i]);
-                st4(b.DRR + e * D + d, drc[i] * gq[i]);
-                st4(b.DGQ + e * D + d, drc[i] * rr[i]);
-                st4(b.DBQ + e * D + d, drc[i]);
-            }
+            if (lane < F) b.SX[row * F + lane] = lane < half ? na[lane] : nb[lane - half];
         }
     }
     // column partials: one row set per WAVE ([gridDim.x * waves][3][D] then [gridDim.x * waves] scalars); the host reduces the
@@ -609,6 +593,89 @@ __global__ __launch_bounds__(1024) void k_edge_features_bwd(EdgeBwdArgs b) {
         }
     }
     if (lane == 0) b.part[(int64_t)gridDim.x * waves * 3 * D + prow_id] = c_gb;
+}
+
+// (2) the product / translation side: p = h * rc * t (nav applied downstream), err = +-(h - t) + rc, -dist = -||err||:
+//     per edge dh, dt, and d rc in its three uses (d rel_repr row, d gate_q, d bias_q contributions).  One wave per edge.
+template <int C4>
+__global__ __launch_bounds__(256) void k_edge_translate_bwd(EdgeBwdArgs b) {
+    const EdgeFeatArgs& a = b.f;
+    const int D = a.D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int dirs = (a.dir_fwd ? 1 : 0) + (a.dir_bwd ? 1 : 0);
+    for (int64_t le = (int64_t)blockIdx.x * waves + wave; le < a.e_count; le += (int64_t)gridDim.x * waves) {
+        const int64_t e = a.e_begin + le;
+        const int64_t hv = __builtin_amdgcn_readfirstlane((int)a.edge_index[e]);
+        const int64_t tv = __builtin_amdgcn_readfirstlane((int)a.edge_index[a.E + e]);
+        const int64_t g = __builtin_amdgcn_readfirstlane((int)a.edge_batch[e]);
+        int64_t rrow = a.rel_by_edge ? e : (int64_t)__builtin_amdgcn_readfirstlane((int)a.edge_attr[e]);
+        if (!a.rel_by_edge) rrow = rrow < 0 ? 0 : (rrow >= a.R ? a.R - 1 : rrow);
+        const float* hp = a.node_repr + hv * D;
+        const float* tp = a.node_repr + tv * D;
+        const float* rp = a.rel_repr + rrow * D;
+        const float* gp = a.gate_q + g * D;
+        const float* bp = a.bias_q + g * D;
+        f4 h[C4], t[C4], rr[C4], gq[C4], rc[C4], dh[C4], dt[C4], drc[C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < D) {
+                h[i] = ld4(hp + d);
+                t[i] = ld4(tp + d);
+                rr[i] = ld4(rp + d);
+                gq[i] = ld4(gp + d);
+                rc[i] = rr[i] * gq[i] + ld4(bp + d);
+                const f4 dp = ld4(b.dP + le * D + d);
+                dh[i] = dp * rc[i] * t[i];
+                dt[i] = dp * h[i] * rc[i];
+                drc[i] = dp * h[i] * t[i] + ld4(b.dRCX + le * D + d);
+            } else {
+                h[i] = t[i] = rr[i] = gq[i] = rc[i] = dh[i] = dt[i] = drc[i] = z4;
+            }
+        }
+        // err_f = h + rc - t, err_b = t + rc - h = 2 rc - err_f... kept as two explicit passes: same arithmetic as the forward
+#pragma unroll
+        for (int out_row = 0; out_row < 2; ++out_row) {
+            if (out_row >= dirs) continue;
+            const int dir = a.dir_fwd ? out_row : 1;
+            const int64_t row = (int64_t)out_row * a.e_count + le;
+            float dsq = 0.f;
+            f4 err[C4];
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                err[i] = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
+                if (4 * lane + 256 * i < D) dsq += hsum4(err[i] * err[i]);
+            }
+            const float nrm = sqrtf(wsum(dsq));
+            const float dnd = b.daux[row * 2 + 1];
+            // -dist = -||err||:  d err = dnd * (-err / ||err||)   (0 at err == 0, like torch.norm's subgradient)
+            const float kerr = nrm > 0.f ? -dnd / nrm : 0.f;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const f4 de = kerr * err[i];
+                if (dir == 0) {
+                    dh[i] += de;
+                    dt[i] -= de;
+                } else {
+                    dt[i] += de;
+                    dh[i] -= de;
+                }
+                drc[i] += de;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < D) {
+                st4(b.DH + e * D + d, dh[i]);
+                st4(b.DT + e * D + d, dt[i]);
+                st4(b.DRR + e * D + d, drc[i] * gq[i]);
+                st4(b.DGQ + e * D + d, drc[i] * rr[i]);
+                st4(b.DBQ + e * D + d, drc[i]);
+            }
+        }
+    }
 }
 
 }  // namespace evi

@@ -134,6 +134,8 @@ class Retriever(nn.Module):
         # None: the forward is a differentiable autograd node in train() mode only (evaluation never builds a graph, whatever
         # torch.is_grad_enabled() says); True / False force it — True gives eval-mode gradients (the parity tests use that)
         self.differentiable: Optional[bool] = None
+        # training: keep the per-edge intermediates of the forward for the backward (memory for time: ≈ 16 (D + H) bytes per edge)
+        self.keep_forward_intermediates = True
         self.emb_dim = int(emb_dim)
         self.hidden_dim = int(hidden_dim)
         self.use_topic_pe = bool(topic_pe)
@@ -263,8 +265,10 @@ class Retriever(nn.Module):
         b.edge_bias = pack["edge_bias"].data_ptr() if pack["edge_bias"] is not None else None
         return b
 
-    def _launch_forward(self, pack):
-        """One evi_retriever_forward call: (logits, logits_fwd, logits_bwd, features-or-None), device tensors."""
+    def _launch_forward(self, pack, keep_for_backward: bool = False):
+        """One evi_retriever_forward call: (logits, logits_fwd, logits_bwd, features-or-None), device tensors.
+        keep_for_backward: the per-edge intermediates are written to `pack["saved"]` (evi_retriever_saved_bytes) so that the
+        backward replays them instead of recomputing the per-edge forward."""
         lib = _lib.load()
         dev, E, N, B = pack["dev"], pack["E"], pack["N"], pack["B"]
         D, H = self.emb_dim, self.hidden_dim
@@ -288,6 +292,11 @@ class Retriever(nn.Module):
         if st is None or st.device != dev:
             st = self._deferred_status = torch.zeros(1, dtype=torch.int32, device=dev)
         o.status = st.data_ptr()
+        o.saved, o.saved_bytes = None, 0
+        if keep_for_backward and E > 0:
+            nbytes = int(lib.evi_retriever_saved_bytes(E, D, H, _DIRECTION_CODE[self.direction_mode]))
+            pack["saved"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            o.saved, o.saved_bytes = pack["saved"].data_ptr(), nbytes
         need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,
                                                              self.dde.num_reverse_rounds, pack["num_relations"]))
         ws = ops._workspace(dev, "retriever_forward", need)
@@ -323,9 +332,12 @@ class Retriever(nn.Module):
         ws = ops._workspace(dev, "retriever_backward", need)
         dl = dlogits.detach().to(device=dev, dtype=torch.float32).contiguous().view(-1)
         b = self._batch_struct(pack)
+        saved = pack.pop("saved", None)  # written by this batch's forward (keep_forward_intermediates); None: recompute
         _lib.check(lib.evi_retriever_backward(ctypes.byref(w), ctypes.byref(b), _DIRECTION_CODE[self.direction_mode], dl.data_ptr(),
                                               ctypes.byref(g), perm.data_ptr() if perm is not None else None,
                                               ptr.data_ptr() if ptr is not None else None, ws.data_ptr(), ws.numel(),
+                                              saved.data_ptr() if saved is not None else None,
+                                              saved.numel() if saved is not None else 0,
                                               torch.cuda.current_stream(dev).cuda_stream))
         return grads
 
@@ -494,12 +506,15 @@ class Retriever(nn.Module):
 
 
 class _RetrieverFunction(torch.autograd.Function):
-    """Retriever.forward as one autograd node: forward = evi_retriever_forward, backward = evi_retriever_backward (which
-    recomputes the forward chunk by chunk, so nothing but the batch is kept between the two)."""
+    """Retriever.forward as one autograd node: forward = evi_retriever_forward, backward = evi_retriever_backward.  With
+    `module.keep_forward_intermediates` (default) the forward keeps its per-edge operand / product rows
+    (≈ (4 D + 4 H) floats per edge) and the backward replays them; otherwise the backward recomputes the forward chunk by
+    chunk and nothing but the batch is kept between the two (same gradients either way, bit for bit)."""
 
     @staticmethod
     def forward(ctx, module, pack, *params):
-        logits, logits_fwd, logits_bwd, features = module._launch_forward(pack)
+        logits, logits_fwd, logits_bwd, features = module._launch_forward(
+            pack, keep_for_backward=bool(getattr(module, "keep_forward_intermediates", True)))
         ctx.module, ctx.pack = module, pack
         extra = [t for t in (logits_fwd, logits_bwd, features) if t is not None]
         if extra:

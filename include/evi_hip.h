@@ -593,6 +593,10 @@ typedef struct EviRetrieverOutput {
                             * [0, batch.num_relations) was seen on the relation-dedupe path (the edge is scored with a
                             * clamped relation row; the reference raises IndexError at the embedding gather,
                             * src/data/components/embedding_store.py:139-150) */
+    void* saved;           /* training only, may be NULL: evi_retriever_saved_bytes() of device memory the forward fills
+                            * with its per-edge intermediates (state_net.0's operand and product rows); handing the same
+                            * buffer to evi_retriever_backward saves it the per-edge forward recomputation */
+    size_t saved_bytes;
 } EviRetrieverOutput;
 
 /* Eval-mode Retriever._forward_impl (src/models/components/retriever.py:195-289): dropout is the
@@ -618,9 +622,11 @@ int evi_retriever_forward(const EviRetrieverWeights* weights, const EviRetriever
  * with respect to the batch's embeddings are not produced (the reference's tables are frozen inputs). */
 size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                               int dde_reverse_rounds, int64_t num_relations);
+size_t evi_retriever_saved_bytes(int64_t E, int D, int H, int direction_mode);
 int evi_retriever_backward(const EviRetrieverWeights* weights, const EviRetrieverBatch* batch, int direction_mode,
                            const float* dlogits, const EviRetrieverWeights* grads, const int64_t* rel_perm,
-                           const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, void* stream);
+                           const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, const void* saved,
+                           size_t saved_bytes, void* stream);
 
 #ifdef __cplusplus
 }

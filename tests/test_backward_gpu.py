@@ -146,3 +146,30 @@ def test_backward_multi_chunk_batch_matches_finite_differences(dev, monkeypatch)
 
     numeric = (f(+1) - f(-1)) / (2 * eps)
     assert abs(analytic - numeric) <= 2e-3 * max(1.0, abs(numeric)), (analytic, numeric)
+
+
+@pytest.mark.parametrize("direction_mode", ["bidirectional", "forward"])
+def test_replayed_forward_intermediates_give_the_recomputing_backwards_bits(dev, direction_mode):
+    """keep_forward_intermediates (the forward's per-edge rows kept in `saved`, the backward replays them) against the
+    backward that recomputes the forward: same kernels on the same values, so every gradient is equal bit for bit — over
+    two chunks and in a single-direction mode (a different `saved` layout)."""
+    from evi_rag_amd.retriever import Retriever
+
+    D = H = 64
+    sb = synthetic.make_batch(24, nodes_per_graph=900, edges_per_graph=3000, emb_dim=D, num_relations=50, seed=3)
+    assert sb.num_edges > 65536
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = 50
+    torch.manual_seed(2)
+    model = Retriever(emb_dim=D, hidden_dim=H, direction_mode=direction_mode).to(dev).eval()
+    model.differentiable = True
+    g = torch.randn(sb.num_edges, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    grads = {}
+    for keep in (True, False):
+        model.keep_forward_intermediates = keep
+        model.zero_grad(set_to_none=True)
+        (model(batch).logits * g).sum().backward()
+        grads[keep] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
+    assert float(grads[True]["state_net.0.weight"].abs().max()) > 0
