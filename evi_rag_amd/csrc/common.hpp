@@ -76,6 +76,9 @@ struct GemmBatch {
     int64_t k_total = 0;   // padded K of the whole operands
     int64_t w_ld = 0;      // row stride of the W planes (elements)
 };
+void gemm_tn_plan(int M, int N, int64_t K, int max_slices, int64_t* Ks_out, int* S_out);
+int launch_gemm_tn_bf16x3(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t K, int64_t Ks, int S,
+                          float* Cparts, hipStream_t st);
 int launch_gemm_nt_bf16x3_splitk(const float* A, int64_t M, int64_t Ktot, int64_t lda, const float* W, int N, int64_t ldw, int Ks,
                                  int S, float* Cparts, void* wsplit, hipStream_t st);
 int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st);

@@ -711,8 +711,9 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     return L;
 }
 
-// C [M, N] (+)= A^T B with A [K, M], B [K, N] row-major and K large: explicit transposes, split-K NT GEMMs (scorer_gemm), and an
-// ordered reduction of the slice results.  Correct and deterministic; the transposes cost two extra passes over A and B.
+// C [M, N] (+)= A^T B with A [K, M], B [K, N] row-major and K large: split-K launches of the TN kernel (gemm_tn.hip) and an
+// ordered reduction of the slice results (deterministic).  The exact-f32 mode of the tests transposes both operands and goes
+// through the f32 NT GEMM slice by slice.
 static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, float* C, int accumulate, const BwdLayout& L,
                    char* ws, hipStream_t st) {
     if (K <= 0) {
@@ -720,28 +721,26 @@ static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, flo
         return EVI_OK;
     }
     const int64_t Kp = (K + 31) / 32 * 32;
-    float* At = reinterpret_cast<float*>(ws + L.At);
-    float* Bt = reinterpret_cast<float*>(ws + L.Bt);
     float* part = reinterpret_cast<float*>(ws + L.tnpart);
-    const dim3 ga((unsigned)((Kp + 31) / 32), (unsigned)((M + 31) / 32)), gb((unsigned)((Kp + 31) / 32), (unsigned)((N + 31) / 32));
-    hipLaunchKernelGGL(k_transpose_pad, ga, dim3(256), 0, st, A, K, M, (int64_t)M, At, Kp);
-    hipLaunchKernelGGL(k_transpose_pad, gb, dim3(256), 0, st, Bm, K, N, (int64_t)N, Bt, Kp);
-    EVI_LAUNCH_CHECK();
     if (!use_f32_gemm()) {
-        // one launch: the K-slices ride in gridDim.y (the output is only (M / 256) x (N / 256) tiles: slices fill the chip)
-        const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
-        int64_t S = (768 + tiles - 1) / tiles;  // ~3 workgroups per CU
-        if (S > kTnMaxSlices) S = kTnMaxSlices;
-        int64_t Ks = ((Kp + S - 1) / S + 31) / 32 * 32;
-        if (Ks < 256) Ks = 256;
-        S = (Kp + Ks - 1) / Ks;
-        int rc = launch_gemm_nt_bf16x3_splitk(At, M, Kp, Kp, Bt, N, Kp, (int)Ks, (int)S, part, ws + L.wsplit2, st);
+        // one launch of the TN kernel (gemm_tn.hip: the operands are read as they lie, k-major); the K-slices ride in
+        // gridDim.y — the output is only (M / 256) x (N / 256) tiles, slices fill the chip
+        int64_t Ks;
+        int S;
+        gemm_tn_plan(M, N, K, kTnMaxSlices, &Ks, &S);
+        int rc = launch_gemm_tn_bf16x3(A, M, M, Bm, N, N, K, Ks, (int)S, part, st);
         if (rc) return rc;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, part, (int)S,
                            (int64_t)M * N, C, accumulate ? 1 : 0);
         EVI_LAUNCH_CHECK();
         return EVI_OK;
     }
+    float* At = reinterpret_cast<float*>(ws + L.At);
+    float* Bt = reinterpret_cast<float*>(ws + L.Bt);
+    const dim3 ga((unsigned)((Kp + 31) / 32), (unsigned)((M + 31) / 32)), gb((unsigned)((Kp + 31) / 32), (unsigned)((N + 31) / 32));
+    hipLaunchKernelGGL(k_transpose_pad, ga, dim3(256), 0, st, A, K, M, (int64_t)M, At, Kp);
+    hipLaunchKernelGGL(k_transpose_pad, gb, dim3(256), 0, st, Bm, K, N, (int64_t)N, Bt, Kp);
+    EVI_LAUNCH_CHECK();
     // exact-f32 mode (tests): slice by slice through the f32 GEMM
     int64_t S = (Kp + kTnSlice - 1) / kTnSlice;
     if (S > kTnMaxSlices) S = kTnMaxSlices;

@@ -240,7 +240,8 @@ struct CombineBwdArgs {
 template <int C4>
 __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
     const CombineArgs& a = b.f;
-    __shared__ float red[4][5 * 1280 + 4];
+    __shared__ float red[4][1280 + 4];
+    __shared__ float cst[4][1280];  // wd, ln_w, ln_b, v: read from LDS where they are used (registers are the scarce resource here)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H = a.H;
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -248,19 +249,17 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
 #pragma unroll
     for (int i = 0; i < C4; ++i) c_lnw[i] = c_lnb[i] = c_ys[i] = c_wd[i] = c_b1[i] = z4;
     float c_S = 0.f;
-    f4 wdv[C4], lnw[C4], lnb[C4], vh[C4];
-#pragma unroll
-    for (int i = 0; i < C4; ++i) {
-        const int d = 4 * lane + 256 * i;
-        if (d < H) {
-            wdv[i] = ld4(a.wd + d);
-            lnw[i] = ld4(a.ln_w + d);
-            lnb[i] = ld4(a.ln_b + d);
-            vh[i] = ld4(a.v + d);
-        } else {
-            wdv[i] = lnw[i] = lnb[i] = vh[i] = z4;
-        }
+    for (int d = threadIdx.x; d < H; d += blockDim.x) {
+        cst[0][d] = a.wd[d];
+        cst[1][d] = a.ln_w[d];
+        cst[2][d] = a.ln_b[d];
+        cst[3][d] = a.v[d];
     }
+    __syncthreads();
+    const float* wdv_ = cst[0];
+    const float* lnw_ = cst[1];
+    const float* lnb_ = cst[2];
+    const float* vh_ = cst[3];
     const float invH = 1.0f / (float)H;
     for (int64_t le = (int64_t)blockIdx.x * 4 + wave; le < a.e_count; le += (int64_t)gridDim.x * 4) {
         const int64_t e = a.e_begin + le;
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                     f4 x = nav * pav[i] + ld4(sb + d);
                     x += dir == 0 ? diff[i] : -diff[i];
                     x += base[i];
-                    x += wdv[i] * negdist;
+                    x += ld4(wdv_ + d) * negdist;
                     v[i] = x;
                     sum += hsum4(x);
                 } else {
@@ -324,9 +323,10 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                 const int d = 4 * lane + 256 * i;
                 if (d < H) {
                     zh[dir][i] = (v[i] - mean) * rstd[dir];
-                    av[dir][i] = zh[dir][i] * lnw[i] + lnb[i];
+                    av[dir][i] = zh[dir][i] * ld4(lnw_ + d) + ld4(lnb_ + d);
+                    const f4 vv = ld4(vh_ + d);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dot = fmaf(vh[i][c], gelu_erf(av[dir][i][c]), dot);
+                    for (int c = 0; c < 4; ++c) dot = fmaf(vv[c], gelu_erf(av[dir][i][c]), dot);
                 }
             }
             lg[dir] = wsum(dot) + a.v[H];
@@ -367,14 +367,15 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                 const int d = 4 * lane + 256 * i;
                 g[i] = z4;
                 if (d < H) {
+                    const f4 vv = ld4(vh_ + d), lw = ld4(lnw_ + d);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float y = gelu_erf(av[dir][i][c]);
-                        const float da = dlg[dir] * vh[i][c] * gelu_erf_grad(av[dir][i][c]);
+                        const float da = dlg[dir] * vv[c] * gelu_erf_grad(av[dir][i][c]);
                         c_ys[i][c] = fmaf(dlg[dir], y, c_ys[i][c]);
                         c_lnw[i][c] = fmaf(da, zh[dir][i][c], c_lnw[i][c]);
                         c_lnb[i][c] += da;
-                        g[i][c] = da * lnw[i][c];
+                        g[i][c] = da * lw[c];
                     }
                     m1 += hsum4(g[i]);
                     m2 += hsum4(g[i] * zh[dir][i]);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                     dzv[dir][i] = dz;
                     st4(b.DZ + row * H + d, dz);
                     dnav += hsum4(dz * pav[i]);
-                    dnd += hsum4(dz * wdv[i]);
+                    dnd += hsum4(dz * ld4(wdv_ + d));
                     c_wd[i] += dz * ndv[dir];
                     c_b1[i] += dz;
                 }
@@ -414,27 +415,23 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
             }
         }
     }
-    // the four waves' column sums, added in wave order; one partial row set per workgroup
-#pragma unroll
-    for (int i = 0; i < C4; ++i) {
-        const int d = 4 * lane + 256 * i;
-        if (d < H) {
-            st4(&red[wave][0 * 1280 + d], c_lnw[i]);
-            st4(&red[wave][1 * 1280 + d], c_lnb[i]);
-            st4(&red[wave][2 * 1280 + d], c_ys[i]);
-            st4(&red[wave][3 * 1280 + d], c_wd[i]);
-            st4(&red[wave][4 * 1280 + d], c_b1[i]);
-        }
-    }
-    if (lane == 0) red[wave][5 * 1280] = c_S;  // wave-uniform: every lane holds the same sum
-    __syncthreads();
+    // the four waves' column sums, added in wave order, one vector at a time through a [4][H] LDS buffer; one partial row set
+    // per workgroup
     float* prow = b.part + (int64_t)blockIdx.x * 5 * H;
-    for (int k = threadIdx.x; k < 5 * H; k += blockDim.x) {
-        const int which = k / H, d = k - which * H;
-        prow[k] = ((red[0][which * 1280 + d] + red[1][which * 1280 + d]) + red[2][which * 1280 + d]) + red[3][which * 1280 + d];
+#pragma unroll
+    for (int which = 0; which < 5; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            if (d < H) st4(&red[wave][d], which == 0 ? c_lnw[i] : which == 1 ? c_lnb[i] : which == 2 ? c_ys[i] : which == 3 ? c_wd[i] : c_b1[i]);
+        }
+        if (which == 0 && lane == 0) red[wave][1280] = c_S;  // wave-uniform: every lane holds the same sum
+        __syncthreads();
+        for (int d = threadIdx.x; d < H; d += blockDim.x) prow[which * H + d] = ((red[0][d] + red[1][d]) + red[2][d]) + red[3][d];
+        if (which == 0 && threadIdx.x == 0)
+            b.part[(int64_t)gridDim.x * 5 * H + blockIdx.x] = ((red[0][1280] + red[1][1280]) + red[2][1280]) + red[3][1280];
     }
-    if (threadIdx.x == 0)
-        b.part[(int64_t)gridDim.x * 5 * H + blockIdx.x] = ((red[0][5 * 1280] + red[1][5 * 1280]) + red[2][5 * 1280]) + red[3][5 * 1280];
 }
 
 // ---- state-row inputs -> per-edge gradients ------------------------------------------------------------------

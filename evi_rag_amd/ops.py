@@ -659,6 +659,29 @@ def group_max(values: torch.Tensor, group: torch.Tensor, num_groups: int) -> tor
 _ACT = {None: 0, "none": 0, "tanh": 1, "sigmoid": 2}
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, accumulate: bool = False) -> torch.Tensor:
+    """a.T @ b for a [K, M], b [K, N] f32 (row-major, K long): the weight gradient of a Linear layer over K rows
+    (`grad_out.t() @ input`).  Split-bf16 arithmetic (~1e-5 relative), split-K with an ordered reduction: two calls give
+    the same bits.  accumulate: added to `out`."""
+    dev = _require_gpu(a, b)
+    a2, b2 = _f32c(a, "a"), _f32c(b, "b")
+    if a2.dim() != 2 or b2.dim() != 2 or a2.size(0) != b2.size(0):
+        raise ValueError(f"gemm_tn: a [K, M] and b [K, N] must share K, got {tuple(a2.shape)} and {tuple(b2.shape)}")
+    K, M = a2.shape
+    N = b2.size(1)
+    if out is None:
+        if accumulate:
+            raise ValueError("gemm_tn: accumulate needs an output tensor")
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    elif out.shape != (M, N) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("gemm_tn: out must be a contiguous f32 [M, N] tensor")
+    lib = _lib.load()
+    ws = _workspace(dev, "gemm_tn", int(lib.evi_gemm_tn_bf16x3_workspace_bytes(M, N)))
+    _lib.check(lib.evi_gemm_tn_bf16x3(_ptr(a2), M, M, _ptr(b2), N, N, K, _ptr(out), 1 if accumulate else 0, ws.data_ptr(),
+                                      ws.numel(), _stream(dev)))
+    return out
+
+
 def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str] = None, *,
                mode: str = "f32") -> torch.Tensor:
     """act(x @ weight.T + bias).  mode "f32": exact f32-input MFMA GEMM; "bf16x3": split-bf16 GEMM

@@ -604,6 +604,13 @@ typedef struct EviRetrieverOutput {
  * configs/model/retriever_module.yaml:25).  direction_mode: 0 bidirectional, 1 forward, 2 backward.
  * Dense contractions run on the split-bf16 GEMM (evi_gemm_nt_bf16x3) unless the environment
  * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM. */
+/* C [M, N] (+)= A^T B for A [K, M], B [K, N] f32 row-major (row strides lda, ldb) and K long: the weight-gradient product of
+ * a Linear layer over K rows (autograd's `grad_out.t() @ input` behind every nn.Linear of src/models/components/retriever.py).
+ * Split-bf16 arithmetic like evi_gemm_nt_bf16x3, split-K with an ordered reduction (deterministic, no float atomics). */
+size_t evi_gemm_tn_bf16x3_workspace_bytes(int M, int N);
+int evi_gemm_tn_bf16x3(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t K, float* C,
+                       int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 size_t evi_retriever_prepare_bytes(int D, int H, int dde_rounds, int dde_reverse_rounds);
 int evi_retriever_prepare(const EviRetrieverWeights* weights, void* prepared, size_t prepared_bytes, void* stream);
 size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,

@@ -471,3 +471,24 @@ def test_prepared_weight_cache_follows_the_weights(dev):
     # train mode never serves from the cache
     model.train()
     assert model._prepared_weights(model._weights_struct(), dev) is None
+
+
+@pytest.mark.parametrize("K,M,N", [(1, 8, 8), (31, 20, 768), (257, 300, 260), (4096, 768, 768), (70001, 768, 20), (65536, 512, 1280)])
+def test_gemm_tn_equals_the_f64_product_and_is_reproducible(dev, K, M, N):
+    """evi_gemm_tn_bf16x3 (a.T @ b, the weight-gradient product): within the split-bf16 bound of the f64 product of the same
+    f32 operands (|err| <= 4e-5 * sum_k |a||b| elementwise), for K that is not a multiple of the k-tile or the slice, M / N
+    that leave partial tiles; bit-identical on a second call; `accumulate` adds."""
+    from evi_rag_amd import ops
+
+    g = torch.Generator(device=dev).manual_seed(K + M + N)
+    a = torch.randn(K, M, device=dev, generator=g)
+    b = torch.randn(K, N, device=dev, generator=g)
+    got = ops.gemm_tn(a, b)
+    want = a.double().t() @ b.double()
+    bound = 4e-5 * (a.double().abs().t() @ b.double().abs()) + 1e-30
+    assert bool(((got.double() - want).abs() <= bound).all()), float(((got.double() - want).abs() / bound).max())
+    again = ops.gemm_tn(a, b)
+    assert torch.equal(got, again)
+    acc = got.clone()
+    ops.gemm_tn(a, b, acc, accumulate=True)
+    assert torch.allclose(acc, 2 * got, rtol=1e-5, atol=1e-4)  # (got + p0) + p1 ... rounds differently from 2 (p0 + p1 ...)
