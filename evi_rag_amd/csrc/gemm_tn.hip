@@ -180,14 +180,16 @@ __global__ void k_tn_reduce(const float* __restrict__ part, int S, int64_t len, 
     out[i] = acc;
 }
 
-// slice plan of a TN product: S slices of Ks rows (Ks a multiple of 32), ~3 workgroups per CU, S a multiple of 8 when it can be
+// slice plan of a TN product: S slices of Ks rows (Ks a multiple of 32).  One workgroup fits per CU (128 KiB of LDS), so the
+// slice count is chosen to fill the 256 CUs once — tiles * S as close below 256 as it gets — which also keeps the partial
+// sums few; max_slices bounds the partial buffer.
 void gemm_tn_plan(int M, int N, int64_t K, int max_slices, int64_t* Ks_out, int* S_out) {
     const int64_t Kp = (K + 31) / 32 * 32;
     const int tiles = ((M + TM - 1) / TM) * ((N + TNN - 1) / TNN);
-    int64_t S = (768 + tiles - 1) / tiles;
+    int64_t S = 256 / tiles;
+    if (S < 1) S = 1;
     if (const char* e = getenv("EVI_TN_SLICES")) S = atoi(e) > 0 ? atoi(e) : S;
     if (S > max_slices) S = max_slices;
-    if (S >= 8) S = S / 8 * 8;
     int64_t Ks = ((Kp + S - 1) / S + 31) / 32 * 32;
     if (Ks < 256) Ks = 256;
     if ((Kp + Ks - 1) / Ks < S) S = (Kp + Ks - 1) / Ks;
