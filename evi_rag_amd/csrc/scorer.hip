@@ -341,7 +341,23 @@ struct CombineArgs {
     float* logits;
     float* logits_fwd;
     float* logits_bwd;
+    uint32_t drop_thr;   // training dropout on the GELU output: a column is dropped when its 16-bit hash < drop_thr (0 = off)
+    float drop_scale;    // 65536 / (65536 - drop_thr)
+    uint64_t drop_seed;
 };
+
+// The dropout multipliers of four consecutive columns d .. d + 3 of row `row` (= direction * E + edge): one splitmix64 word
+// per (row, d / 4) gives four 16-bit uniforms.  Forward and backward call it with the same arguments.
+__device__ inline f4 dropout_mul4(uint64_t seed, int64_t row, int H, int d, uint32_t thr, float scale) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(row * (int64_t)(H >> 2) + (d >> 2) + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    f4 m;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m[c] = (uint32_t)((z >> (16 * c)) & 0xFFFFu) >= thr ? scale : 0.f;
+    return m;
+}
 
 template <int C4>
 __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
             if (d < H) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) y[dir][i][c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
+                if (a.drop_thr) y[dir][i] = y[dir][i] * dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale);
                 dot += hsum4(ld4(a.v + d) * y[dir][i]);
             }
         }
@@ -844,6 +861,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     EVI_REQUIRE(out->logits, "evi_retriever_forward: output logits pointer is null");
     const int dir_fwd = direction_mode != 2, dir_bwd = direction_mode != 1;
     const int dirs = dir_fwd + dir_bwd;
+    EVI_REQUIRE(b->dropout_p >= 0.f && b->dropout_p < 1.f, "dropout probability has to be between 0 and 1, but got %g", (double)b->dropout_p);
+    uint32_t drop_thr = (uint32_t)lrintf(b->dropout_p * 65536.0f);
+    if (drop_thr > 65535u) drop_thr = 65535u;
     const int S = 1 + w->dde_rounds + w->dde_reverse_rounds;
     const int F = 2 * 2 * S;
     const FwdLayout L = fwd_layout(N, E, B, D, H, F, b->num_relations, 2);
@@ -1047,6 +1067,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         c.h1c = out->edge_features ? F32(L.h1n) : nullptr;
         c.v = vhead;
         c.edge_bias = b->edge_bias;
+        c.drop_thr = drop_thr;
+        c.drop_scale = drop_thr ? 65536.0f / (float)(65536u - drop_thr) : 1.0f;
+        c.drop_seed = b->dropout_seed;
         c.logits = out->logits;
         c.logits_fwd = out->logits_fwd;
         c.logits_bwd = out->logits_bwd;

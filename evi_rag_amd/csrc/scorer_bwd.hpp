@@ -325,8 +325,9 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                     zh[dir][i] = (v[i] - mean) * rstd[dir];
                     av[dir][i] = zh[dir][i] * ld4(lnw_ + d) + ld4(lnb_ + d);
                     const f4 vv = ld4(vh_ + d);
+                    const f4 dm = a.drop_thr ? dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale) : f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dot = fmaf(vv[c], gelu_erf(av[dir][i][c]), dot);
+                    for (int c = 0; c < 4; ++c) dot = fmaf(vv[c], dm[c] * gelu_erf(av[dir][i][c]), dot);
                 }
             }
             lg[dir] = wsum(dot) + a.v[H];
@@ -368,10 +369,11 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                 g[i] = z4;
                 if (d < H) {
                     const f4 vv = ld4(vh_ + d), lw = ld4(lnw_ + d);
+                    const f4 dm = a.drop_thr ? dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale) : f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float y = gelu_erf(av[dir][i][c]);
-                        const float da = dlg[dir] * vv[c] * gelu_erf_grad(av[dir][i][c]);
+                        const float y = dm[c] * gelu_erf(av[dir][i][c]);
+                        const float da = dlg[dir] * vv[c] * dm[c] * gelu_erf_grad(av[dir][i][c]);
                         c_ys[i][c] = fmaf(dlg[dir], y, c_ys[i][c]);
                         c_lnw[i][c] = fmaf(da, zh[dir][i][c], c_lnw[i][c]);
                         c_lnb[i][c] += da;

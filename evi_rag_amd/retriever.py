@@ -263,6 +263,7 @@ class Retriever(nn.Module):
         b.edge_attr, b.num_relations = pack["edge_attr"].data_ptr(), pack["num_relations"]
         b.topic_one_hot, b.topic_stride = pack["topic_one_hot"].data_ptr(), int(pack["topic_one_hot"].size(1))
         b.edge_bias = pack["edge_bias"].data_ptr() if pack["edge_bias"] is not None else None
+        b.dropout_p, b.dropout_seed = float(pack.get("dropout_p", 0.0)), int(pack.get("dropout_seed", 0))
         return b
 
     def _launch_forward(self, pack, keep_for_backward: bool = False):
@@ -350,11 +351,12 @@ class Retriever(nn.Module):
         return out, (feats if return_features else None)
 
     def _compute_hide_seek_bias(self, batch: Any, *, edge_index: torch.Tensor) -> Optional[torch.Tensor]:
-        """The hide-and-seek logit penalty in eval mode (hide_seek_cfg.apply_in_eval): each edge is "hidden" with
-        probability p_near / p_far by whether it touches a seed or answer node, and a hidden edge gets bias_near /
-        bias_far added to both directional logits.  reference: _should_apply_hide_seek / _compute_hide_seek_bias,
-        src/models/components/retriever.py:307-367 (the draw is torch.rand on the device, as there)."""
-        if not (self.hide_seek_enabled and self.hide_seek_apply_in_eval):
+        """The hide-and-seek logit penalty (always in training, in evaluation with hide_seek_cfg.apply_in_eval): each edge is
+        "hidden" with probability p_near / p_far by whether it touches a seed or answer node, and a hidden edge gets
+        bias_near / bias_far added to both directional logits.  reference: _should_apply_hide_seek /
+        _compute_hide_seek_bias, src/models/components/retriever.py:307-367 (the draw is torch.rand on the device, as there;
+        it carries no gradient)."""
+        if not (self.hide_seek_enabled and (self.training or self.hide_seek_apply_in_eval)):
             return None
         dev = edge_index.device
         edge_is_near = getattr(batch, "edge_is_near", None)
@@ -382,12 +384,6 @@ class Retriever(nn.Module):
         return torch.where(drop, bias, torch.zeros_like(bias)).to(torch.float32).contiguous()
 
     def _forward_impl(self, batch: Any, *, return_features: bool):
-        if self.training and (float(self.state_net[3].p) > 0.0 or self.hide_seek_enabled):
-            raise NotImplementedError(
-                "evi_rag_amd.Retriever differentiates the deterministic (eval-mode) graph only: the training-time dropout "
-                "inside state_net and the random hide-and-seek bias are not implemented.  Use .eval(), or construct the "
-                "module with dropout_p=0 and hide_seek_cfg={'enabled': False}."
-            )
         param = self.score_head.weight
         dev = param.device
         if dev.type != "cuda":
@@ -488,6 +484,14 @@ class Retriever(nn.Module):
                     topic_one_hot=topic_one_hot,
                     edge_bias=self._compute_hide_seek_bias(batch, edge_index=edge_index),  # None unless apply_in_eval
                     want_features=return_features or self.emit_edge_embeddings)
+        drop_p = float(self.state_net[3].p) if self.training else 0.0
+        if drop_p > 0.0:
+            # nn.Dropout between state_net's GELU and state_net.4 (:179): the mask is a counter-based hash of a per-call seed
+            # drawn from torch's CPU generator (torch.manual_seed makes a run reproducible); the backward regenerates it
+            if drop_p >= 1.0:
+                raise ValueError(f"dropout probability has to be below 1 for training, but got {drop_p}")
+            pack["dropout_p"] = drop_p
+            pack["dropout_seed"] = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         both = self.direction_mode == "bidirectional"
         params = [p for _, p in self._param_fields()]
         differentiable = self.training if self.differentiable is None else bool(self.differentiable)

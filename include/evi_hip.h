@@ -579,6 +579,12 @@ typedef struct EviRetrieverBatch {
     int topic_stride;
     const float* edge_bias;             /* [E] or NULL: added to both directional logits before they are combined
                                            (the hide-and-seek penalty, src/models/components/retriever.py:247-256) */
+    float dropout_p;                    /* training: nn.Dropout(p) between state_net's GELU and state_net.4
+                                         * (src/models/components/retriever.py:179); 0 = off (evaluation) */
+    uint64_t dropout_seed;              /* the mask is a counter-based hash of (seed, direction, edge, column): the backward
+                                         * regenerates it from the same seed.  Not torch's Philox stream: masks are equal in
+                                         * distribution (keep probability 1 - round(p 2^16) / 2^16, kept values scaled by its
+                                         * reciprocal), not bit for bit */
 } EviRetrieverBatch;
 
 /* RetrieverOutput (src/models/components/retriever.py:80-99); any pointer but logits may be NULL. */

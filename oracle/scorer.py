@@ -44,8 +44,10 @@ def projector(x: np.ndarray, w: Dict[str, np.ndarray], name: str) -> np.ndarray:
     return np.tanh(linear(x, w[f"{name}.network.0.weight"], w[f"{name}.network.0.bias"])).astype(np.float32)
 
 
-def score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_raw):
-    """One direction.  reference: Retriever._score_edges (:453-484), _encode_structure (:486-495)."""
+def score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_raw, dropout_mul=None):
+    """One direction.  reference: Retriever._score_edges (:453-484), _encode_structure (:486-495).
+    dropout_mul [E, H] or None: the training-mode nn.Dropout of state_net (:179) with an explicit mask — the kept entries hold
+    1 / (1 - p), the dropped ones 0 (F.dropout's scaling); None is eval mode (identity)."""
     gate = sigmoid(linear(query_repr, w["q_gate.0.weight"], w["q_gate.0.bias"]))
     bias = np.tanh(linear(query_repr, w["q_bias.0.weight"], w["q_bias.0.bias"])).astype(np.float32)
     r_ctx = (relation_repr * gate + bias).astype(np.float32)
@@ -58,13 +60,15 @@ def score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_raw):
     combined = np.concatenate([inter, s, err, dist.astype(np.float32)], axis=-1)
     h = linear(combined, w["state_net.0.weight"], w["state_net.0.bias"])
     h = gelu(layer_norm(h, w["state_net.1.weight"], w["state_net.1.bias"]))
+    if dropout_mul is not None:
+        h = (h * np.asarray(dropout_mul, np.float32)).astype(np.float32)
     feats = linear(h, w["state_net.4.weight"], w["state_net.4.bias"])  # Dropout (index 3) is identity in eval
     logits = linear(feats, w["score_head.weight"], w["score_head.bias"])[:, 0]
     return logits.astype(np.float32), feats.astype(np.float32)
 
 
 def retriever_forward(w: Dict[str, np.ndarray], batch, *, num_rounds: int, num_reverse_rounds: int,
-                      direction_mode: str = "bidirectional") -> Dict[str, np.ndarray]:
+                      direction_mode: str = "bidirectional", dropout_mul=None, edge_bias=None) -> Dict[str, np.ndarray]:
     """Eval-mode forward of the reference Retriever on a flat batch (evi_rag_amd.synthetic
     SyntheticBatch or any object with the same attributes).
     reference: Retriever._forward_impl / _prepare_edge_inputs / _project_nodes /
@@ -88,9 +92,15 @@ def retriever_forward(w: Dict[str, np.ndarray], batch, *, num_rounds: int, num_r
     out: Dict[str, np.ndarray] = {"query_ids": query_ids, "node_struct": ns}
     lf = ff = lb = fb = None
     if direction_mode in ("forward", "bidirectional"):
-        lf, ff = score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_fwd)
+        lf, ff = score_edges(w, query_repr, head_repr, relation_repr, tail_repr, struct_fwd,
+                             None if dropout_mul is None else dropout_mul[0])
     if direction_mode in ("backward", "bidirectional"):
-        lb, fb = score_edges(w, query_repr, tail_repr, relation_repr, head_repr, struct_bwd)
+        lb, fb = score_edges(w, query_repr, tail_repr, relation_repr, head_repr, struct_bwd,
+                             None if dropout_mul is None else dropout_mul[1])
+    if edge_bias is not None:  # the hide-and-seek penalty: added to both directional logits before the combine (:247-256)
+        eb = np.asarray(edge_bias, np.float32)
+        lf = None if lf is None else (lf + eb).astype(np.float32)
+        lb = None if lb is None else (lb + eb).astype(np.float32)
     if direction_mode == "bidirectional":
         st = np.stack([lf, lb], axis=0).astype(np.float64)
         e = np.exp(st - st.max(axis=0, keepdims=True))

@@ -83,7 +83,7 @@ def test_parameter_gradients_match_the_reference_autograd(dev, name, gemm, tol, 
 def test_backward_without_relation_dedupe_and_through_the_loss(dev):
     """(a) dedupe_relations=False (relation rows projected per edge): same gradients as the de-duplicated path;
     (b) the training-shaped use: RetrieverLoss on the differentiable forward, loss.backward(), every parameter gets a finite
-    gradient, and train() mode with dropout_p = 0 takes the same path while dropout_p > 0 is refused."""
+    gradient, and train() mode with dropout_p = 0 takes the same path."""
     from evi_rag_amd.loss import RetrieverLoss
     from evi_rag_amd.retriever import Retriever
 
@@ -109,10 +109,6 @@ def test_backward_without_relation_dedupe_and_through_the_loss(dev):
     for n, p in m.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
     assert float(m.state_net[0].weight.grad.abs().max()) > 0
-    bad = _model_from(z, dev)  # dropout_p = 0.1 (the reference default)
-    bad.train()
-    with pytest.raises(NotImplementedError, match="dropout"):
-        bad(batch)
 
 
 def test_backward_multi_chunk_batch_matches_finite_differences(dev, monkeypatch):
@@ -173,3 +169,86 @@ def test_replayed_forward_intermediates_give_the_recomputing_backwards_bits(dev,
     for n in grads[True]:
         assert torch.equal(grads[True][n], grads[False][n]), n
     assert float(grads[True]["state_net.0.weight"].abs().max()) > 0
+
+
+def _dropout_multipliers(seed, E, H, p):
+    """The kernel's dropout mask restated with numpy integers (csrc/scorer.hip: dropout_mul4): [2, E, H] multipliers."""
+    thr = min(int(round(p * 65536.0)), 65535)
+    scale = np.float32(65536.0 / (65536 - thr))
+    rows = np.arange(2 * E, dtype=np.uint64)[:, None]
+    quads = np.arange(H // 4, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (rows * np.uint64(H // 4) + quads + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = np.stack([(z >> np.uint64(16 * c)) & np.uint64(0xFFFF) for c in range(4)], axis=-1).reshape(2 * E, H)
+    return np.where(u >= thr, scale, np.float32(0)).astype(np.float32).reshape(2, E, H)
+
+
+def test_training_mode_dropout_and_hide_and_seek(dev, monkeypatch):
+    """train() with the reference's defaults (dropout_p = 0.1, hide-and-seek on, retriever.py:105-183): (a) the logits equal
+    the oracle's forward given the SAME dropout mask (the kernel's counter-based mask restated in numpy) — the mask is not
+    torch's Philox stream, parity with the reference is in distribution; (b) the kept fraction is 1 - p; (c) hide-and-seek
+    with p_near = p_far = 1 shifts every logit by exactly bias_near / bias_far; (d) the gradients under dropout agree with
+    central finite differences of the forward run with the same seed."""
+    from oracle import scorer as oscorer
+
+    monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
+    z = np.load(os.path.join(GOLD, "retriever_toy.npz"), allow_pickle=False)
+    batch = _batch_from(z, dev)
+    w = {k[2:]: z[k] for k in z.files if k.startswith("w_")}
+    rounds = z["rounds"].tolist()
+    nb = types.SimpleNamespace(**{k[2:]: z[k] for k in z.files if k.startswith("b_")})
+    E, H = int(batch.edge_index.size(1)), int(z["H"])
+    p = 0.25
+    m = _model_from(z, dev, dropout_p=p, hide_seek_cfg={"enabled": False})
+    m.train()
+    torch.manual_seed(11)
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    torch.manual_seed(11)
+    with torch.no_grad():
+        got = m(batch)
+    mul = _dropout_multipliers(seed, E, H, p)
+    assert abs(float((mul > 0).mean()) - (1 - p)) < 0.02
+    want = oscorer.retriever_forward(w, nb, num_rounds=rounds[0], num_reverse_rounds=rounds[1], direction_mode=str(z["direction"]),
+                                     dropout_mul=mul)
+    np.testing.assert_allclose(got.logits.cpu().numpy(), want["logits"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(got.edge_embeddings.cpu().numpy(), want["edge_embeddings"], rtol=2e-4, atol=2e-4)
+    with torch.no_grad():
+        other = m(batch)  # the next draw: another mask
+    assert float((other.logits - got.logits).abs().max()) > 1e-3
+
+    # (c) hide-and-seek, every edge hidden
+    hs = {"enabled": True, "p_near": 1.0, "p_far": 1.0, "bias_near": -2.0, "bias_far": -0.5, "apply_in_eval": False}
+    mh = _model_from(z, dev, dropout_p=0.0, hide_seek_cfg=hs)
+    with torch.no_grad():
+        plain = mh(batch).logits
+        mh.train()
+        hidden = mh(batch).logits
+    from evi_rag_amd import ops
+    near = ops.qa_edge_mask(batch.edge_index, int(batch.num_nodes), batch.q_local_indices, batch.a_local_indices)
+    shift = torch.where(near, torch.tensor(-2.0, device=dev), torch.tensor(-0.5, device=dev))
+    assert float((hidden - plain - shift).abs().max()) < 1e-5
+
+    # (d) gradients under dropout vs finite differences with the mask held fixed
+    g = torch.from_numpy(z["gvec"]).to(dev)
+    m.zero_grad(set_to_none=True)
+    torch.manual_seed(11)
+    (m(batch).logits * g).sum().backward()
+    direction = {n: torch.randn_like(q) for n, q in m.named_parameters()}
+    analytic = sum(float((q.grad.double() * direction[n].double()).sum()) for n, q in m.named_parameters())
+    eps = 1e-3
+
+    def f(sign):
+        with torch.no_grad():
+            for n, q in m.named_parameters():
+                q.add_(sign * eps * direction[n])
+            torch.manual_seed(11)
+            val = float((m(batch).logits.double() * g.double()).sum())
+            for n, q in m.named_parameters():
+                q.sub_(sign * eps * direction[n])
+        return val
+
+    numeric = (f(+1) - f(-1)) / (2 * eps)
+    assert abs(analytic - numeric) <= 3e-3 * max(1.0, abs(numeric)), (analytic, numeric)

@@ -279,8 +279,15 @@ def test_retriever_error_contract(dev):
     ns.edge_index = ns.edge_index[:, :0]
     out = m(ns)  # empty edge list -> empty outputs (reference :206-207)
     assert out.logits.numel() == 0 and out.edge_embeddings.shape == (0, 16)
-    with pytest.raises(NotImplementedError):
-        m.train()(synthetic.as_namespace(sb, device=dev))
+    # train() with hide-and-seek on (the reference default) needs the seed / answer indices, like the reference (:325-329)
+    ns = synthetic.as_namespace(sb, device=dev)
+    for attr in ("q_local_indices", "a_local_indices", "edge_is_near"):
+        if hasattr(ns, attr):
+            delattr(ns, attr)
+    mh = Retriever(emb_dim=16, hidden_dim=16, hide_seek_cfg={"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0,
+                                                             "bias_far": -0.5}).to(dev)
+    with pytest.raises(ValueError, match="q_local_indices/a_local_indices required for hide-and-seek"):
+        mh.train()(ns)
 
 
 def test_logits_only_forward_matches_full(dev):
