@@ -641,6 +641,16 @@ int evi_retriever_backward(const EviRetrieverWeights* weights, const EviRetrieve
                            const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, const void* saved,
                            size_t saved_bytes, void* stream);
 
+/* ---- training path: optimiser step over flat buffers (csrc/optim.hip) ---------------------------------------------------
+ * evi_grad_norm: norm_out[0] = |scale| * ||g||_2 (f64 accumulation in a fixed order) — the total norm Lightning's
+ * gradient_clip_val feeds to torch.nn.utils.clip_grad_norm_ (configs/trainer/default.yaml:20).
+ * evi_adamw_step: torch.optim.AdamW's update (src/utils/optimization.py:20-35; configs/model/retriever_module.yaml:37-40) on
+ * g * grad_scale * min(1, max_norm / (grad_norm[0] + 1e-6)); grad_norm NULL = no clipping.  step counts from 1. */
+size_t evi_grad_norm_workspace_bytes(int64_t n);
+int evi_grad_norm(const float* g, int64_t n, float scale, float* norm_out, void* workspace, size_t workspace_bytes, void* stream);
+int evi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, float grad_scale, const float* grad_norm, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
