@@ -220,8 +220,8 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     model.emit_edge_embeddings = True
     gemm_ms = ms[2] / iters
     tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    # training-shaped step (§8f-4): differentiable forward -> RetrieverLoss -> backward (evi_retriever_backward recomputes the
-    # forward inside); eval-mode graph (no dropout), gradients of all 25 parameters
+    # training-shaped step (§8f-4): differentiable forward (per-edge intermediates kept) -> RetrieverLoss -> backward
+    # (evi_retriever_backward replays them); eval-mode graph (no dropout), gradients of all 25 parameters
     from evi_rag_amd.loss import RetrieverLoss
 
     loss_fn = RetrieverLoss(infonce_temperature=0.07)
@@ -243,6 +243,33 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     model.differentiable = None
     model.emit_edge_embeddings = True
     model.zero_grad(set_to_none=True)
+    # the whole optimiser step the reference's trainer does per batch (train.RetrieverTrainer): train() mode with the reference's
+    # defaults (dropout_p 0.1, hide-and-seek on: configs/model/retriever_module.yaml:8-25), loss, backward, gradient-norm
+    # clipping at 1.0, AdamW over the flat parameter buffer — on a model of its own (the trainer re-points its parameters)
+    from evi_rag_amd.train import RetrieverTrainer
+
+    torch.manual_seed(0)
+    tmodel = Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1,
+                       hide_seek_cfg={"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0, "bias_far": -0.5,
+                                      "apply_in_eval": False}).to(dev)
+    tmodel.emit_edge_embeddings = False
+    trainer = RetrieverTrainer(tmodel, loss=RetrieverLoss(infonce_temperature=0.07),
+                               optimizer_cfg={"type": "adamw", "lr": 1e-3, "weight_decay": 1e-4}, gradient_clip_val=1.0)
+    first = trainer.training_step(batch)
+    trainer.training_step(batch)
+    torch.cuda.synchronize(dev)
+    step_ms = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        last = trainer.training_step(batch)
+        torch.cuda.synchronize(dev)
+        step_ms.append((time.perf_counter() - t0) * 1e3)
+    t_opt = sum(step_ms) / len(step_ms) * 1e-3
+    train_obj = {"what": "RetrieverTrainer.training_step: train() forward (dropout 0.1, hide-and-seek) -> InfoNCE loss -> backward -> "
+                         "clip_grad_norm 1.0 -> AdamW (flat buffers); same batch 8 times",
+                 "ms_per_step": t_opt * 1e3, "questions_per_s": graphs / t_opt, "loss_first_step": float(first),
+                 "loss_last_step": float(last), "step_ms": step_ms, "parameters": int(trainer.optimizer.numel)}
+    del trainer, tmodel
     exact = os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
     # split-bf16: three bf16 MFMAs per algorithmic product -> executed flops = 3 x algorithmic
     executed_tf, peak, kname = (tf, 157.3, "k_gemm_nt (f32 MFMA 32x32x2)") if exact else \
@@ -263,6 +290,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         "forward_logits_only_ms_per_batch": t_lite * 1e3,
         "metrics_ms_per_batch": t_met * 1e3,
         "train_step_ms_per_batch": t_train * 1e3,
+        "train": train_obj,
         "queries_per_s": graphs / (t_fwd + t_met),
         "edges_per_s": E / t_fwd,
         "roofline": {"bound": "mfma", "achieved": executed_tf, "peak": peak, "unit": "TFLOP/s", "frac": executed_tf / peak,

@@ -37,6 +37,32 @@ def main():
         torch.cuda.synchronize()
         print(f"forward + backward: {e0.elapsed_time(e1) / n:.3f} ms per batch, E={sb.num_edges} N={sb.num_nodes}")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "train":  # the whole optimiser step (train.RetrieverTrainer), reference defaults
+        import time
+
+        from evi_rag_amd.loss import RetrieverLoss
+        from evi_rag_amd.train import RetrieverTrainer
+
+        tm = Retriever(emb_dim=D, hidden_dim=D, dropout_p=float(os.environ.get("EVI_PROFILE_DROPOUT", "0.1")),
+                       hide_seek_cfg={"enabled": os.environ.get("EVI_PROFILE_HIDE_SEEK", "1") == "1", "p_near": 0.7, "p_far": 0.1,
+                                      "bias_near": -2.0, "bias_far": -0.5}).to(dev)
+        tm.emit_edge_embeddings = False
+        tr = RetrieverTrainer(tm, loss=RetrieverLoss(infonce_temperature=0.07))
+        for _ in range(2):
+            tr.training_step(batch)
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            tr.training_step(batch)
+        e1.record()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        print(f"training step: {e0.elapsed_time(e1) / n:.3f} ms per batch on the device clock, host issue time {t_host / n * 1e3:.3f} ms, "
+              f"E={sb.num_edges} N={sb.num_nodes}")
+        return
     for _ in range(3):
         model(batch)
     torch.cuda.synchronize()
