@@ -252,3 +252,46 @@ def test_training_mode_dropout_and_hide_and_seek(dev, monkeypatch):
 
     numeric = (f(+1) - f(-1)) / (2 * eps)
     assert abs(analytic - numeric) <= 3e-3 * max(1.0, abs(numeric)), (analytic, numeric)
+
+
+@pytest.mark.parametrize("D,H", [(320, 256), (768, 768), (1024, 1024), (1280, 1280), (256, 1100)])
+def test_backward_at_wide_dims_matches_finite_differences(dev, monkeypatch, D, H):
+    """The per-edge backward kernels are templated on ceil(width / 256) (1..5 sixteen-byte column groups per lane); the golden
+    batches are narrow (one group).  At the reference's widths — 768 (bge-base), 1024 (the default), 1280 (the maximum) and
+    D != H — the directional derivative along a random parameter direction must equal the central finite difference of the
+    forward (exact-f32 GEMMs), with dropout on, and the replaying and the recomputing backward must agree bit for bit."""
+    from evi_rag_amd.retriever import Retriever
+
+    monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
+    sb = synthetic.make_batch(3, nodes_per_graph=40, edges_per_graph=120, emb_dim=D, num_relations=9, seed=D + H)
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = 9
+    torch.manual_seed(D)
+    model = Retriever(emb_dim=D, hidden_dim=H, dropout_p=0.2, hide_seek_cfg={"enabled": False}).to(dev).train()
+    g = torch.randn(sb.num_edges, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) / sb.num_edges ** 0.5
+    grads = {}
+    for keep in (True, False):
+        model.keep_forward_intermediates = keep
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(77)  # the dropout seed is drawn from torch's CPU generator
+        (model(batch).logits * g).sum().backward()
+        grads[keep] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
+        assert bool(torch.isfinite(grads[True][n]).all()), n
+    direction = {n: torch.randn_like(p) / p.numel() ** 0.5 for n, p in model.named_parameters()}
+    analytic = sum(float((grads[True][n].double() * direction[n].double()).sum()) for n in direction)
+    eps = 2e-3
+
+    def f(sign):
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.add_(sign * eps * direction[n])
+            torch.manual_seed(77)
+            val = float((model(batch).logits.double() * g.double()).sum())
+            for n, p in model.named_parameters():
+                p.sub_(sign * eps * direction[n])
+        return val
+
+    numeric = (f(+1) - f(-1)) / (2 * eps)
+    assert abs(analytic - numeric) <= 5e-3 * max(0.05, abs(numeric)), (analytic, numeric)
