@@ -76,6 +76,9 @@ struct GemmBatch {
     int64_t k_total = 0;   // padded K of the whole operands
     int64_t w_ld = 0;      // row stride of the W planes (elements)
 };
+bool gemm_skinny_fits(int64_t M, int K, int64_t lda, int64_t ldw);
+int launch_gemm_skinny(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw, const float* bias, int act,
+                       float* C, int64_t ldc, hipStream_t st);
 void gemm_tn_plan(int M, int N, int64_t K, int max_slices, int64_t* Ks_out, int* S_out);
 int launch_gemm_tn_bf16x3(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t K, int64_t Ks, int S,
                           float* Cparts, hipStream_t st);

@@ -478,6 +478,8 @@ static bool use_f32_gemm() {
 static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                        const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st,
                        const void* wplanes = nullptr) {
+    // a handful of rows (question-side projections, the non-text embedding): one wave per output column, exact f32 (gemm_skinny.hip)
+    if (gemm_skinny_fits(M, K, lda, ldw)) return launch_gemm_skinny(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
     if (use_f32_gemm()) return launch_gemm_nt(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
     if (wplanes) return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wplanes, N, bias, act, C, ldc, st);
     return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st);
