@@ -249,4 +249,27 @@ class RetrieverTrainer:
             self.scheduler.last_epoch = int(sd.get("scheduler_last_epoch", 0))
 
 
+def _save_checkpoint(self, path) -> None:
+    """A checkpoint in Lightning's layout as far as the reference reads it: `state_dict` with the retriever under the
+    `model.` prefix of `RetrieverModule` (retriever_module.py:59) — what `src/eval.py:_load_checkpoint_strict` (:80-111) and
+    `evi_rag_amd.eval` load — plus `epoch`, `global_step` and this trainer's optimiser / schedule state for resuming.
+    Tensors only: loadable with `torch.load(weights_only=True)`."""
+    sd = self.state_dict()
+    blob = {"state_dict": {f"model.{k}": v.detach().cpu() for k, v in sd["model"].items()}, "epoch": self.current_epoch,
+            "global_step": self.global_step,
+            "optimizer_states": [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in sd["optimizer"].items()}],
+            "lr_schedulers": [{"last_epoch": sd["scheduler_last_epoch"]}]}
+    torch.save(blob, str(path))
+
+
+def _load_checkpoint(self, path) -> None:
+    blob = torch.load(str(path), map_location="cpu", weights_only=True)
+    self.load_state_dict({"model": {k[len("model."):]: v for k, v in blob["state_dict"].items() if k.startswith("model.")},
+                          "optimizer": blob["optimizer_states"][0], "global_step": blob["global_step"], "current_epoch": blob["epoch"],
+                          "scheduler_last_epoch": blob["lr_schedulers"][0]["last_epoch"]})
+
+
+RetrieverTrainer.save_checkpoint = _save_checkpoint
+RetrieverTrainer.load_checkpoint = _load_checkpoint
+
 __all__ = ["RetrieverTrainer", "FlatAdamW", "CosineSchedule", "setup_optimizer"]

@@ -183,3 +183,63 @@ def test_two_rank_training_averages_gradients(dev, tmp_path):
         assert np.allclose(z[r]["__losses"], [l[r] for l in ref_losses], rtol=2e-5)
     mean = sum(sum(l) for l in ref_losses) / (world * w.STEPS)  # equal graph counts: the weighted mean is the plain mean
     assert abs(float(z[0]["__epoch_loss"]) - mean) < 1e-5 and float(z[0]["__epoch_loss"]) == float(z[1]["__epoch_loss"])
+
+
+def test_fit_over_a_packed_split_then_evaluate_from_the_checkpoint(dev, tmp_path):
+    """The whole loop on the data path the evaluation uses: packed split resident in HBM -> PackedLoader (shuffled) ->
+    RetrieverTrainer.fit with the reference's training-mode defaults (dropout, hide-and-seek) -> a Lightning-layout
+    checkpoint -> `eval.load_checkpoint_strict` (what `src/eval.py:80-111` does) into a fresh model -> RetrieverEvaluator.
+    Training must lower the evaluation loss, and the restored model must evaluate exactly like the trained one."""
+    from evi_rag_amd import eval as ev
+    from evi_rag_amd import packed_dataset as pd, synthetic
+    from evi_rag_amd.eval_loop import RetrieverEvaluator
+    from evi_rag_amd.loss import RetrieverLoss
+    from evi_rag_amd.retriever import Retriever
+    from evi_rag_amd.train import RetrieverTrainer
+
+    D = 32
+    base = synthetic.make_batch(24, nodes_per_graph=50, edges_per_graph=160, emb_dim=D, num_relations=11, seed=9)
+    pd.write_packed(tmp_path / "train.packed", pd.samples_from_flat_batch(base))
+    ent = torch.from_numpy(np.random.default_rng(1).standard_normal((int(base.node_embedding_ids.max()) + 1, D)).astype(np.float32))
+    rel = torch.from_numpy(np.random.default_rng(2).standard_normal((11, D)).astype(np.float32))
+    torch.save(ent, tmp_path / "entity_embeddings.pt")
+    torch.save(rel, tmp_path / "relation_embeddings.pt")
+    from evi_rag_amd.embedding_store import GlobalEmbeddingStore
+
+    store = GlobalEmbeddingStore(tmp_path, device=dev)
+    ds = pd.PackedRetrievalDataset(tmp_path / "train.packed", device=dev, embeddings=store)
+    hs = {"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0, "bias_far": -0.5, "apply_in_eval": False}
+    torch.manual_seed(4)
+    model = Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1, hide_seek_cfg=hs).to(dev)
+    loss = RetrieverLoss(infonce_temperature=0.5)
+
+    def evaluate(m):
+        m.eval()
+        return RetrieverEvaluator(m, loss=loss, k_values=[1, 5, 20]).run(pd.PackedLoader(ds, batch_size=8))["metrics"]
+
+    before = evaluate(model)
+    trainer = RetrieverTrainer(model, loss=loss, optimizer_cfg={"type": "adamw", "lr": 3e-3, "weight_decay": 1e-4},
+                               scheduler_cfg={"type": "cosine", "t_max": 6, "eta_min": 1e-6})
+    log = trainer.fit(pd.PackedLoader(ds, batch_size=8, shuffle=True, random_seed=0), max_epochs=6)
+    assert log["steps"] == 18 and len(log["epochs"]) == 6
+    assert log["epochs"][-1]["train/loss"] < log["epochs"][0]["train/loss"]
+    after = evaluate(model)
+    assert after["test/loss"] < before["test/loss"]
+    trainer.save_checkpoint(tmp_path / "last.ckpt")
+    fresh = Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1, hide_seek_cfg=hs).to(dev)
+    ev.load_checkpoint_strict(fresh, str(tmp_path / "last.ckpt"))
+    restored = evaluate(fresh)
+    assert restored == after
+    # resume: a trainer restored from the file continues exactly where the first one stands
+    t2 = RetrieverTrainer(Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1, hide_seek_cfg=hs).to(dev), loss=loss,
+                          optimizer_cfg={"type": "adamw", "lr": 3e-3, "weight_decay": 1e-4}, scheduler_cfg={"type": "cosine", "t_max": 6, "eta_min": 1e-6})
+    t2.load_checkpoint(tmp_path / "last.ckpt")
+    assert t2.global_step == 18 and t2.current_epoch == 6 and t2.optimizer.lr == trainer.optimizer.lr
+    batch = next(iter(pd.PackedLoader(ds, batch_size=8)))
+    torch.manual_seed(1)
+    a = float(trainer.training_step(batch))
+    torch.manual_seed(1)
+    b = float(t2.training_step(batch))
+    assert a == b
+    for p, q in zip(trainer.model.parameters(), t2.model.parameters()):
+        assert torch.equal(p, q)
