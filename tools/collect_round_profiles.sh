@@ -15,6 +15,9 @@ SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
 # 1. per-kernel time of the default bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_profiled.json 2> $O/bench_profiled.err || exit 1
 cp $S/stats/bench_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
+# 1b. the headline leg alone (every launch of the scan kernel has the headline shape: the table's average x 3 = kernel_ms_per_step)
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/stats_h -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-two-stage --no-cpu-baseline --no-graph-eval --no-encode --no-extra-legs > $O/${TAG}_bench_headline_only.json 2> $O/bench_headline.err || exit 1
+cp $S/stats_h/bench_kernel_stats.csv $O/${TAG}_bench_headline_only_kernel_stats.csv
 echo "stats done"
 
 # 2. HBM traffic of the headline scan (f32 single-stage) and of the two-stage scan: separate FETCH / WRITE passes
@@ -49,7 +52,7 @@ echo "per-kernel traffic done"
 
 # 3. SQ counters: scorer forward (+backward), graph kernels, the headline scan
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $S/sq_scorer -o sq -- python3 $R/tools/scorer_forward_profile.py full > /dev/null 2> $O/sq_scorer.err || exit 4
-python3 $R/tools/pmc_kernels.py $S/sq_scorer/sq_counter_collection.csv --match k_gemm k_edge k_state k_split --out $O/${TAG}_pmc_sq_scorer.json --note "tools/scorer_forward_profile.py full (config-3 batch, D=H=768)" > /dev/null
+python3 $R/tools/pmc_kernels.py $S/sq_scorer/sq_counter_collection.csv --match k_gemm k_edge k_state k_split k_combine --out $O/${TAG}_pmc_sq_scorer.json --note "tools/scorer_forward_profile.py full (config-3 batch, D=H=768)" > /dev/null
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $S/sq_scan -o sq -- python3 $R/bench.py $SMALL --no-two-stage > /dev/null 2> $O/sq_scan.err || exit 5
 python3 $R/tools/pmc_kernels.py $S/sq_scan/sq_counter_collection.csv --match k_cosine k_candidates k_query --out $O/${TAG}_pmc_sq_scan.json --note "bench.py headline scan (config 2, f32)" > /dev/null
 echo "sq done"
@@ -57,6 +60,10 @@ echo "sq done"
 # 4. kernel stats of the scorer forward/backward and the graph kernels on their own
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/st_bwd -o s -- python3 $R/tools/scorer_forward_profile.py bwd > /dev/null 2> $O/st_bwd.err || exit 6
 cp $S/st_bwd/s_kernel_stats.csv $O/${TAG}_scorer_fwd_bwd_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/st_train -o s -- python3 $R/tools/scorer_forward_profile.py train > /dev/null 2> $O/st_train.err || exit 6
+cp $S/st_train/s_kernel_stats.csv $O/${TAG}_train_step_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/st_fwd -o s -- python3 $R/tools/scorer_forward_profile.py full > /dev/null 2> $O/st_fwd.err || exit 6
+cp $S/st_fwd/s_kernel_stats.csv $O/${TAG}_scorer_forward_kernel_stats.csv
 for B in 32 512; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $S/st_g$B -o s -- python3 $R/bench.py --graph-kernels --graph-batch $B --steps 20 --warmup 5 > $O/${TAG}_config3_graph_kernels_b$B.json 2> $O/st_g$B.err || exit 7
   cp $S/st_g$B/s_kernel_stats.csv $O/${TAG}_config3_graph_kernels_b${B}_kernel_stats.csv
