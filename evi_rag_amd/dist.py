@@ -68,10 +68,16 @@ class ShardedIndex:
     def __init__(self, local_rows: torch.Tensor, num_rows_total: int, *, group=None,
                  local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
                  row_scale: Optional[torch.Tensor] = None, method: str = "scan",
-                 shadow: Optional[torch.Tensor] = None, exchange: Optional[Callable] = None, fp8_mfma: bool = False) -> None:
+                 shadow: Optional[torch.Tensor] = None, exchange: Optional[Callable] = None, fp8_mfma: bool = False,
+                 lane_groups: Optional[Sequence] = None) -> None:
         """exchange(all_records, local_record): fills `all_records` (world x record bytes, uint8, rank order) from every
         rank's `local_record`, ordered on the CURRENT stream.  Default: one `dist.all_gather_into_tensor` over `group`
-        (RCCL).  Injected by the tests that run two ranks on ONE GPU, where RCCL refuses two ranks per device."""
+        (RCCL).  Injected by the tests that run two ranks on ONE GPU, where RCCL refuses two ranks per device.
+        lane_groups: two process groups over the same ranks, one per pipeline lane of `topk_async`.  A communicator must
+        not be driven from two streams at once, so each lane owns one: the collectives of a lane are ordered among
+        themselves (every rank alternates lanes identically) and never queue behind the other lane's.  Default: `group`
+        for lane 0 and a `dist.new_group` over the same ranks for lane 1 — a collective call, so with the default every
+        process of the job constructs its ShardedIndex at the same point (as `bench.py` does)."""
         self.group = group
         self.fp8_mfma = bool(fp8_mfma)  # e4m3 shard: native fp8 matrix instruction instead of widening to f16 (ops.cosine_topk)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -114,9 +120,17 @@ class ShardedIndex:
         self.two_lanes = os.environ.get("EVI_TWO_LANES", "1") != "0"
         # EVI_FORCE_EXCHANGE=1 runs the exchange even with one rank (rehearses the multi-rank path on one GPU)
         self._exchange = self.world > 1 or (os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and dist.is_initialized())
+        self._lane_groups = [group, group]
+        if lane_groups is not None:
+            if len(lane_groups) != 2:
+                raise ValueError("lane_groups must hold two process groups (one per pipeline lane)")
+            self._lane_groups = list(lane_groups)
+        elif exchange is None and self._exchange and self.two_lanes and dist.is_initialized():
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            self._lane_groups[1] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
 
-    def _rccl_all_gather(self, all_records: torch.Tensor, local_record: torch.Tensor) -> None:
-        dist.all_gather_into_tensor(all_records, local_record, group=self.group)
+    def _rccl_all_gather(self, all_records: torch.Tensor, local_record: torch.Tensor, lane: int = 0) -> None:
+        dist.all_gather_into_tensor(all_records, local_record, group=self._lane_groups[lane] if hasattr(self, "_lane_groups") else self.group)
 
     def _two_stage_workspace(self, queries: torch.Tensor, k: int, lane: int = 0) -> torch.Tensor:
         from . import _lib
@@ -274,7 +288,10 @@ def _topk_async_lanes(self: "ShardedIndex", queries: torch.Tensor, k: int, main)
     with torch.cuda.stream(lane):
         sv, iv = ops.topk_packed_views(p["local"][slot], Q, k)
         _local_scan(self, queries, k, (sv, iv), p["ws"][slot], lane=slot)
-        self._exchange_fn(p["all"][slot], p["local"][slot])
+        if self._exchange_fn == self._rccl_all_gather:
+            self._rccl_all_gather(p["all"][slot], p["local"][slot], lane=slot)  # the lane's own communicator
+        else:
+            self._exchange_fn(p["all"][slot], p["local"][slot])
         ops.topk_merge_packed(p["all"][slot], self.world, Q, k, out=(p["out_s"][slot], p["out_i"][slot]))
         p["done"][slot].record(lane)
     return p["out_s"][slot], p["out_i"][slot], p["done"][slot]

@@ -62,6 +62,15 @@ def _worker(rank, world, port, out_dir):
         idx = edist.ShardedIndex(torch.from_numpy(xn[b[rank]: b[rank + 1]]), N, local_topk=_oracle_local_topk,
                                  merge=_oracle_merge)
         assert (idx.row_begin, idx.row_end) == (b[rank], b[rank + 1])
+        # one communicator per pipeline lane (a communicator must not be driven from two streams at once): lane 1 got a
+        # group of its own over the same ranks, and a record exchanged on either reaches every rank in rank order
+        assert idx._lane_groups[0] is None and idx._lane_groups[1] is not None
+        assert dist.get_process_group_ranks(idx._lane_groups[1]) == list(range(world))
+        for lane in (0, 1):
+            mine = torch.full((16,), rank * 10 + lane, dtype=torch.uint8)
+            everyone = torch.empty(world * 16, dtype=torch.uint8)
+            idx._rccl_all_gather(everyone, mine, lane=lane)
+            assert everyone.view(world, 16)[:, 0].tolist() == [r * 10 + lane for r in range(world)]
         s, i = idx.topk(torch.from_numpy(qn), K)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), i=i.numpy())
         # metric states: each rank saw a different subset of graphs
