@@ -146,9 +146,7 @@ class RetrieverLoss(torch.nn.Module):
 
     def _launch(self, x, targets, edge_batch, num_graphs, near, want_grad):
         dev = x.device
-        counts = torch.bincount(edge_batch.clamp(0, num_graphs - 1), minlength=num_graphs)
-        edge_ptr = torch.zeros(num_graphs + 1, dtype=torch.int64, device=dev)
-        edge_ptr[1:] = torch.cumsum(counts, 0)
+        edge_ptr = ops.ids_to_ptr(edge_batch.clamp(0, num_graphs - 1), num_graphs)
         scalars = torch.zeros(16, dtype=torch.float64, device=dev)
         grouped = (edge_batch[1:] >= edge_batch[:-1]).all() if edge_batch.numel() > 1 else torch.ones((), dtype=torch.bool, device=dev)
         scalars[15] = grouped.to(torch.float64)

@@ -94,8 +94,7 @@ def rank_batch(preds: torch.Tensor, target: Optional[torch.Tensor], batch: Any, 
         ids = i64(ids)
         if ids.numel() != E:
             raise ValueError(f"query_ids/scores mismatch: {tuple(ids.shape)} vs {tuple(scores.shape)}")
-        counts = torch.bincount(ids, minlength=B)
-        edge_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+        edge_ptr = ops.ids_to_ptr(ids, B)  # no device-to-host read (torch.bincount reads the maximum back)
     edge_ptr = i64(edge_ptr)
     if edge_ptr.numel() != B + 1:
         raise ValueError(f"edge ptr length mismatch: {edge_ptr.numel()} vs expected {B + 1}")
@@ -378,10 +377,8 @@ def _bridge_sublists(preds, target, batch, num_graphs, indexes):
     ids = torch.as_tensor(ids).to(device=dev, dtype=torch.long).view(-1)
     tgt = target.detach().reshape(-1).to(dev)
     tgt = (tgt > 0.5) if tgt.dtype != torch.bool else tgt
-    counts = torch.bincount(ids[bridge], minlength=B)
-    edge_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
-    full_counts = torch.bincount(ids, minlength=B)
-    full_ptr = torch.cat([full_counts.new_zeros(1), full_counts.cumsum(0)])
+    edge_ptr = ops.ids_to_ptr(ids[bridge], B)
+    full_ptr = ops.ids_to_ptr(ids, B)
     return scores[bridge].contiguous(), tgt[bridge].contiguous(), edge_ptr, bridge, tgt, full_ptr, B
 
 

@@ -659,6 +659,17 @@ def group_max(values: torch.Tensor, group: torch.Tensor, num_groups: int) -> tor
 _ACT = {None: 0, "none": 0, "tanh": 1, "sigmoid": 2}
 
 
+def ids_to_ptr(ids: torch.Tensor, num_segments: int) -> torch.Tensor:
+    """[num_segments + 1] int64 offsets of the segments of `ids` (values in [0, num_segments); any order): what
+    `cat([0], bincount(ids, minlength=B).cumsum(0))` gives — without torch.bincount's device-to-host read of the maximum."""
+    ids = ids.view(-1).to(torch.long)
+    ptr = torch.zeros(int(num_segments) + 1, dtype=torch.long, device=ids.device)
+    if ids.numel():
+        ptr[1:].scatter_add_(0, ids, torch.ones_like(ids))
+        torch.cumsum(ptr, 0, out=ptr)
+    return ptr
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, accumulate: bool = False) -> torch.Tensor:
     """a.T @ b for a [K, M], b [K, N] f32 (row-major, K long): the weight gradient of a Linear layer over K rows
     (`grad_out.t() @ input`).  Split-bf16 arithmetic (~1e-5 relative), split-K with an ordered reduction: two calls give

@@ -327,8 +327,7 @@ class Retriever(nn.Module):
         if R > 0:  # edges grouped by relation id (stable), for the ordered segment sums of the relation rows' gradients
             attr = pack["edge_attr"].clamp(0, R - 1)
             perm = torch.argsort(attr, stable=True)
-            ptr = torch.zeros(R + 1, dtype=torch.long, device=dev)
-            ptr[1:] = torch.cumsum(torch.bincount(attr, minlength=R), 0)
+            ptr = ops.ids_to_ptr(attr, R)
         need = int(lib.evi_retriever_backward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds, self.dde.num_reverse_rounds, R))
         ws = ops._workspace(dev, "retriever_backward", need)
         dl = dlogits.detach().to(device=dev, dtype=torch.float32).contiguous().view(-1)
