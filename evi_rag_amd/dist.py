@@ -62,6 +62,9 @@ def _default_merge(scores, ids):
     return ops.topk_merge(scores, ids)
 
 
+_LANE1_GROUPS: dict = {}
+
+
 class ShardedIndex:
     """The local shard of a row-sharded, L2-normalised index plus the cross-rank top-k merge."""
 
@@ -127,7 +130,10 @@ class ShardedIndex:
             self._lane_groups = list(lane_groups)
         elif exchange is None and self._exchange and self.two_lanes and dist.is_initialized():
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            self._lane_groups[1] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+            key = (tuple(ranks), dist.get_backend(group))
+            if key not in _LANE1_GROUPS:  # one extra communicator per set of ranks for the life of the process
+                _LANE1_GROUPS[key] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+            self._lane_groups[1] = _LANE1_GROUPS[key]
 
     def _rccl_all_gather(self, all_records: torch.Tensor, local_record: torch.Tensor, lane: int = 0) -> None:
         dist.all_gather_into_tensor(all_records, local_record, group=self._lane_groups[lane] if hasattr(self, "_lane_groups") else self.group)
