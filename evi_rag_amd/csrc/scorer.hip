@@ -31,10 +31,22 @@ namespace evi {
 constexpr int kEdgeChunk = 65536;
 constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default
 
+// Sum over the 64 lanes of a wave, returned wave-uniform.  DPP adds inside the 16-lane rows (quad swaps, half-row and row
+// mirrors), row broadcasts across rows, one readlane of lane 63: seven VALU instructions and a scalar result — the
+// __shfl_xor butterfly compiles to six DEPENDENT ds_bpermute round trips through the LDS pipe (~100 cycles each), and the
+// per-edge kernels reduce 8-16 times per edge.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ inline float wsum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1, 0, 3, 2]
+    v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2, 3, 0, 1]
+    v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_mov<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
+    v += dpp_mov<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // GELU with erf (torch.nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, about two
 // f32 ulps of the result): 13 instructions instead of libm erff's ~40 — k_edge_features and
