@@ -53,7 +53,9 @@ __device__ inline float wsum(float v) {
 // k_state_combine evaluate 48 GELUs per lane per edge and were VALU-bound on them.
 __device__ inline float erf_as(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    // v_rcp_f32 (1 ulp) on a denominator in [1, inf): the correctly rounded __frcp_rn is a ten-instruction division sequence,
+    // a fifth of these kernels' vector instructions; the approximation's own error is twice the reciprocal's
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);

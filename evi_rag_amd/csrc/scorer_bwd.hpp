@@ -26,6 +26,21 @@ __device__ inline float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
     return fmaf(x, 0.3989422804014327f * __expf(-0.5f * x * x), cdf);
 }
+// GELU and its derivative together: one reciprocal and ONE exponential (erf's exp(-(x / sqrt2)^2) is phi's exp(-x^2 / 2)).
+// y is computed by gelu_erf's own expression, so it equals the forward's value bit for bit.
+__device__ inline void gelu_erf_both(float x, float& y, float& dy) {
+    const float xs = x * 0.70710678118654752440f;
+    const float ax = fabsf(xs);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float ex = __expf(-ax * ax);
+    const float er = copysignf(1.0f - p * t * ex, xs);
+    y = 0.5f * x * (1.0f + er);
+    dy = fmaf(x, 0.3989422804014327f * ex, 0.5f * (1.0f + er));
+}
 
 // ---- generic pieces ---------------------------------------------------------------------------------
 __global__ void k_zero_f32(float* __restrict__ p, int64_t n) {
@@ -279,13 +294,13 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                 pav[i] = base[i] = diff[i] = z4;
             }
         }
-        f4 zh[2][C4], av[2][C4];  // normalised pre-activation and the affine LayerNorm output per direction
+        f4 zh[2][C4], yv[2][C4], gv[2][C4];  // normalised pre-activation, GELU of the affine LayerNorm output and GELU' per direction
         float rstd[2] = {0.f, 0.f}, lg[2] = {0.f, 0.f}, navv[2] = {0.f, 0.f}, ndv[2] = {0.f, 0.f};
         int out_row = 0;
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
 #pragma unroll
-            for (int i = 0; i < C4; ++i) zh[dir][i] = av[dir][i] = z4;
+            for (int i = 0; i < C4; ++i) zh[dir][i] = yv[dir][i] = gv[dir][i] = z4;
             if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
             const int64_t row = (int64_t)out_row * a.e_count + le;
             const float nav = a.aux[row * 2], negdist = a.aux[row * 2 + 1];
@@ -323,11 +338,17 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                 const int d = 4 * lane + 256 * i;
                 if (d < H) {
                     zh[dir][i] = (v[i] - mean) * rstd[dir];
-                    av[dir][i] = zh[dir][i] * ld4(lnw_ + d) + ld4(lnb_ + d);
+                    const f4 av = zh[dir][i] * ld4(lnw_ + d) + ld4(lnb_ + d);
                     const f4 vv = ld4(vh_ + d);
                     const f4 dm = a.drop_thr ? dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale) : f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dot = fmaf(vv[c], dm[c] * gelu_erf(av[dir][i][c]), dot);
+                    for (int c = 0; c < 4; ++c) {
+                        float y, dy;
+                        gelu_erf_both(av[c], y, dy);
+                        yv[dir][i][c] = dm[c] * y;   // what state_net.4 sees (dropout applied)
+                        gv[dir][i][c] = dm[c] * dy;
+                        dot = fmaf(vv[c], yv[dir][i][c], dot);
+                    }
                 }
             }
             lg[dir] = wsum(dot) + a.v[H];
@@ -369,11 +390,10 @@ __global__ __launch_bounds__(256) void k_combine_bwd(CombineBwdArgs b) {
                 g[i] = z4;
                 if (d < H) {
                     const f4 vv = ld4(vh_ + d), lw = ld4(lnw_ + d);
-                    const f4 dm = a.drop_thr ? dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale) : f4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float y = dm[c] * gelu_erf(av[dir][i][c]);
-                        const float da = dlg[dir] * vv[c] * dm[c] * gelu_erf_grad(av[dir][i][c]);
+                        const float y = yv[dir][i][c];
+                        const float da = dlg[dir] * vv[c] * gv[dir][i][c];
                         c_ys[i][c] = fmaf(dlg[dir], y, c_ys[i][c]);
                         c_lnw[i][c] = fmaf(da, zh[dir][i][c], c_lnw[i][c]);
                         c_lnb[i][c] += da;
@@ -538,7 +558,10 @@ __global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
                     av[i] = uh[i] * lw + lb;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        sv[i][c] = gelu_erf(av[i][c]);
+                        float y, dy;
+                        gelu_erf_both(av[i][c], y, dy);
+                        sv[i][c] = y;
+                        av[i][c] = dy;  // from here on av holds GELU'
                         gacc = fmaf(gw[c], sv[i][c], gacc);
                     }
                 }
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
                     c_gw[i] += dpre * sv[i];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float da = ds[c] * gelu_erf_grad(av[i][c]);
+                        const float da = ds[c] * av[i][c];
                         c_lw[i][c] = fmaf(da, uh[i][c], c_lw[i][c]);
                         c_lb[i][c] += da;
                         gg[i][c] = da * lw[c];
