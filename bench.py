@@ -729,7 +729,7 @@ class Ctx:
 
 
 def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, want_two_stage=False, sustained_s=0.0,
-                  cpu_rows=0, cpu_seconds=0.0, workload=None, fp8_mfma=False, fp8_ab=False):
+                  cpu_rows=0, cpu_seconds=0.0, workload=None, fp8_mfma=False, fp8_ab=False, many_query=0):
     """One index configuration end to end: build the (sharded) resident index in its storage type, W untimed + K timed
     steps through ShardedIndex.topk_async, live kernel times (hipExtLaunchKernelGGL events inside the library), planted-row
     Hits@k.  Returns the JSON object of the leg (complete on rank 0)."""
@@ -923,6 +923,37 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
                                    "traffic": None, "traffic_source": None}}
         del idx3, out3
 
+    # BASELINE configs[3] also names Q = 512: the same resident shard, 512 queries per step, through the scan (16 passes of 32
+    # queries) and through the GEMM-shaped pass (evi_cosine_topk_gemm: split-bf16 selection + exact re-scoring, same result)
+    many = None
+    if many_query and world == 1 and index_dtype in ("f32", "f16"):
+        gq = torch.Generator(device=dev).manual_seed(seed + 77)
+        rows = torch.randint(0, row_end - row_begin, (many_query,), device=dev, generator=gq)
+        mq = ops.normalize_embeddings(shard[rows].float() + 0.05 * torch.randn(many_query, D, device=dev, generator=gq))
+
+        def wall(fn, iters=4):
+            fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                r = fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / iters, r
+
+        t_scan, r_scan = wall(lambda: ops.cosine_topk(mq, shard, k, row_scale=row_scale, method="scan"))
+        t_gemm, r_gemm = wall(lambda: ops.cosine_topk_gemm(mq, shard, k, row_scale=row_scale))
+        found = float((r_gemm[1][:, :10] == rows.view(-1, 1)).any(dim=1).float().mean().item())
+        many = {"queries_per_step": many_query,
+                "scan": {"ms_per_step": t_scan * 1e3, "queries_per_s": many_query / t_scan,
+                         "what": f"{(many_query + 31) // 32} passes of 32 queries over the shard"},
+                "gemm": {"ms_per_step": t_gemm * 1e3, "queries_per_s": many_query / t_gemm,
+                         "what": "evi_cosine_topk_gemm: one GEMM-shaped pass selects candidates (split-bf16), the scan's arithmetic "
+                                 "re-scores them; proof flag read back once per call",
+                         "executed_TFLOPs_lower_bound": 2.0 * many_query * (row_end - row_begin) * D / t_gemm / 1e12},
+                "identical_ids": bool(torch.equal(r_scan[1], r_gemm[1])), "identical_scores": bool(torch.equal(r_scan[0], r_gemm[0])),
+                "planted_row_in_top10": found}
+        del mq, r_scan, r_gemm
+
     # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
     s_last, i_last = out
     g = gold[(warmup + steps - 1) % n_batches].to(dev).view(Q, 1)
@@ -1005,6 +1036,8 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             result["overlap_vs_f32"] = overlap
         if fp8_native is not None:
             result["fp8_mfma"] = fp8_native
+        if many is not None:
+            result["many_query"] = many
         if ms[2] > ms[0]:
             # the many-query path did the work: the dominant kernel is the split-bf16 GEMM (MFMA-bound), priced by the
             # flops it executes (3 bf16 products per f32 product) against the dense bf16 peak
@@ -1070,7 +1103,7 @@ def main():
             # (12.5 M rows), in the storage type the config names, through the same scan — each with its own roofline
             result["config4_shard"] = run_index_leg(
                 ctx, N=12_500_000, D=768, Q=args.queries, k=args.k, index_dtype="f16", method="scan", steps=args.steps,
-                warmup=args.warmup, seed=3, cpu_rows=1 << 18, cpu_seconds=min(cpu_s, 5.0),
+                warmup=args.warmup, seed=3, cpu_rows=1 << 18, cpu_seconds=min(cpu_s, 5.0), many_query=512,
                 workload="configs[3] per-rank shard: 1/8 of the 100 M x 768 index, f16 storage (what each of 8 MI355X scans per batch)")
             result["config5_shard"] = run_index_leg(
                 ctx, N=12_500_000, D=1024, Q=args.queries, k=args.k, index_dtype="fp8", method="scan", steps=args.steps,
