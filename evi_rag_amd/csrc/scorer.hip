@@ -28,7 +28,16 @@
 
 namespace evi {
 
-constexpr int kEdgeChunk = 65536;
+// edges per chunk of the per-edge pipeline (EVI_EDGE_CHUNK overrides: the tests that need several chunks on small batches)
+constexpr int kEdgeChunkDefault = 65536;
+static int edge_chunk() {
+    static const int v = [] {
+        const char* e = getenv("EVI_EDGE_CHUNK");
+        const int n = e ? atoi(e) : 0;
+        return n >= 64 ? n : kEdgeChunkDefault;
+    }();
+    return v;
+}
 constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default
 
 // Sum over the 64 lanes of a wave, returned wave-uniform.  DPP adds inside the 16-lane rows (quad swaps, half-row and row
@@ -566,7 +575,7 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
         return at;
     };
     L.dedupe = (R > 0 && R <= E) ? 1 : 0;
-    L.ec = E < kEdgeChunk ? (E > 0 ? E : 1) : kEdgeChunk;
+    L.ec = E < edge_chunk() ? (E > 0 ? E : 1) : edge_chunk();
     const size_t f = sizeof(float);
     const size_t n1 = (size_t)(N > 0 ? N : 1), e1 = (size_t)(E > 0 ? E : 1);
     L.node_repr = take(n1 * D * f);
