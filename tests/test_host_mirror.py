@@ -88,3 +88,25 @@ def test_write_packed_layout_and_validation(tmp_path):
     bad = dict(samples[0], edge_index=samples[0]["edge_index"] + 1000)
     with pytest.raises(ValueError, match="out of range"):
         pd.write_packed(tmp_path / "bad2", [bad])
+
+
+def test_cosine_schedule_equals_torch_cosine_annealing():
+    """train.CosineSchedule (closed form, stepped per epoch) against torch.optim.lr_scheduler.CosineAnnealingLR — the
+    scheduler the reference builds (src/models/retriever_module.py:341-354; t_max 200, eta_min 1e-6 in
+    configs/model/retriever_module.yaml:42-47)."""
+    import types
+
+    import torch
+
+    from evi_rag_amd.train import CosineSchedule
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    ref = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20, eta_min=1e-6)
+    ours_opt = types.SimpleNamespace(lr=1e-3, initial_lr=1e-3)
+    ours = CosineSchedule(ours_opt, t_max=20, eta_min=1e-6)
+    for _ in range(20):
+        opt.step()
+        ref.step()
+        ours.step()
+        assert abs(ours_opt.lr - ref.get_last_lr()[0]) < 1e-12
