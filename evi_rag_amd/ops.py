@@ -514,7 +514,9 @@ def edge_batch(edge_index: torch.Tensor, node_ptr: torch.Tensor):
 
 
 def qa_edge_mask(edge_index: torch.Tensor, num_nodes: int, q_local_indices: torch.Tensor,
-                 a_local_indices: torch.Tensor) -> torch.Tensor:
+                 a_local_indices: torch.Tensor, *, deferred_status: Optional[torch.Tensor] = None, deferred_bit: int = 2) -> torch.Tensor:
+    """deferred_status (device int32 [1]): instead of reading the kernel's range-check flag back (one host-device
+    synchronisation per call), OR `deferred_bit` into this sticky word; whoever owns the word checks it once per epoch."""
     dev = _require_gpu(edge_index)
     ei = _i64c(edge_index, "edge_index")
     E = ei.size(1)
@@ -526,7 +528,9 @@ def qa_edge_mask(edge_index: torch.Tensor, num_nodes: int, q_local_indices: torc
     lib = _lib.load()
     _lib.check(lib.evi_qa_edge_mask(_ptr(ei), E, int(num_nodes), _ptr(q), q.numel(), _ptr(a), a.numel(), ws.data_ptr(),
                                     _ptr(out), status.data_ptr(), _stream(dev)))
-    if int(status.item()) != 0:
+    if deferred_status is not None:
+        deferred_status.bitwise_or_((status != 0).to(torch.int32) * int(deferred_bit))
+    elif int(status.item()) != 0:
         raise ValueError("q/a local indices exceed num_nodes; batch collation is invalid.")
     return out.bool()
 

@@ -97,7 +97,7 @@ def compute_edge_batch(edge_index: torch.Tensor, *, node_ptr: torch.Tensor, num_
 
 
 def compute_qa_edge_mask(edge_index: torch.Tensor, *, num_nodes: int, q_local_indices: torch.Tensor,
-                         a_local_indices: torch.Tensor) -> torch.Tensor:
+                         a_local_indices: torch.Tensor, deferred_status: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reference: compute_qa_edge_mask, src/utils/graph_utils.py:107-153."""
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
@@ -105,7 +105,7 @@ def compute_qa_edge_mask(edge_index: torch.Tensor, *, num_nodes: int, q_local_in
         raise ValueError(f"num_nodes must be positive, got {num_nodes}")
     q = torch.as_tensor(q_local_indices, dtype=torch.long)
     a = torch.as_tensor(a_local_indices, dtype=torch.long)
-    return ops.qa_edge_mask(edge_index, int(num_nodes), q, a)
+    return ops.qa_edge_mask(edge_index, int(num_nodes), q, a, deferred_status=deferred_status)
 
 
 class Retriever(nn.Module):
@@ -266,6 +266,14 @@ class Retriever(nn.Module):
         b.dropout_p, b.dropout_seed = float(pack.get("dropout_p", 0.0)), int(pack.get("dropout_seed", 0))
         return b
 
+    def _status_word(self, dev: torch.device) -> torch.Tensor:
+        """The sticky device word behind check_deferred(): bit 0 = a relation id outside num_relations, bit 1 = seed / answer
+        indices outside the batch's nodes (hide-and-seek mask)."""
+        st = getattr(self, "_deferred_status", None)
+        if st is None or st.device != dev:
+            st = self._deferred_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        return st
+
     def _launch_forward(self, pack, keep_for_backward: bool = False):
         """One evi_retriever_forward call: (logits, logits_fwd, logits_bwd, features-or-None), device tensors.
         keep_for_backward: the per-edge intermediates are written to `pack["saved"]` (evi_retriever_saved_bytes) so that the
@@ -289,10 +297,7 @@ class Retriever(nn.Module):
         o.edge_features = features.data_ptr() if features is not None else None
         o.node_struct = None
         # sticky flag for relation ids outside the stated num_relations (no read-back here: check_deferred())
-        st = getattr(self, "_deferred_status", None)
-        if st is None or st.device != dev:
-            st = self._deferred_status = torch.zeros(1, dtype=torch.int32, device=dev)
-        o.status = st.data_ptr()
+        o.status = self._status_word(dev).data_ptr()
         o.saved, o.saved_bytes = None, 0
         if keep_for_backward and E > 0:
             nbytes = int(lib.evi_retriever_saved_bytes(E, D, H, _DIRECTION_CODE[self.direction_mode]))
@@ -366,7 +371,9 @@ class Retriever(nn.Module):
             num_nodes = getattr(batch, "num_nodes", None)
             if num_nodes is None:
                 raise ValueError("Batch missing num_nodes required for hide-and-seek.")
-            near = compute_qa_edge_mask(edge_index, num_nodes=int(num_nodes), q_local_indices=q, a_local_indices=a)
+            # the range check of the seed / answer indices is deferred (bit 1 of the sticky status word: check_deferred())
+            near = compute_qa_edge_mask(edge_index, num_nodes=int(num_nodes), q_local_indices=q, a_local_indices=a,
+                                        deferred_status=self._status_word(dev))
         else:
             near = torch.as_tensor(edge_is_near).to(device=dev, dtype=torch.bool).view(-1)
             if near.numel() != edge_index.size(1):
@@ -537,8 +544,11 @@ def _check_deferred(self) -> None:
     since the last call met an `edge_attr` outside [0, batch.num_relations) on the relation-dedupe path.  Such edges were
     scored with a clamped relation row (never an out-of-bounds read).  One read-back: call once per epoch."""
     st = getattr(self, "_deferred_status", None)
-    if st is not None and int(st.item()) != 0:
+    code = int(st.item()) if st is not None else 0
+    if code != 0:
         st.zero_()
+        if code & 2:
+            raise ValueError("q/a local indices exceed num_nodes; batch collation is invalid.")
         raise IndexError("edge_attr out of range: a relation id exceeds batch.num_relations")
 
 

@@ -207,6 +207,9 @@ class RetrieverTrainer:
         loss_sum = float(self._loss_dev.item()) if self._loss_dev is not None else 0.0
         if self._ungrouped is not None and bool(self._ungrouped.item()):
             raise ValueError("edge_batch is not sorted by graph in a training batch; the loader must group edges by graph.")
+        check = getattr(self.model, "check_deferred", None)
+        if check is not None:
+            check()  # deferred range checks of the epoch's forwards (relation ids, seed / answer indices)
         graphs = float(self._graphs)
         if self._world() > 1:
             from .dist import all_reduce_sum_

@@ -295,3 +295,27 @@ def test_backward_at_wide_dims_matches_finite_differences(dev, monkeypatch, D, H
 
     numeric = (f(+1) - f(-1)) / (2 * eps)
     assert abs(analytic - numeric) <= 5e-3 * max(0.05, abs(numeric)), (analytic, numeric)
+
+
+def test_hide_and_seek_index_check_is_deferred_not_dropped(dev):
+    """The range check of the seed / answer indices behind the hide-and-seek mask no longer costs a host-device
+    synchronisation per forward: a bad index sets a bit in the module's sticky status word and `check_deferred()` raises
+    the reference's ValueError (src/utils/graph_utils.py:107-153) — once per epoch in RetrieverTrainer / RetrieverEvaluator."""
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(3, nodes_per_graph=30, edges_per_graph=90, emb_dim=16, num_relations=7, seed=5)
+    batch = synthetic.as_namespace(sb, device=dev)
+    hs = {"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0, "bias_far": -0.5}
+    m = Retriever(emb_dim=16, hidden_dim=16, dropout_p=0.0, hide_seek_cfg=hs).to(dev).train()
+    with torch.no_grad():
+        m(batch)
+    m.check_deferred()  # clean batch: nothing pending
+    batch.q_local_indices = batch.q_local_indices.clone()
+    batch.q_local_indices[0] = int(batch.num_nodes) + 5
+    if hasattr(batch, "edge_is_near"):
+        del batch.edge_is_near
+    with torch.no_grad():
+        m(batch)  # scored (the bad index is ignored by the mask kernel), flagged
+    with pytest.raises(ValueError, match="q/a local indices exceed num_nodes"):
+        m.check_deferred()
+    m.check_deferred()  # the flag was consumed
