@@ -384,10 +384,12 @@ class Retriever(nn.Module):
             return None
         if self.hide_seek_bias_near == 0.0 and self.hide_seek_bias_far == 0.0:
             return None
-        drop_prob = torch.where(near, torch.tensor(self.hide_seek_p_near, device=dev), torch.tensor(self.hide_seek_p_far, device=dev))
+        # python scalars, not torch.tensor(x, device=...): that is a synchronous host-to-device copy, i.e. a wait for the stream
+        near_f = near.to(torch.float32)
+        drop_prob = near_f * self.hide_seek_p_near + (1.0 - near_f) * self.hide_seek_p_far
         drop = torch.rand_like(drop_prob) < drop_prob
-        bias = torch.where(near, torch.tensor(self.hide_seek_bias_near, device=dev), torch.tensor(self.hide_seek_bias_far, device=dev))
-        return torch.where(drop, bias, torch.zeros_like(bias)).to(torch.float32).contiguous()
+        bias = near_f * self.hide_seek_bias_near + (1.0 - near_f) * self.hide_seek_bias_far
+        return torch.where(drop, bias, torch.zeros_like(bias)).contiguous()
 
     def _forward_impl(self, batch: Any, *, return_features: bool):
         param = self.score_head.weight
