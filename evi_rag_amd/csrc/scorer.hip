@@ -746,7 +746,7 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.kmax = kmax;
     L.At = take((size_t)mx * kmax * f);
     L.Bt = take((size_t)mx * kmax * f);
-    L.tnpart = take((size_t)kTnMaxSlices * mx * mx * f);
+    L.tnpart = take((size_t)kTnMaxSlices * mx * (mx > F ? mx : F) * f);  // slice partials [S][M][N]: M, N <= max(D, H, F)
     L.wsplit2 = take(gemm_bf16x3_workspace_bytes(mx, (int)kmax));  // planes of a whole transposed operand (split-K batch)
     L.colpart = take(((size_t)(kmax + kColsumRows - 1) / kColsumRows + 16) * 5 * mx * f);  // also the scratch row of the five / three column vectors
     L.total = off;

@@ -319,3 +319,28 @@ def test_hide_and_seek_index_check_is_deferred_not_dropped(dev):
     with pytest.raises(ValueError, match="q/a local indices exceed num_nodes"):
         m.check_deferred()
     m.check_deferred()  # the flag was consumed
+
+
+def test_backward_narrow_model_many_edges(dev, monkeypatch):
+    """D = H = 16 with F = 20 structure features (F > max(D, H)) and enough edges for the full slice count of the
+    weight-gradient products: the [S][M][N] partial buffer is sized by max(D, H, F) (it used to be max(D, H): the
+    struct_proj.0 product overran it by a quarter).  Split-bf16 and exact-f32 gradients must agree."""
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(6, nodes_per_graph=700, edges_per_graph=2200, emb_dim=16, num_relations=9, seed=21)
+    assert sb.num_edges > 8192
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = 9
+    g = torch.randn(sb.num_edges, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) / sb.num_edges ** 0.5
+    grads = {}
+    for mode in ("bf16", "f32"):
+        if mode == "f32":
+            monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
+        torch.manual_seed(8)
+        m = Retriever(emb_dim=16, hidden_dim=16).to(dev).eval()
+        m.differentiable = True
+        (m(batch).logits * g).sum().backward()
+        grads[mode] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for n in grads["f32"]:
+        scale = float(grads["f32"][n].abs().max()) + 1e-6
+        assert float((grads["bf16"][n] - grads["f32"][n]).abs().max()) / scale < 3e-4, n

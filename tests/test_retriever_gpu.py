@@ -480,7 +480,8 @@ def test_prepared_weight_cache_follows_the_weights(dev):
     assert model._prepared_weights(model._weights_struct(), dev) is None
 
 
-@pytest.mark.parametrize("K,M,N", [(1, 8, 8), (31, 20, 768), (257, 300, 260), (4096, 768, 768), (70001, 768, 20), (65536, 512, 1280)])
+@pytest.mark.parametrize("K,M,N", [(1, 8, 8), (31, 20, 768), (257, 300, 260), (4096, 768, 768), (70001, 768, 20), (65536, 512, 1280),
+                                   (131072, 768, 20), (1000, 300, 1), (513, 16, 32), (64, 1280, 33)])
 def test_gemm_tn_equals_the_f64_product_and_is_reproducible(dev, K, M, N):
     """evi_gemm_tn_bf16x3 (a.T @ b, the weight-gradient product): within the split-bf16 bound of the f64 product of the same
     f32 operands (|err| <= 4e-5 * sum_k |a||b| elementwise), for K that is not a multiple of the k-tile or the slice, M / N
@@ -492,7 +493,7 @@ def test_gemm_tn_equals_the_f64_product_and_is_reproducible(dev, K, M, N):
     b = torch.randn(K, N, device=dev, generator=g)
     got = ops.gemm_tn(a, b)
     want = a.double().t() @ b.double()
-    bound = 4e-5 * (a.double().abs().t() @ b.double().abs()) + 1e-30
+    bound = 4e-5 * (a.double().abs().t() @ b.double().abs()) + 1e-30  # N <= 32 runs exact f32 FMAs: far inside it
     assert bool(((got.double() - want).abs() <= bound).all()), float(((got.double() - want).abs() / bound).max())
     again = ops.gemm_tn(a, b)
     assert torch.equal(got, again)
