@@ -243,3 +243,17 @@ def test_fit_over_a_packed_split_then_evaluate_from_the_checkpoint(dev, tmp_path
     assert a == b
     for p, q in zip(trainer.model.parameters(), t2.model.parameters()):
         assert torch.equal(p, q)
+
+
+def test_example_script_runs(dev, tmp_path, capsys):
+    """examples/train_and_eval_synthetic.py end to end at a small size: the training loss falls and the evaluation line prints."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("evi_example", os.path.join(os.path.dirname(HERE), "examples", "train_and_eval_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = mod.main(["--graphs", "48", "--nodes", "40", "--edges", "120", "--dim", "32", "--relations", "9", "--batch-size", "16",
+                    "--epochs", "4", "--out", str(tmp_path)])
+    assert log["steps"] == 12 and log["epochs"][-1]["train/loss"] < log["epochs"][0]["train/loss"]
+    out = capsys.readouterr().out
+    assert "questions_per_s" in out and "test/loss" in out
