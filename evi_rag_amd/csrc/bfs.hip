@@ -41,8 +41,8 @@ struct BfsQueueShared {
     int qcount[2];
     int hub_count;
     int big_count;
-    int hubs[kBfsHubCap];
-    int big[kBfsBigCap];
+    int4 hubs[kBfsHubCap];  // (out begin, out end, in begin, in end) of the node's CSR rows: read once, when it is classified
+    int4 big[kBfsBigCap];
 };
 
 __device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __restrict__ q0, int32_t* __restrict__ q1, int64_t n0,
@@ -95,14 +95,14 @@ __device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __re
             if (deg > kBfsWaveDegree) {  // power-law hubs: a 2 000-entry row is 30 trips for a wave, 2 for the workgroup
                 const int slot = atomicAdd(&sh->big_count, 1);
                 if (slot < kBfsBigCap) {
-                    sh->big[slot] = v;
+                    sh->big[slot] = make_int4(ob, oe, ib, ie);
                     continue;
                 }
             }
             if (deg > kBfsThreadDegree) {
                 const int slot = atomicAdd(&sh->hub_count, 1);
                 if (slot < kBfsHubCap) {
-                    sh->hubs[slot] = v;
+                    sh->hubs[slot] = make_int4(ob, oe, ib, ie);
                     continue;
                 }  // list full: expand it here (correct, slower)
             }
@@ -111,16 +111,16 @@ __device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __re
         }
         __syncthreads();
         const int nh = sh->hub_count < kBfsHubCap ? sh->hub_count : kBfsHubCap;
-        for (int h = wave; h < nh; h += kBfsThreads / 64) {
-            const int64_t gv = n0 + sh->hubs[h];
-            if (mode != 2) walk(out_nbr, out_ptr[gv], out_ptr[gv + 1], lane, 64);
-            if (mode != 1) walk(in_nbr, in_ptr[gv], in_ptr[gv + 1], lane, 64);
+        for (int h = wave; h < nh; h += kBfsThreads / 64) {  // the row bounds ride in the list: no second trip to the pointers
+            const int4 r = sh->hubs[h];
+            walk(out_nbr, r.x, r.y, lane, 64);  // an unused direction has an empty range
+            walk(in_nbr, r.z, r.w, lane, 64);
         }
         const int nb = sh->big_count < kBfsBigCap ? sh->big_count : kBfsBigCap;
         for (int h = 0; h < nb; ++h) {
-            const int64_t gv = n0 + sh->big[h];
-            if (mode != 2) walk(out_nbr, out_ptr[gv], out_ptr[gv + 1], tid, kBfsThreads);
-            if (mode != 1) walk(in_nbr, in_ptr[gv], in_ptr[gv + 1], tid, kBfsThreads);
+            const int4 r = sh->big[h];
+            walk(out_nbr, r.x, r.y, tid, kBfsThreads);
+            walk(in_nbr, r.z, r.w, tid, kBfsThreads);
         }
     }
 }
