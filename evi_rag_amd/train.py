@@ -202,6 +202,17 @@ class RetrieverTrainer:
         self.global_step += 1
         return scalars[2]
 
+    def _common_steps(self, loader) -> Optional[int]:
+        """With more than one rank: the smallest number of batches any rank's loader holds this epoch (one small MIN
+        all-reduce), None otherwise or when the loader has no length."""
+        if self._world() <= 1 or not hasattr(loader, "__len__"):
+            return None
+        n = torch.tensor([len(loader)], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            n = n.to(self.optimizer.flat.device)
+        dist.all_reduce(n, op=dist.ReduceOp.MIN, group=self.group)
+        return int(n.item())
+
     def on_train_epoch_end(self) -> Dict[str, float]:
         """The epoch's `train/loss` (batch-size-weighted mean, summed over ranks like sync_dist=True) + scheduler step."""
         loss_sum = float(self._loss_dev.item()) if self._loss_dev is not None else 0.0
@@ -231,7 +242,11 @@ class RetrieverTrainer:
         for _ in range(int(max_epochs)):
             if hasattr(loader, "set_epoch"):
                 loader.set_epoch(self.current_epoch)
+            limit = self._common_steps(loader)
             for i, batch in enumerate(loader):
+                if limit is not None and i >= limit:
+                    break  # another rank's share of the split is one batch shorter: every rank stops there (the gradient
+                           # all-reduce is a collective — an extra step on one rank would wait forever)
                 self.training_step(batch, i)
                 steps += 1
             logs.append(self.on_train_epoch_end())

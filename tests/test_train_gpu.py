@@ -58,7 +58,7 @@ def test_flat_adamw_equals_torch_adamw_with_gradient_clipping(dev):
     assert ours[0]._version > v0  # the kernel's write is visible to version-keyed caches
 
 
-def _manual_reference(dev, batches, steps, lr, t_max=None):
+def _manual_reference(dev, batches, steps, lr, t_max=None, more_steps=0, more_lr=None):
     """The same training loop with torch.optim.AdamW + clip_grad_norm_ around the differentiable mirror; `batches`: the
     per-rank batches whose gradients are averaged (DDP)."""
     sys.path.insert(0, HERE)
@@ -70,7 +70,10 @@ def _manual_reference(dev, batches, steps, lr, t_max=None):
     loss_fn = RetrieverLoss(infonce_temperature=0.5)
     opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=1e-4, foreach=False)
     losses = []
-    for _ in range(steps):
+    for it in range(steps + more_steps):
+        if it == steps and more_lr is not None:
+            for gp in opt.param_groups:
+                gp["lr"] = more_lr
         opt.zero_grad(set_to_none=True)
         acc = None
         per_rank = []
@@ -175,13 +178,16 @@ def test_two_rank_training_averages_gradients(dev, tmp_path):
     sys.path.insert(0, HERE)
     import train_rank_worker as w
 
-    ref_model, ref_losses = _manual_reference(dev, [w.make_batch(0, dev), w.make_batch(1, dev)], w.STEPS, 1e-2)
+    # the workers ran 3 training steps, closed the epoch (one cosine step of t_max 4), then fit() 2 more steps at the new
+    # learning rate; the torch loop below does the same
+    ref_model, ref_losses = _manual_reference(dev, [w.make_batch(0, dev), w.make_batch(1, dev)], w.STEPS, 1e-2, more_steps=2,
+                                              more_lr=1e-6 + (1e-2 - 1e-6) * (1 + math.cos(math.pi / 4)) / 2)
     for n, q in ref_model.named_parameters():
         assert np.array_equal(z[0][n], z[1][n]), n  # the ranks stay in lock-step, bit for bit
-        assert _close(n, z[0][n], q.detach().cpu().numpy(), w.STEPS, 1e-2), n
+        assert _close(n, z[0][n], q.detach().cpu().numpy(), w.STEPS + 2, 1e-2), n
     for r in range(world):
-        assert np.allclose(z[r]["__losses"], [l[r] for l in ref_losses], rtol=2e-5)
-    mean = sum(sum(l) for l in ref_losses) / (world * w.STEPS)  # equal graph counts: the weighted mean is the plain mean
+        assert np.allclose(z[r]["__losses"], [l[r] for l in ref_losses[: w.STEPS]], rtol=2e-5)
+    mean = sum(sum(l) for l in ref_losses[: w.STEPS]) / (world * w.STEPS)  # equal graph counts: the weighted mean is the plain mean
     assert abs(float(z[0]["__epoch_loss"]) - mean) < 1e-5 and float(z[0]["__epoch_loss"]) == float(z[1]["__epoch_loss"])
 
 

@@ -51,6 +51,9 @@ def main():
     for _ in range(STEPS):
         losses.append(trainer.training_step(batch))
     log = trainer.on_train_epoch_end()
+    # fit() over loaders of different lengths (rank 0: 3 batches, rank 1: 2): every rank stops after the common 2
+    fit_log = trainer.fit([batch] * (3 - rank), max_epochs=1)
+    assert fit_log["steps"] == 2, fit_log["steps"]
     out = {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
     out["__losses"] = torch.stack(losses).cpu().numpy()
     out["__epoch_loss"] = np.array(log["train/loss"])
