@@ -668,8 +668,46 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
                                             "GB_per_s": sum(k["algorithmic_bytes"] for k in res["kernels"].values()) / (total_ms * 1e-3) / 1e9}}
     res["gpu_graphs_per_s"] = B / (seq_ms * 1e-3)  # the replayed pipeline; the eager per-kernel legs above include host launch gaps
     res["gpu_epoch_seconds"] = graphs / res["gpu_graphs_per_s"]
+    # shortest-path labelling of the same batch: the (seed, answer) pairs' shortest-path DAG
+    # edges for every graph — one BFS job per seed and per answer, evi_shortest_path_pairs in two passes — through the
+    # mirror `labelling.shortest_path_union_mask_by_pair_batch`, host glue (pair lists, the reference's 6-tuples) included
+    from evi_rag_amd import labelling
+
+    per_graph = []
+    for i in range(B):
+        n0, n1, e0, e1 = int(sb.ptr[i]), int(sb.ptr[i + 1]), int(sb.edge_ptr[i]), int(sb.edge_ptr[i + 1])
+        per_graph.append((n1 - n0, sb.edge_index[0, e0:e1] - n0, sb.edge_index[1, e0:e1] - n0,
+                          (sb.q_local_indices[int(sb.q_ptr[i]): int(sb.q_ptr[i + 1])] - n0).tolist(),
+                          (sb.a_local_indices[int(sb.a_ptr[i]): int(sb.a_ptr[i + 1])] - n0).tolist()))
+
+    def label():
+        gb = labelling.GraphBatch([g[0] for g in per_graph], [g[1] for g in per_graph], [g[2] for g in per_graph], device=dev)
+        return labelling.shortest_path_union_mask_by_pair_batch(gb, [g[3] for g in per_graph], [g[4] for g in per_graph])
+
+    label()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    reps = 3 if B <= 64 else 1
+    for _ in range(reps):
+        lab = label()
+    torch.cuda.synchronize(dev)
+    t_lab = (time.perf_counter() - t0) / reps
+    res["labelling"] = {"what": "GraphBatch (flatten + CSR) + shortest_path_union_mask_by_pair_batch: all (seed, answer) pairs of the batch, "
+                                "undirected, results as the reference's per-graph 6-tuples on the host",
+                        "ms_per_batch": t_lab * 1e3, "graphs_per_s": B / t_lab, "pairs": int(sum(len(r[1]) for r in lab)),
+                        "positive_edges": int(sum(int(r[0].sum()) for r in lab))}
     if cpu:  # the reference's own Python / numpy algorithms, restated (oracle), on a sample of the same graphs
         from oracle import graph as og
+
+        gl = min(4, B)
+        t0 = time.perf_counter()
+        for i in range(gl):
+            n, src, dst, q, a = per_graph[i]
+            want = og.shortest_path_union_mask_by_pair(n, src.tolist(), dst.tolist(), q, a)
+            assert np.array_equal(np.asarray(want[0], bool), lab[i][0]) and list(want[3]) == list(lab[i][3]), "labelling differs from the oracle"
+        cpu_lab = (time.perf_counter() - t0) / gl
+        res["labelling"]["cpu_baseline"] = {"value": 1.0 / cpu_lab, "unit": "graphs/s", "cores": 1, "kind": "port",
+                                            "sample": f"oracle _shortest_path_union_mask_by_pair on {gl} of the graphs, {cpu_lab * 1e3:.1f} ms/graph; results equal"}
 
         g = min(cpu_graphs, B)
         t0 = time.perf_counter()
