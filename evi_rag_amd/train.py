@@ -177,7 +177,16 @@ class RetrieverTrainer:
         if targets is None:
             raise ValueError("Batch missing labels required for retriever loss.")
         self.optimizer.zero_grad()
-        output = model(batch)
+        # the loss reads the logits only: the [E, H] edge features (state_net.4 on the combined rows, a GEMM per chunk) are
+        # not formed — score_head is folded into state_net.4, same logits and gradients
+        keep = getattr(model, "emit_edge_embeddings", None)
+        if keep is not None:
+            model.emit_edge_embeddings = False
+        try:
+            output = model(batch)
+        finally:
+            if keep is not None:
+                model.emit_edge_embeddings = keep
         logits = output.logits
         near = None
         if self.loss.requires_edge_is_near:
