@@ -34,6 +34,37 @@ CHUNK_ROWS = 1 << 16
 EPS = 1e-6
 
 
+# EVI_BENCH_BACKEND=gloo: rehearse the multi-rank control flow on ONE GPU — every rank uses the same device, the process
+# group is gloo and the [Q, k] record exchange is staged through host memory (RCCL refuses two ranks per device).  Sharding,
+# barriers, max-over-ranks timing and the rank-0 JSON line are exactly the N > 1 path; the numbers mean nothing.
+REHEARSAL_BACKEND = os.environ.get("EVI_BENCH_BACKEND", "nccl").lower()
+
+
+def all_reduce_(t, op):
+    if REHEARSAL_BACKEND == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def host_staged_exchange(dev, world):
+    """exchange callable for ShardedIndex under the gloo rehearsal, or None (RCCL all-gather) otherwise."""
+    if REHEARSAL_BACKEND != "gloo" or world <= 1:
+        return None
+
+    def exchange(all_records, local_record):
+        torch.cuda.current_stream(dev).synchronize()
+        host = local_record.cpu()
+        gathered = torch.empty(world * host.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(gathered, host)
+        all_records.copy_(gathered)
+
+    return exchange
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +148,7 @@ def build_queries(dev, shard, row_begin, row_end, n_total, n_batches, Q, D, seed
         local = (gold[mine] - row_begin).to(dev)
         base[mine.to(dev)] = shard.index_select(0, local).float()
     if world > 1:
-        dist.all_reduce(base, op=dist.ReduceOp.SUM)
+        all_reduce_(base, dist.ReduceOp.SUM)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed * 7 + 12345)
     noise = torch.randn((n_batches, Q, D), generator=gen, device=dev, dtype=torch.float32)
@@ -795,7 +826,9 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         raise SystemExit("--topk-method two_stage goes with the f32 index (its f16 shadow is built here)")
     method = method if index_dtype in ("f32", "f16") else "scan"
     shadow = ops.index_shadow_f16(shard) if method == "two_stage" else None
-    index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow, fp8_mfma=fp8_mfma and index_dtype == "fp8")
+    xchg = host_staged_exchange(dev, world)
+    index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow, fp8_mfma=fp8_mfma and index_dtype == "fp8",
+                         exchange=xchg)
     index.workspace = ws
 
     def timed_run(index, steps=steps, warmup=warmup):
@@ -864,7 +897,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             _lib.check(lib.evi_timing_read(ms, launches, 4))
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce_(t, dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, list(ms), list(launches), out
 
@@ -897,7 +930,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             dt = time.perf_counter() - t0
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                all_reduce_(t, dist.ReduceOp.MAX)
                 dt = float(t.item())
             chunks.append(Q * per_chunk / dt)
             n_done += per_chunk
@@ -919,7 +952,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
     two_stage = None
     if method == "scan" and index_dtype == "f32" and want_two_stage:
         shadow = ops.index_shadow_f16(shard)
-        idx2 = ShardedIndex(shard, N, method="two_stage", shadow=shadow)
+        idx2 = ShardedIndex(shard, N, method="two_stage", shadow=shadow, exchange=xchg)
         idx2.workspace = ws
         e2, ms2, l2, out2 = timed_run(idx2)
         failed = idx2.two_stage_failed()
@@ -945,7 +978,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
     # A/B in this process (fp8 index): the same batches through the native fp8 matrix instruction (two e4m3 query pieces)
     fp8_native = None
     if index_dtype == "fp8" and fp8_ab and not fp8_mfma:
-        idx3 = ShardedIndex(shard, N, row_scale=row_scale, method="scan", fp8_mfma=True)
+        idx3 = ShardedIndex(shard, N, row_scale=row_scale, method="scan", fp8_mfma=True, exchange=xchg)
         idx3.workspace = ws
         e3, ms3, l3, out3 = timed_run(idx3)
         b3 = (row_end - row_begin) * D + Q * D * 4 + Q * k * 12 + (row_end - row_begin) * 4
@@ -1109,6 +1142,8 @@ def main():
     args.gpus = world  # under a launcher WORLD_SIZE is authoritative
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    if REHEARSAL_BACKEND == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: the ranks share the device(s)
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible "
                          "(one rank per GPU)")
@@ -1118,7 +1153,10 @@ def main():
     # on the side stream) on a single GPU
     rehearse = world == 1 and os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and "MASTER_ADDR" in os.environ
     if world > 1 or rehearse:
-        dist.init_process_group("nccl", device_id=dev)
+        if REHEARSAL_BACKEND == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from evi_rag_amd import _lib
 

@@ -100,3 +100,30 @@ def test_bench_spawns_its_own_ranks(dev):
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r2.returncode != 0  # rank 1 has no device: reported, not hung
         assert b"launch multi-GPU runs with torch.distributed.run" not in r2.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_control_flow_on_one_gpu(dev):
+    """The whole `bench.py --gpus 2` flow under torch.distributed.run with both ranks on the one GPU (EVI_BENCH_BACKEND=gloo:
+    gloo process group, host-staged record exchange — RCCL refuses two ranks per device): row sharding of the index, the
+    query batch assembled by an all-reduce, `topk_async` lanes with the exchange, barriers, max-over-ranks timing, the
+    two-stage leg, ONE JSON line from rank 0 — and the merged result must still find every planted row."""
+    import json
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["EVI_BENCH_BACKEND"] = "gloo"
+    root = os.path.dirname(HERE)
+    small = ["--steps", "4", "--warmup", "2", "--rows", "300001", "--dim", "128", "--k", "50", "--no-cpu-baseline",
+             "--no-graph-eval", "--no-encode", "--no-extra-legs"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + small,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["sharding"] == "rows/2" and line["scaling"] == "strong"
+    assert line["hits_at_k"]["hits@1"] == 1.0 and line["hits_at_k"]["hits@50"] == 1.0 and line["sorted_ok"]
+    assert line["value"] > 0 and line["two_stage"]["identical_to_f32_scan"] and not line["two_stage"]["proof_failed"]
