@@ -710,7 +710,7 @@ static BwdLayout bwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.DU = take((size_t)2 * ec * D * f);
     L.SX = take((size_t)2 * ec * F * f);
     L.partC = take(((size_t)L.gridC * 5 * H + L.gridC) * f);
-    L.partE = take(((size_t)L.gridE * L.wavesE * 3 * D + (size_t)L.gridE * L.wavesE) * f);
+    L.partE = take(((size_t)L.gridE * L.wavesE * 4 * D + (size_t)L.gridE * L.wavesE) * f);
     L.DDF = take(e1 * H * f);
     L.DH = take(e1 * D * f);
     L.DT = take(e1 * D * f);
@@ -1165,19 +1165,18 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                 hipLaunchKernelGGL(k_edge_translate_bwd<DPL>, dim3(gt > 0 ? gt : 1), dim3(256), 0, st, eb);
             });
             EVI_LAUNCH_CHECK();
-            // the per-wave partial table [gridE * waves][3 D] -> one row (two ordered stages), then into the three gradients
+            // the per-wave partial table [gridE * waves][4 D] -> one row (two ordered stages), then into the four gradients
             const int64_t prow = (int64_t)BL.gridE * BL.wavesE;
-            float* tmp = BF(BL.colpart) + ((prow + kColsumRows - 1) / kColsumRows + 1) * 3 * D;  // behind colsum_into's own scratch
-            hipLaunchKernelGGL(k_zero_f32, dim3(8), dim3(256), 0, st, tmp, (int64_t)3 * D);
-            if ((rc = colsum_into(BF(BL.partE), prow, 3 * D, tmp, 0, BL, bws, st))) return rc;
-            float* dst3[3] = {G(g->struct_ln_w), G(g->struct_ln_b), G(g->struct_gate_w)};
-            for (int q = 0; q < 3; ++q)
-                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, dst3[q], tmp + (int64_t)q * D, (int64_t)D);
-            if ((rc = colsum_into(BF(BL.partE) + prow * 3 * D, prow, 1, G(g->struct_gate_b), 1, BL, bws, st))) return rc;
+            float* tmp = BF(BL.colpart) + ((prow + kColsumRows - 1) / kColsumRows + 1) * 4 * D;  // behind colsum_into's own scratch
+            hipLaunchKernelGGL(k_zero_f32, dim3(8), dim3(256), 0, st, tmp, (int64_t)4 * D);
+            if ((rc = colsum_into(BF(BL.partE), prow, 4 * D, tmp, 0, BL, bws, st))) return rc;
+            float* dst4[4] = {G(g->struct_ln_w), G(g->struct_ln_b), G(g->struct_gate_w), G(g->struct_b)};
+            for (int q = 0; q < 4; ++q)
+                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, dst4[q], tmp + (int64_t)q * D, (int64_t)D);
+            if ((rc = colsum_into(BF(BL.partE) + prow * 4 * D, prow, 1, G(g->struct_gate_b), 1, BL, bws, st))) return rc;
         }
-        // struct_proj.0: weight [D, F] += dU^T SX, bias += column sums of dU
+        // struct_proj.0: weight [D, F] += dU^T SX (its bias gradient, the column sums of dU, came with the kernel's partials)
         if ((rc = tn_gemm(BF(BL.DU), D, BF(BL.SX), F, M, G(g->struct_w), 1, BL, bws, st))) return rc;
-        if ((rc = colsum_into(BF(BL.DU), M, D, G(g->struct_b), 1, BL, bws, st))) return rc;
     }
     if (!bw) return EVI_OK;
     // ---- backward: once per batch ----------------------------------------------------------------------------------

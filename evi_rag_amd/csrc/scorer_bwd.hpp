@@ -470,7 +470,7 @@ struct EdgeBwdArgs {
     float* DBQ;           // [E, D]  drc
     float* DU;            // [dirs * e_count, D]  d (struct_proj.0 output)
     float* SX;            // [dirs * e_count, F]  struct_proj.0 input rows
-    float* part;          // [gridDim.x * waves][3][D]: d struct_ln_w, d struct_ln_b, d struct_gate_w; then [gridDim.x * waves] d struct_gate_b
+    float* part;          // [gridDim.x * waves][4][D]: d struct_ln_w, d struct_ln_b, d struct_gate_w, d struct_proj.0.bias; then [gridDim.x * waves] d struct_gate_b
 };
 
 // Two kernels (one would need ~400 registers per lane: it spilled).
@@ -498,9 +498,9 @@ __global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
     const int half = F >> 1;
     const float inv_d = 1.0f / (float)D;
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f4 c_lw[C4], c_lb[C4], c_gw[C4];
+    f4 c_lw[C4], c_lb[C4], c_gw[C4], c_du[C4];  // column sums: d struct_ln_w, d struct_ln_b, d struct_gate_w, d struct_proj.0.bias (= sum of dU rows)
 #pragma unroll
-    for (int i = 0; i < C4; ++i) c_lw[i] = c_lb[i] = c_gw[i] = z4;
+    for (int i = 0; i < C4; ++i) c_lw[i] = c_lb[i] = c_gw[i] = c_du[i] = z4;
     float c_gb = 0.f;
     const int dirs = (a.dir_fwd ? 1 : 0) + (a.dir_bwd ? 1 : 0);
 
@@ -595,16 +595,20 @@ __global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
 #pragma unroll
             for (int i = 0; i < C4; ++i) {
                 const int d = 4 * lane + 256 * i;
-                if (d < D) st4(b.DU + row * D + d, rstd * (gg[i] - m1 - uh[i] * m2));
+                if (d < D) {
+                    const f4 du = rstd * (gg[i] - m1 - uh[i] * m2);
+                    st4(b.DU + row * D + d, du);
+                    c_du[i] += du;
+                }
             }
             // the struct MLP's input row (wave-uniform values): [ns[a] | ns[b]] with (a, b) = (head, tail) / (tail, head)
             if (lane < F) b.SX[row * F + lane] = lane < half ? na[lane] : nb[lane - half];
         }
     }
-    // column partials: one row set per WAVE ([gridDim.x * waves][3][D] then [gridDim.x * waves] scalars); the host reduces the
+    // column partials: one row set per WAVE ([gridDim.x * waves][4][D] then [gridDim.x * waves] scalars); the host reduces the
     // table in two ordered stages
     const int64_t prow_id = (int64_t)blockIdx.x * waves + wave;
-    float* prow = b.part + prow_id * 3 * D;
+    float* prow = b.part + prow_id * 4 * D;
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
         const int d = 4 * lane + 256 * i;
@@ -612,9 +616,10 @@ __global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
             st4(prow + 0 * D + d, c_lw[i]);
             st4(prow + 1 * D + d, c_lb[i]);
             st4(prow + 2 * D + d, c_gw[i]);
+            st4(prow + 3 * D + d, c_du[i]);
         }
     }
-    if (lane == 0) b.part[(int64_t)gridDim.x * waves * 3 * D + prow_id] = c_gb;
+    if (lane == 0) b.part[(int64_t)gridDim.x * waves * 4 * D + prow_id] = c_gb;
 }
 
 // (2) the product / translation side: p = h * rc * t (nav applied downstream), err = +-(h - t) + rc, -dist = -||err||:
