@@ -69,6 +69,40 @@ def write_tree(root: Path, data_dir: Path, *, emb_dim: int = 16, hidden_dim: int
         "defaults": [{"override hydra_logging": "colorlog"}],
         "run": {"dir": "${paths.log_dir}/${oc.select:hydra.runtime.choices.experiment,${task_name}}_"
                        "${oc.select:hydra.runtime.choices.dataset,${oc.select:dataset.name,unknown}}/runs/fixed"}})
+    # the training side of the tree (configs/train.yaml, experiment/train_retriever.yaml, callbacks/{model_checkpoint,
+    # early_stopping}.yaml, trainer/{default,gpu}.yaml of the reference, in miniature)
+    _dump(cfg / "train.yaml", {
+        "defaults": ["_self_", {"window": "default"}, {"ckpt": "default"}, {"dataset": None}, {"data": None}, {"model": None},
+                     {"callbacks": "train_default"}, {"logger": None}, {"trainer": "default"}, {"paths": "default"}, {"hydra": "default"},
+                     {"experiment": None}, {"optional local": "default"}],
+        "task_name": "train", "tags": ["dev"], "train": True, "test": True, "ckpt_path": None, "seed": 42},
+        header="# @package _global_\n\n")
+    _dump(cfg / "callbacks" / "model_checkpoint.yaml", {"model_checkpoint": {
+        "_target_": "lightning.pytorch.callbacks.ModelCheckpoint", "dirpath": None, "filename": None, "monitor": None, "save_last": None,
+        "save_top_k": 1, "mode": "min", "auto_insert_metric_name": True, "save_weights_only": False}})
+    _dump(cfg / "callbacks" / "early_stopping.yaml", {"early_stopping": {
+        "_target_": "lightning.pytorch.callbacks.EarlyStopping", "monitor": None, "min_delta": 0.0, "patience": 3, "mode": "min"}})
+    _dump(cfg / "callbacks" / "train_default.yaml", {
+        "defaults": ["model_checkpoint", "early_stopping", "_self_"],
+        "model_checkpoint": {"dirpath": "${paths.output_dir}/checkpoints", "filename": "epoch_{epoch:03d}", "monitor": "val/ranking/mrr",
+                             "mode": "max", "save_last": True, "auto_insert_metric_name": False},
+        "early_stopping": {"monitor": "val/ranking/mrr", "patience": 10, "mode": "max"}})
+    _dump(cfg / "trainer" / "default.yaml", {"_target_": "lightning.pytorch.trainer.Trainer", "default_root_dir": "${paths.output_dir}",
+                                             "min_epochs": 50, "max_epochs": 200, "accelerator": "auto", "devices": "auto",
+                                             "precision": "16-mixed", "gradient_clip_val": 1.0, "check_val_every_n_epoch": 10})
+    _dump(cfg / "trainer" / "gpu.yaml", {"defaults": ["default"], "accelerator": "gpu", "devices": 1})
+    _dump(cfg / "experiment" / "train_retriever.yaml", {
+        "defaults": [{"override /data": "retriever"}, {"override /model": "retriever_module"}, {"override /trainer": "gpu"},
+                     {"override /logger": "none"}],
+        "task_name": "retriever_train", "tags": ["retriever"],
+        "trainer": {"min_epochs": 0, "max_epochs": 6, "check_val_every_n_epoch": 1},
+        "model": {"compile_model": False, "loss": {"infonce_weight": 1.0, "bce_weight": 0.0},
+                  "optimizer_cfg": {"type": "adamw", "lr": 3.0e-3, "weight_decay": 1.0e-4},
+                  "scheduler_cfg": {"type": "cosine", "t_max": 6, "eta_min": 1.0e-6, "interval": "epoch"}},
+        "callbacks": {"model_checkpoint": {"monitor": "val/answer/reachability@20", "mode": "max", "filename": "epoch_{epoch:03d}",
+                                           "auto_insert_metric_name": False, "save_weights_only": True},
+                      "early_stopping": {"monitor": "val/answer/reachability@20", "mode": "max", "patience": 10}}},
+        header="# @package _global_\n#\n# Retriever training (single recommended config).\n\n")
     _dump(cfg / "logger" / "none.yaml", {})
     _dump(cfg / "experiment" / "eval_retriever.yaml", {
         "defaults": [{"override /data": "retriever"}, {"override /model": "retriever_module"}, {"override /callbacks": "retriever_eval"},

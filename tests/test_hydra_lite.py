@@ -59,7 +59,7 @@ def test_compose_errors_are_loud(tmp_path):
     with pytest.raises(hl.ConfigError, match="not set"):
         hl.resolve_all({"a": "${oc.env:EVI_SURELY_UNSET_VARIABLE}"})
     with pytest.raises(FileNotFoundError):
-        hl.compose(cfg_dir, "train", [])
+        hl.compose(cfg_dir, "no_such_primary", [])
     assert hl.resolve_all({"a": {"b": [10, 20]}, "c": "x${a.b.1}y", "d": "${a.b}"}) == {"a": {"b": [10, 20]}, "c": "x20y", "d": [10, 20]}
 
 
@@ -190,3 +190,40 @@ def test_overlay_composes_over_the_reference_tree(monkeypatch):
     assert isinstance(model, Retriever) and model.emb_dim == 1024
     with pytest.raises(hl.ConfigError, match="pkg://"):
         hl.compose(REFERENCE_CONFIGS, "eval", ["experiment=eval_retriever", "hydra.searchpath=[pkg://x]"])
+
+
+def test_training_tree_composes(tmp_path, monkeypatch):
+    """`train.yaml` + `experiment=train_retriever` of the miniature tree (same shape as the reference's): the values the training
+    entry point reads — optimiser, schedule, clipping, checkpoint / early-stopping callbacks — come out as the overlays state."""
+    from evi_rag_amd import hydra_lite as hl
+    from tests.config_tree import write_tree
+
+    monkeypatch.setenv("EVI_TEST_PROJECT_ROOT", str(tmp_path / "proj"))
+    cfg = hl.compose(write_tree(tmp_path, tmp_path / "data"), "train", ["experiment=train_retriever", "dataset=toyqa"])
+    assert cfg["model"]["optimizer_cfg"] == {"type": "adamw", "lr": 3.0e-3, "weight_decay": 1.0e-4}
+    assert cfg["model"]["scheduler_cfg"]["type"] == "cosine" and cfg["trainer"]["gradient_clip_val"] == 1.0
+    assert cfg["trainer"]["max_epochs"] == 6 and cfg["trainer"]["check_val_every_n_epoch"] == 1 and cfg["trainer"]["devices"] == 1
+    mc = cfg["callbacks"]["model_checkpoint"]
+    assert mc["monitor"] == "val/answer/reachability@20" and mc["mode"] == "max" and mc["save_last"] is True
+    assert mc["dirpath"].replace("//", "/").endswith("/logs/train_retriever_toyqa/runs/fixed/checkpoints")
+    assert cfg["callbacks"]["early_stopping"]["patience"] == 10 and cfg["seed"] == 42
+
+
+@pytest.mark.skipif(not REFERENCE_CONFIGS.is_dir(), reason="the reference checkout is only present in the build container")
+def test_compose_the_reference_training_tree(monkeypatch):
+    """The real configs/ of the reference: `train.yaml` + `experiment=train_retriever dataset=webqsp` composes, and what the
+    training entry point reads comes out as the YAML files state it (configs/model/retriever_module.yaml:8-47,
+    configs/trainer/default.yaml, configs/experiment/train_retriever.yaml)."""
+    from evi_rag_amd import hydra_lite as hl
+
+    monkeypatch.setenv("PROJECT_ROOT", "/proj")
+    cfg = hl.compose(REFERENCE_CONFIGS, "train", ["experiment=train_retriever", "dataset=webqsp"])
+    assert cfg["model"]["optimizer_cfg"] == {"type": "adamw", "lr": 1.0e-3, "weight_decay": 1.0e-4}
+    assert cfg["model"]["scheduler_cfg"]["type"] == "cosine" and cfg["model"]["scheduler_cfg"]["t_max"] == 200
+    assert cfg["trainer"]["gradient_clip_val"] == 1.0 and cfg["trainer"]["max_epochs"] == 10000 and cfg["trainer"]["check_val_every_n_epoch"] == 1
+    r = cfg["model"]["retriever"]
+    assert r["dropout_p"] == 0.1 and r["hide_seek_cfg"]["enabled"] is True and r["hide_seek_cfg"]["p_near"] == 0.7
+    assert cfg["model"]["loss"]["infonce_weight"] == 1.0 and cfg["model"]["loss"]["bce_weight"] == 0.0
+    mc = cfg["callbacks"]["model_checkpoint"]
+    assert mc["monitor"] == "val/answer/reachability@100" and mc["mode"] == "max" and mc["save_last"] is True
+    assert cfg["callbacks"]["early_stopping"]["patience"] == 10 and cfg["data"]["splits"]["train"] == "train"
