@@ -227,3 +227,31 @@ def test_compose_the_reference_training_tree(monkeypatch):
     mc = cfg["callbacks"]["model_checkpoint"]
     assert mc["monitor"] == "val/answer/reachability@100" and mc["mode"] == "max" and mc["save_last"] is True
     assert cfg["callbacks"]["early_stopping"]["patience"] == 10 and cfg["data"]["splits"]["train"] == "train"
+
+
+@pytest.mark.skipif(not REFERENCE_CONFIGS.is_dir(), reason="the reference checkout is only present in the build container")
+def test_training_overlay_composes_over_the_reference_tree(monkeypatch):
+    """configs/experiment/train_retriever_mi355x.yaml over the reference's real tree: the reference's `train_retriever` with the
+    two `_target_`s swapped and full precision selected; nothing else differs."""
+    import copy
+    import json
+    import re
+    from pathlib import Path
+
+    from evi_rag_amd import hydra_lite as hl
+
+    overlay = Path(__file__).resolve().parent.parent / "configs"
+    monkeypatch.setenv("PROJECT_ROOT", "/proj")
+    base = hl.compose(REFERENCE_CONFIGS, "train", ["experiment=train_retriever", "dataset=webqsp"])
+    cfg = hl.compose(REFERENCE_CONFIGS, "train", ["experiment=train_retriever_mi355x", "dataset=webqsp"], searchpath=[overlay])
+    assert cfg["model"]["retriever"]["_target_"] == "evi_rag_amd.retriever.Retriever" and cfg["model"]["loss"]["_target_"] == "evi_rag_amd.loss.RetrieverLoss"
+    assert cfg["trainer"]["precision"] == "32-true" and cfg["model"]["retriever"]["dropout_p"] == 0.1
+    same = copy.deepcopy(cfg)
+    same["model"]["retriever"]["_target_"] = base["model"]["retriever"]["_target_"]
+    same["model"]["loss"]["_target_"] = base["model"]["loss"]["_target_"]
+    same["trainer"]["precision"] = base["trainer"]["precision"]
+
+    def norm(c):
+        return re.sub(r"\\d{4}-\\d{2}-\\d{2}_\\d{2}-\\d{2}-\\d{2}", "T", json.dumps(c, sort_keys=True).replace("train_retriever_mi355x", "train_retriever"))
+
+    assert norm(same) == norm(base)
