@@ -110,3 +110,55 @@ def test_cosine_schedule_equals_torch_cosine_annealing():
         ref.step()
         ours.step()
         assert abs(ours_opt.lr - ref.get_last_lr()[0]) < 1e-12
+
+
+def test_lmdb_to_packed_reading_loop(tmp_path, monkeypatch):
+    """tools/lmdb_to_packed.py against a stand-in for the `lmdb` package (absent from the build image) with the same
+    open / begin / cursor interface: samples come out in key order with the key as `sample_id`, metadata records and
+    non-sample values are skipped, torch tensors (what the reference pickles) are accepted, `--limit` stops early."""
+    import importlib.util
+    import pickle
+    import sys
+    import types
+
+    import torch
+
+    from evi_rag_amd import packed_dataset as pd, synthetic
+
+    base = synthetic.make_batch(4, nodes_per_graph=12, edges_per_graph=30, emb_dim=8, num_relations=4, seed=3)
+    samples = pd.samples_from_flat_batch(base)
+    records = {}
+    for i, s in enumerate(samples):
+        s = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in s.items() if k != "sample_id"}
+        records[f"q{i:03d}".encode()] = pickle.dumps(s)
+    records[b"__meta__"] = pickle.dumps({"version": 1})
+    records[b"zzz_not_a_sample"] = pickle.dumps([1, 2, 3])
+
+    class _Txn:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def cursor(self):
+            return iter(sorted(records.items()))
+
+    class _Env:
+        def begin(self, write=False):
+            return _Txn()
+
+        def close(self):
+            pass
+
+    fake = types.ModuleType("lmdb")
+    fake.open = lambda path, **kw: _Env()
+    monkeypatch.setitem(sys.modules, "lmdb", fake)
+    spec = importlib.util.spec_from_file_location("lmdb_to_packed", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lmdb_to_packed.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    meta = mod.main(["--lmdb", str(tmp_path / "test.lmdb")])
+    assert meta["num_samples"] == 4 and meta["sample_ids"] == ["q000", "q001", "q002", "q003"]
+    assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_node.npy"), base.ptr)
+    assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_edge.npy"), base.edge_ptr)
+    assert mod.main(["--lmdb", str(tmp_path / "test.lmdb"), "--out", str(tmp_path / "two"), "--limit", "2"])["num_samples"] == 2
