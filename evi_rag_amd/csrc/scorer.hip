@@ -383,7 +383,7 @@ __device__ inline f4 dropout_mul4(uint64_t seed, int64_t row, int H, int d, uint
 }
 
 template <int C4>
-__global__ __launch_bounds__(256) void k_state_combine(CombineArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4 : 1, 8))) void k_state_combine(CombineArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (le >= a.e_count) return;
