@@ -129,7 +129,8 @@ def test_lmdb_to_packed_reading_loop(tmp_path, monkeypatch):
     samples = pd.samples_from_flat_batch(base)
     records = {}
     for i, s in enumerate(samples):
-        s = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in s.items() if k != "sample_id"}
+        s = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in s.items()
+             if k not in ("sample_id", "question", "seed_entity_ids")}  # the core record (:2196-2209); the rest lives in the aux LMDB
         records[f"q{i:03d}".encode()] = pickle.dumps(s)
     records[b"__meta__"] = pickle.dumps({"version": 1})
     records[b"zzz_not_a_sample"] = pickle.dumps([1, 2, 3])
@@ -151,14 +152,28 @@ def test_lmdb_to_packed_reading_loop(tmp_path, monkeypatch):
         def close(self):
             pass
 
+    aux_records = {f"q{i:03d}".encode(): pickle.dumps({"question": f"who is {i}?", "seed_entity_ids": torch.tensor([i])}) for i in range(4)}
+
+    class _AuxTxn(_Txn):
+        def cursor(self):
+            return iter(sorted(aux_records.items()))
+
+    class _AuxEnv(_Env):
+        def begin(self, write=False):
+            return _AuxTxn()
+
+    (tmp_path / "test.aux.lmdb").mkdir()  # the pipeline writes the aux records beside the core ones (<split>.aux.lmdb)
     fake = types.ModuleType("lmdb")
-    fake.open = lambda path, **kw: _Env()
+    fake.open = lambda path, **kw: _AuxEnv() if str(path).endswith(".aux.lmdb") else _Env()
     monkeypatch.setitem(sys.modules, "lmdb", fake)
     spec = importlib.util.spec_from_file_location("lmdb_to_packed", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lmdb_to_packed.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     meta = mod.main(["--lmdb", str(tmp_path / "test.lmdb")])
     assert meta["num_samples"] == 4 and meta["sample_ids"] == ["q000", "q001", "q002", "q003"]
+    import json
+
+    assert json.loads((tmp_path / "test.packed" / "meta.json").read_text())["questions"][2] == "who is 2?"  # merged from the aux records
     assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_node.npy"), base.ptr)
     assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_edge.npy"), base.edge_ptr)
     assert mod.main(["--lmdb", str(tmp_path / "test.lmdb"), "--out", str(tmp_path / "two"), "--limit", "2"])["num_samples"] == 2
