@@ -260,5 +260,74 @@ def build_graph(sample, entity_vocab, relation_vocab, graph_id: str, *, path_mod
                         validate_graph_edges=validate_graph_edges, remove_self_loops=remove_self_loops)[0]
 
 
-__all__ = ["GraphRecord", "CodedGraph", "index_graphs_coded", "label_graphs", "validate_graph_record", "build_graphs",
+__all__ = ["GraphRecord", "CodedGraph", "index_graphs_coded", "label_graphs", "validate_graph_record", "build_graphs", "records_to_samples",
            "build_graph"]
+
+
+def records_to_samples(records: Sequence[GraphRecord], seed_entity_ids: Sequence[Sequence[int]],
+                       answer_entity_ids: Sequence[Sequence[int]], question_emb, *, questions: Optional[Sequence[str]] = None,
+                       num_topics: int = 2, split: str = "") -> List[dict]:
+    """GraphRecords -> the per-sample dictionaries the reference's materialisation stage serialises into its LMDBs
+    (scripts/build_retrieval_pipeline.py:2141-2224: core keys + aux keys), ready for `packed_dataset.write_packed` — the
+    LMDB-free hand-over from graph construction to the HBM-resident split.
+
+    question_emb: [len(records), D] (array or tensor).  seed / answer entity ids are the question's GLOBAL entity ids; their
+    local indices are the positions in the graph's `node_entity_ids` (ids outside the graph are dropped: `_local_indices`,
+    :1742-1744); `topic_one_hot` marks the seeds (`F.one_hot(mask, num_topics)`, :2188-2191)."""
+    q = np.asarray(question_emb.detach().cpu().numpy() if hasattr(question_emb, "detach") else question_emb, dtype=np.float32)
+    if q.ndim != 2 or q.shape[0] != len(records):
+        raise ValueError(f"question_emb must be [{len(records)}, D], got {tuple(q.shape)}")
+    if int(num_topics) < 2:
+        raise ValueError(f"num_topics must be >= 2, got {num_topics}")
+    out = []
+    for i, g in enumerate(records):
+        num_nodes, num_edges = len(g.node_entity_ids), len(g.edge_src)
+        if num_edges <= 0:
+            raise ValueError(f"Invalid graph with zero edges for {g.graph_id} (split={split}). "
+                             "Fix raw parquet/filters and rebuild; empty edge_index is unsupported.")
+        labels = np.asarray(g.positive_triple_mask, dtype=np.float32)
+        if labels.shape[0] != num_edges:
+            raise ValueError(f"Label length mismatch for {g.graph_id}: labels={labels.shape[0]} vs num_edges={num_edges}. "
+                             "Rebuild normalized parquet caches to match the updated schema.")
+        q_entities, a_entities = seed_entity_ids[i], answer_entity_ids[i]
+        if q_entities is None:
+            raise ValueError(f"seed_entity_ids is null for {g.graph_id}")
+        if a_entities is None:
+            raise ValueError(f"answer_entity_ids is null for {g.graph_id}")
+        position = {int(nid): idx for idx, nid in enumerate(g.node_entity_ids)}
+        q_local = [position[int(t)] for t in q_entities if int(t) in position]
+        a_local = [position[int(t)] for t in a_entities if int(t) in position]
+        topic = np.zeros((num_nodes, int(num_topics)), dtype=np.float32)
+        topic[:, 0] = 1.0
+        if q_local:
+            topic[q_local, 0] = 0.0
+            topic[q_local, 1] = 1.0
+        if g.pair_start_node_locals and len(g.pair_edge_counts) != len(g.pair_start_node_locals):
+            raise ValueError(f"pair_edge_counts length {len(g.pair_edge_counts)} != pair_count "
+                             f"{len(g.pair_start_node_locals)} for {g.graph_id}")
+        sample = {
+            "sample_id": g.graph_id,
+            "edge_index": np.asarray([g.edge_src, g.edge_dst], dtype=np.int64),
+            "edge_attr": np.asarray(g.edge_relation_ids, dtype=np.int64),
+            "labels": labels,
+            "num_nodes": num_nodes,
+            "node_global_ids": np.asarray(g.node_entity_ids, dtype=np.int64),
+            "node_embedding_ids": np.asarray(g.node_embedding_ids, dtype=np.int64),
+            "question_emb": q[i: i + 1],
+            "topic_one_hot": topic,
+            "q_local_indices": np.asarray(q_local, dtype=np.int64),
+            "a_local_indices": np.asarray(a_local, dtype=np.int64),
+            "answer_entity_ids": np.asarray(list(a_entities), dtype=np.int64),
+            "answer_entity_ids_len": np.asarray([len(a_entities)], dtype=np.int64),
+            # aux keys (:2212-2224)
+            "question": str(questions[i]) if questions is not None else "",
+            "seed_entity_ids": np.asarray(list(q_entities), dtype=np.int64),
+            "pair_start_node_locals": np.asarray(g.pair_start_node_locals, dtype=np.int64),
+            "pair_answer_node_locals": np.asarray(g.pair_answer_node_locals, dtype=np.int64),
+            "pair_edge_local_ids": np.asarray(g.pair_edge_local_ids, dtype=np.int64),
+            "pair_edge_counts": np.asarray(g.pair_edge_counts, dtype=np.int64),
+        }
+        if g.pair_shortest_lengths is not None and len(g.pair_shortest_lengths) == len(g.pair_start_node_locals):
+            sample["pair_shortest_lengths"] = np.asarray(g.pair_shortest_lengths, dtype=np.int64)
+        out.append(sample)
+    return out

@@ -177,3 +177,39 @@ def test_lmdb_to_packed_reading_loop(tmp_path, monkeypatch):
     assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_node.npy"), base.ptr)
     assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_edge.npy"), base.edge_ptr)
     assert mod.main(["--lmdb", str(tmp_path / "test.lmdb"), "--out", str(tmp_path / "two"), "--limit", "2"])["num_samples"] == 2
+
+
+def test_records_to_samples_is_the_lmdb_free_hand_over(tmp_path):
+    """graph_build.records_to_samples: GraphRecords -> the sample dictionaries of the reference's materialisation stage
+    (scripts/build_retrieval_pipeline.py:2141-2224) -> write_packed, without an LMDB in between: local seed / answer indices
+    by position in node_entity_ids (ids outside the graph dropped), topic one-hot on the seeds, labels from the positive mask,
+    the reference's fail-fast errors."""
+    from evi_rag_amd import packed_dataset as pd
+    from evi_rag_amd.graph_build import GraphRecord, records_to_samples
+
+    g0 = GraphRecord(graph_id="g0", node_entity_ids=[50, 7, 19, 3], node_embedding_ids=[5, 0, 2, 9], node_labels=["a", "b", "c", "d"],
+                     edge_src=[0, 1, 2], edge_dst=[1, 2, 3], edge_relation_ids=[4, 4, 1], positive_triple_mask=[True, False, True],
+                     pair_start_node_locals=[0], pair_answer_node_locals=[3], pair_edge_local_ids=[0, 2], pair_edge_counts=[2],
+                     pair_shortest_lengths=[3])
+    g1 = GraphRecord(graph_id="g1", node_entity_ids=[8, 9], node_embedding_ids=[1, 1], node_labels=["x", "y"], edge_src=[1], edge_dst=[0],
+                     edge_relation_ids=[0], positive_triple_mask=[False], pair_start_node_locals=[], pair_answer_node_locals=[],
+                     pair_edge_local_ids=[], pair_edge_counts=[], pair_shortest_lengths=[])
+    qe = np.arange(16, dtype=np.float32).reshape(2, 8)
+    samples = records_to_samples([g0, g1], [[50, 777], [9]], [[3, 19, 123456], [8]], qe, questions=["q zero", "q one"])
+    s0, s1 = samples
+    assert s0["q_local_indices"].tolist() == [0] and s0["a_local_indices"].tolist() == [3, 2]  # 777 / 123456 are not in the graph
+    assert s0["answer_entity_ids"].tolist() == [3, 19, 123456] and s0["answer_entity_ids_len"].tolist() == [3]
+    assert s0["topic_one_hot"].tolist() == [[0, 1], [1, 0], [1, 0], [1, 0]] and s1["topic_one_hot"].tolist() == [[1, 0], [0, 1]]
+    assert s0["labels"].tolist() == [1.0, 0.0, 1.0] and s0["edge_index"].tolist() == [[0, 1, 2], [1, 2, 3]]
+    assert s0["question_emb"].shape == (1, 8) and s1["question"] == "q one" and s0["seed_entity_ids"].tolist() == [50, 777]
+    meta = pd.write_packed(tmp_path / "p", samples)
+    assert meta["num_samples"] == 2 and meta["sample_ids"] == ["g0", "g1"] and meta["emb_dim"] == 8
+    assert np.load(tmp_path / "p" / "ptr_node.npy").tolist() == [0, 4, 6] and np.load(tmp_path / "p" / "ptr_edge.npy").tolist() == [0, 3, 4]
+    assert np.load(tmp_path / "p" / "pair_shortest_lengths.npy").tolist() == [3]
+    empty = GraphRecord(graph_id="e", node_entity_ids=[1], node_embedding_ids=[1], node_labels=["z"], edge_src=[], edge_dst=[],
+                        edge_relation_ids=[], positive_triple_mask=[], pair_start_node_locals=[], pair_answer_node_locals=[],
+                        pair_edge_local_ids=[], pair_edge_counts=[], pair_shortest_lengths=[])
+    with pytest.raises(ValueError, match="empty edge_index is unsupported"):
+        records_to_samples([empty], [[1]], [[1]], qe[:1])
+    with pytest.raises(ValueError, match="seed_entity_ids is null"):
+        records_to_samples([g1], [None], [[8]], qe[:1])
