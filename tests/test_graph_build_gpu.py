@@ -202,3 +202,49 @@ def test_has_connectivity_golden(dev):
            labelling.has_connectivity(t, ["e"], ["d"], path_mode="qa_directed"),
            labelling.has_connectivity(t, ["zz"], ["a"]), labelling.has_connectivity([], ["a"], ["b"])]
     assert got == z["has_connectivity"].tolist()
+
+
+def test_build_graphs_to_packed_split_to_forward(dev, tmp_path):
+    """The offline chain without an LMDB: raw samples -> build_graphs (device) -> records_to_samples -> write_packed ->
+    PackedRetrievalDataset -> Retriever.forward + metrics.  The golden cases with at least one kept edge go through; what
+    the packed batch holds equals the GraphRecords it was made from."""
+    from evi_rag_amd import graph_build, packed_dataset as pd
+    from evi_rag_amd.embedding_store import GlobalEmbeddingStore
+    from evi_rag_amd.metrics import RetrieverMetricCollection
+    from evi_rag_amd.retriever import Retriever
+
+    z, ent_vocab, rel_vocab, cases = _golden_samples()
+    group = [(c, s) for c, s in cases if not bool(z[f"c{c}_directed"]) and bool(z[f"c{c}_dedup"]) and bool(z[f"c{c}_noloop"])]
+    recs = graph_build.build_graphs([s for _, s in group], ent_vocab, rel_vocab, [f"g{c}" for c, _ in group], path_mode="undirected",
+                                    dedup_edges=True, remove_self_loops=True)
+    keep = [(g, r) for g, r in zip(group, recs) if len(r.edge_src) > 0]
+    assert len(keep) >= 2
+    recs = [r for _, r in keep]
+    seeds = [[ent_vocab.entity_id(e) for e in s.q_entity] for (_, s), _ in keep]
+    answers = [[ent_vocab.entity_id(e) for e in s.a_entity] for (_, s), _ in keep]
+    D = 16
+    rng = np.random.default_rng(0)
+    samples = graph_build.records_to_samples(recs, seeds, answers, rng.standard_normal((len(recs), D)).astype(np.float32),
+                                             questions=[f"question {i}" for i in range(len(recs))])
+    pd.write_packed(tmp_path / "s.packed", samples)
+    n_emb = max(max(r.node_embedding_ids) for r in recs) + 1
+    n_rel = max(max(r.edge_relation_ids) for r in recs) + 1
+    store = GlobalEmbeddingStore.from_tensors(torch.from_numpy(rng.standard_normal((n_emb, D)).astype(np.float32)).to(dev),
+                                              torch.from_numpy(rng.standard_normal((n_rel, D)).astype(np.float32)).to(dev), device=dev)
+    ds = pd.PackedRetrievalDataset(tmp_path / "s.packed", device=dev, embeddings=store)
+    batch = next(iter(pd.PackedLoader(ds, batch_size=len(recs))))
+    ptr = batch.ptr.cpu().tolist()
+    for i, r in enumerate(recs):
+        e0, e1 = int(batch.edge_ptr[i]), int(batch.edge_ptr[i + 1])
+        assert (batch.edge_index[0, e0:e1] - ptr[i]).cpu().tolist() == r.edge_src
+        assert batch.edge_attr[e0:e1].cpu().tolist() == r.edge_relation_ids
+        assert (batch.labels[e0:e1] > 0.5).cpu().tolist() == list(r.positive_triple_mask)
+        assert batch.node_embedding_ids[ptr[i]: ptr[i + 1]].cpu().tolist() == r.node_embedding_ids
+    torch.manual_seed(0)
+    model = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
+    with torch.no_grad():
+        out = model(batch)
+    assert out.logits.numel() == int(batch.edge_ptr[-1]) and bool(torch.isfinite(out.logits).all())
+    coll = RetrieverMetricCollection([1, 5])
+    coll.update(preds=out.logits, target=batch.labels > 0.5, indexes=out.query_ids, batch=batch, num_graphs=len(recs))
+    assert all(np.isfinite(float(v)) for v in coll.compute().values())
