@@ -1,17 +1,19 @@
 // Backward of the edge scorer: gradients of a scalar loss with respect to every Retriever parameter, given
-// dL/dlogits — the autograd of src/models/components/retriever.py:195-289, 403-507 in eval-mode arithmetic (dropout and the
-// hide-and-seek bias are the identity / absent, as in the forward this library implements).  Included by scorer.hip (it
-// needs the forward's device helpers and argument structs); everything is inside namespace evi.
+// dL/dlogits — the autograd of src/models/components/retriever.py:195-289, 403-507, with the training-mode dropout of state_net
+// (the mask is regenerated from the forward's seed: dropout_mul4) and the hide-and-seek bias (an additive constant: no
+// gradient of its own).  Included by scorer.hip (it needs the forward's device helpers and argument structs); everything is
+// inside namespace evi.
 //
-// Structure.  The forward is RECOMPUTED chunk by chunk (no tensors are kept from the forward call), then per chunk:
+// Structure.  The per-edge forward (operand rows P / RCX / XS, product rows PA / RC / SB, aux) is REPLAYED from the buffer the
+// training forward kept (EviRetrieverOutput.saved) — or recomputed chunk by chunk when none was kept — then per chunk:
 //   k_combine_bwd        logits -> pre-LayerNorm state rows:  dz_dir [2 Ec, H], and what the factored state_net.0 needs
 //                        (dPA = nav_f dz_f + nav_b dz_b, dRC = dz_f + dz_b, dDiff = dz_f - dz_b, dnav, d(-dist)), plus the
 //                        column sums behind d state_net.1.{weight,bias}, d wd, d state_net.0.bias and the folded head
 //   three NT GEMMs       dP = dPA Wa, dRCX = dRC Wc, dXS = dz Wb        (weights transposed once: [D, H] row-major)
 //   k_edge_translate_bwd -> per-edge dh, dt, d rel_repr row, d gate_q / d bias_q contributions
 //   k_edge_struct_bwd    -> d struct pre-activation rows (dU), the struct MLP's input rows, its LayerNorm / gate column partials
-//   TN products          dWa += dPA^T P, dWc += dRC^T RCX, dWb += dz^T XS, dWs += dU^T struct   (tn_gemm: explicit
-//                        transposes + split-K NT GEMMs + an ordered reduction — correct first, not yet fast)
+//   TN products          dWa += dPA^T P, dWc += dRC^T RCX, dWb += dz^T XS, dWs += dU^T struct   (tn_gemm: the TN split-bf16
+//                        kernel of gemm_tn.hip — operands read as they lie, split-K + an ordered reduction)
 // and once per batch: node / relation / graph segment sums (f64, CSR- or sort-ordered: no float atomics), the tanh / sigmoid
 // backward of the projections and their TN products.  All reductions run in a fixed order for a given batch shape.
 //
