@@ -1,5 +1,6 @@
-// Retriever edge scorer (S1-S6): the eval-mode forward of
-//   src/models/components/retriever.py:195-289 (Retriever._forward_impl) on a flat PyG-style batch.
+// Retriever edge scorer (S1-S6): the forward of
+//   src/models/components/retriever.py:195-289 (Retriever._forward_impl) on a flat PyG-style batch — evaluation, and training
+//   (dropout inside state_net, the hide-and-seek bias, per-edge intermediates kept for the backward of scorer_bwd.hpp).
 //
 // Pipeline (all on the caller's stream, intermediates in the caller's workspace):
 //   1. projections  tanh(x W^T + b): nodes [N,D], questions [B,D] (then q_gate / q_bias on the B

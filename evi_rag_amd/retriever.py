@@ -109,7 +109,8 @@ def compute_qa_edge_mask(edge_index: torch.Tensor, *, num_nodes: int, q_local_in
 
 
 class Retriever(nn.Module):
-    """Drop-in for src.models.components.retriever.Retriever (eval path)."""
+    """Drop-in for src.models.components.retriever.Retriever: evaluation, and — in train() mode — an autograd node whose backward
+    is evi_retriever_backward (the reference's dropout and hide-and-seek included)."""
 
     def __init__(
         self,

@@ -605,9 +605,11 @@ typedef struct EviRetrieverOutput {
     size_t saved_bytes;
 } EviRetrieverOutput;
 
-/* Eval-mode Retriever._forward_impl (src/models/components/retriever.py:195-289): dropout is the
- * identity, the hide-and-seek bias is off (apply_in_eval: false,
- * configs/model/retriever_module.yaml:25).  direction_mode: 0 bidirectional, 1 forward, 2 backward.
+/* Retriever._forward_impl (src/models/components/retriever.py:195-289).  Evaluation: batch.dropout_p = 0 and
+ * batch.edge_bias = NULL (dropout is the identity, the hide-and-seek bias is off: apply_in_eval: false,
+ * configs/model/retriever_module.yaml:25).  Training: batch.dropout_p / dropout_seed switch on nn.Dropout of state_net,
+ * batch.edge_bias carries the hide-and-seek penalty, output.saved keeps the per-edge intermediates for
+ * evi_retriever_backward.  direction_mode: 0 bidirectional, 1 forward, 2 backward.
  * Dense contractions run on the split-bf16 GEMM (evi_gemm_nt_bf16x3) unless the environment
  * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM. */
 /* C [M, N] (+)= A^T B for A [K, M], B [K, N] f32 row-major (row strides lda, ldb) and K long: the weight-gradient product of
