@@ -284,28 +284,33 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     # clipping at 1.0, AdamW over the flat parameter buffer — on a model of its own (the trainer re-points its parameters)
     from evi_rag_amd.train import RetrieverTrainer
 
-    torch.manual_seed(0)
-    tmodel = Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1,
-                       hide_seek_cfg={"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0, "bias_far": -0.5,
-                                      "apply_in_eval": False}).to(dev)
-    tmodel.emit_edge_embeddings = False
-    trainer = RetrieverTrainer(tmodel, loss=RetrieverLoss(infonce_temperature=0.07),
-                               optimizer_cfg={"type": "adamw", "lr": 1e-3, "weight_decay": 1e-4}, gradient_clip_val=1.0)
-    first = trainer.training_step(batch)
-    trainer.training_step(batch)
-    torch.cuda.synchronize(dev)
-    step_ms = []
-    for _ in range(6):
-        t0 = time.perf_counter()
-        last = trainer.training_step(batch)
+    def trainer_leg(precision):
+        torch.manual_seed(0)
+        tmodel = Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1,
+                           hide_seek_cfg={"enabled": True, "p_near": 0.7, "p_far": 0.1, "bias_near": -2.0, "bias_far": -0.5,
+                                          "apply_in_eval": False}).to(dev)
+        tmodel.emit_edge_embeddings = False
+        trainer = RetrieverTrainer(tmodel, loss=RetrieverLoss(infonce_temperature=0.07), precision=precision,
+                                   optimizer_cfg={"type": "adamw", "lr": 1e-3, "weight_decay": 1e-4}, gradient_clip_val=1.0)
+        first = trainer.training_step(batch)
+        trainer.training_step(batch)
         torch.cuda.synchronize(dev)
-        step_ms.append((time.perf_counter() - t0) * 1e3)
-    t_opt = sum(step_ms) / len(step_ms) * 1e-3
-    train_obj = {"what": "RetrieverTrainer.training_step: train() forward (dropout 0.1, hide-and-seek) -> InfoNCE loss -> backward -> "
-                         "clip_grad_norm 1.0 -> AdamW (flat buffers); same batch 8 times",
-                 "ms_per_step": t_opt * 1e3, "questions_per_s": graphs / t_opt, "loss_first_step": float(first),
-                 "loss_last_step": float(last), "step_ms": step_ms, "parameters": int(trainer.optimizer.numel)}
-    del trainer, tmodel
+        step_ms = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            last = trainer.training_step(batch)
+            torch.cuda.synchronize(dev)
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+        t_opt = sum(step_ms) / len(step_ms) * 1e-3
+        return {"precision": precision, "matmul_precision": tmodel.matmul_precision, "ms_per_step": t_opt * 1e3,
+                "questions_per_s": graphs / t_opt, "loss_first_step": float(first), "loss_last_step": float(last), "step_ms": step_ms,
+                "parameters": int(trainer.optimizer.numel)}
+
+    train_obj = dict(trainer_leg("32-true"),
+                     what="RetrieverTrainer.training_step: train() forward (dropout 0.1, hide-and-seek) -> InfoNCE loss -> backward -> "
+                          "clip_grad_norm 1.0 -> AdamW (flat buffers); same batch 8 times; split-bf16 (f32-grade) products")
+    # opt-in: trainer.precision = bf16-mixed (configs/trainer/default.yaml:13-14) -> one bf16 product per GEMM, forward and backward
+    train_obj["bf16_mixed"] = trainer_leg("bf16-mixed")
     exact = os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
     # split-bf16: three bf16 MFMAs per algorithmic product -> executed flops = 3 x algorithmic
     executed_tf, peak, kname = (tf, 157.3, "k_gemm_nt (f32 MFMA 32x32x2)") if exact else \

@@ -81,7 +81,7 @@ int launch_gemm_skinny(const float* A, int64_t M, int K, int64_t lda, const floa
                        float* C, int64_t ldc, hipStream_t st);
 void gemm_tn_plan(int M, int N, int64_t K, int max_slices, int64_t* Ks_out, int* S_out);
 int launch_gemm_tn_bf16x3(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t K, int64_t Ks, int S,
-                          float* Cparts, hipStream_t st);
+                          float* Cparts, hipStream_t st, int single = 0);
 int launch_gemm_nt_bf16x3_splitk(const float* A, int64_t M, int64_t Ktot, int64_t lda, const float* W, int N, int64_t ldw, int Ks,
                                  int S, float* Cparts, void* wsplit, hipStream_t st);
 int split_weight_bf16x3(const float* W, int N, int K, int64_t ldw, void* wsplit, hipStream_t st);
@@ -99,9 +99,9 @@ int split_rows_bf16x3(const float* x, int64_t rows, int K, int64_t ld, int Kp, v
 // Split-bf16 variant (gemm_bf16x3.hip); wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes.
 size_t gemm_bf16x3_workspace_bytes(int N, int K);
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
-                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st);
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single = 0);
 int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
-                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st);
+                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single = 0);
 
 // ---- ordered keys ---------------------------------------------------------------------------
 // A 64-bit key whose unsigned order is the ranking order used everywhere in this library:

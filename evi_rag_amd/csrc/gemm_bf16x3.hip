@@ -460,15 +460,17 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, i
 }
 
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
-                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st) {
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single) {
     if (M == 0 || N == 0) return EVI_OK;
     if (int rc = split_weight_bf16x3(W, N, K, ldw, wsplit, st)) return rc;
-    return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wsplit, N, bias, act, C, ldc, st);
+    return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wsplit, N, bias, act, C, ldc, st, single);
 }
 
-// the same with W already split (split_weight_bf16x3 wrote `wplanes`): what a caller that keeps its weights prepared uses
+// the same with W already split (split_weight_bf16x3 wrote `wplanes`): what a caller that keeps its weights prepared uses.
+// single != 0: one bf16 product (hi * hi only, f32 accumulation and output) — the arithmetic of a bf16-autocast Linear
+// with an f32 result; the scorer's opt-in `bf16-mixed` training precision.
 int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
-                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st) {
+                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single) {
     if (M == 0 || N == 0) return EVI_OK;
     const int Kp = (K + XK - 1) / XK * XK;
     const __bf16* hi = static_cast<const __bf16*>(wplanes);
@@ -483,7 +485,9 @@ int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda,
         return e && e[0] == '1';
     }();
 #define EVI_LAUNCH_X3(ACT)                                                                                              \
-    if (mfma16)                                                                                                         \
+    if (single)                                                                                                         \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
+    else if (mfma16)                                                                                                    \
         hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
     else                                                                                                                \
         hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{});

@@ -23,10 +23,12 @@ constexpr int kTThreads = 512;
 __device__ inline int slot_tn(int r, int c) { return r * 4 + (c ^ ((r >> 2) & 3)); }
 }  // namespace
 
+// P1 = 1: one product (hi * hi) — the `bf16-mixed` training precision; no lo planes, half the LDS.
+template <int P1>
 __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __restrict__ A, int64_t lda, int M,
                                                               const float* __restrict__ B, int64_t ldb, int N, int64_t K,
                                                               int64_t kslice, float* __restrict__ Cparts) {
-    __shared__ uint4 sAhi[2][TM * 4], sAlo[2][TM * 4], sBhi[2][TNN * 4], sBlo[2][TNN * 4];  // 8 x 16 KiB
+    __shared__ uint4 sAhi[2][TM * 4], sAlo[P1 ? 1 : 2][P1 ? 1 : TM * 4], sBhi[2][TNN * 4], sBlo[P1 ? 1 : 2][P1 ? 1 : TNN * 4];  // 8 x 16 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -79,11 +81,13 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
             for (int j = 0; j < 8; ++j) v[j] = j < left ? v[j] : 0.f;
         }
         const bf16x8 h = __builtin_convertvector(v, bf16x8);
-        const f32x8 hf = __builtin_convertvector(h, f32x8);
-        const bf16x8 l = __builtin_convertvector(v - hf, bf16x8);
         const int s = slot_tn(col, kg);
         *reinterpret_cast<bf16x8*>(opb ? &sBhi[buf][s] : &sAhi[buf][s]) = h;
-        *reinterpret_cast<bf16x8*>(opb ? &sBlo[buf][s] : &sAlo[buf][s]) = l;
+        if (!P1) {
+            const f32x8 hf = __builtin_convertvector(h, f32x8);
+            const bf16x8 l = __builtin_convertvector(v - hf, bf16x8);
+            *reinterpret_cast<bf16x8*>(opb ? &sBlo[P1 ? 0 : buf][P1 ? 0 : s] : &sAlo[P1 ? 0 : buf][P1 ? 0 : s]) = l;
+        }
     };
 
     f32x16 acc[4][2];
@@ -104,12 +108,15 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
     for (int i = 0; i < 4; ++i) load_unit(i, k_begin + TK);
     int cur = 0;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += TK) {
-        bf16x8 fah[2], fal[2], fbh[2][2], fbl[2][2];
+        // A fragments are read AHEAD groups before their MFMAs (one group of six MFMAs covers the LDS latency; with one
+        // product a group is two MFMAs, so read two ahead — as in the NT kernel)
+        constexpr int AHEAD = P1 ? 2 : 1, RING = AHEAD + 1;
+        bf16x8 fah[RING], fal[RING], fbh[2][2], fbl[2][2];
         auto read_a = [&](int g) {
             const int c = ((g >> 2) << 1) + fh;
             const int row = wm * 128 + (g & 3) * 32 + fr;
-            fah[g & 1] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot_tn(row, c)]);
-            fal[g & 1] = *reinterpret_cast<const bf16x8*>(&sAlo[cur][slot_tn(row, c)]);
+            fah[g % RING] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot_tn(row, c)]);
+            if (!P1) fal[g % RING] = *reinterpret_cast<const bf16x8*>(&sAlo[P1 ? 0 : cur][P1 ? 0 : slot_tn(row, c)]);
         };
         auto read_b = [&](int ks) {
             const int c = (ks << 1) + fh;
@@ -117,22 +124,23 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + fr;
                 fbh[ks][j] = *reinterpret_cast<const bf16x8*>(&sBhi[cur][slot_tn(row, c)]);
-                fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sBlo[cur][slot_tn(row, c)]);
+                if (!P1) fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sBlo[P1 ? 0 : cur][P1 ? 0 : slot_tn(row, c)]);
             }
         };
         read_b(0);
-        read_a(0);
+#pragma unroll
+        for (int g = 0; g < AHEAD; ++g) read_a(g);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (g + 1 < 8) read_a(g + 1);
+            if (g + AHEAD < 8) read_a(g + AHEAD);
             if (g == 2) read_b(1);
             const int i = g & 3, ks = g >> 2;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16& c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g & 1], fbh[ks][j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbl[ks][j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g & 1], fbh[ks][j], c, 0, 0, 0);
+                if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g % RING], fbh[ks][j], c, 0, 0, 0);
+                if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g % RING], fbl[ks][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g % RING], fbh[ks][j], c, 0, 0, 0);
             }
             // one staging unit in the shadow of this group's MFMAs: split + write the next tile's unit, refetch its registers
             if (g < 4) {
@@ -161,11 +169,12 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
 
 // Cparts [S][M][N]: slice s = rows [s * Ks, min(K, (s + 1) Ks)) of A [K, M] (row stride lda) and B [K, N] (row stride ldb).
 int launch_gemm_tn_bf16x3(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t K, int64_t Ks, int S,
-                          float* Cparts, hipStream_t st) {
+                          float* Cparts, hipStream_t st, int single) {
     if (M <= 0 || N <= 0 || S <= 0) return EVI_OK;
     const dim3 grid((unsigned)(((M + TM - 1) / TM) * ((N + TNN - 1) / TNN) * S));
     const int tok = timing_begin(kTimeGemm, st);
-    hipLaunchKernelGGL(k_gemm_tn_bf16x3, grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
+    if (single) hipLaunchKernelGGL(k_gemm_tn_bf16x3<1>, grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
+    else hipLaunchKernelGGL(k_gemm_tn_bf16x3<0>, grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
     timing_end(tok, st);
     EVI_LAUNCH_CHECK();
     return EVI_OK;

@@ -497,6 +497,16 @@ static bool use_f32_gemm() {
     return v && v[0] == 'f';
 }
 
+// EviRetrieverBatch.matmul_precision of the call in flight on this thread: 1 = the large GEMMs multiply ONE bf16 product
+// (f32 accumulation and results) instead of three.  Set for the duration of retriever_run by SingleProductScope; read by the
+// two places every large product of the scorer goes through (scorer_gemm, tn_gemm).
+static thread_local int t_gemm_single = 0;
+struct SingleProductScope {
+    int before;
+    explicit SingleProductScope(int v) : before(t_gemm_single) { t_gemm_single = v; }
+    ~SingleProductScope() { t_gemm_single = before; }
+};
+
 // act(A W^T + b) on the split-bf16 GEMM (default) or the exact f32 GEMM (EVI_SCORER_GEMM=f32).  wplanes: the weight's
 // bf16 hi / lo planes when the caller keeps them prepared (evi_retriever_prepare), else they are made here in `wsplit`.
 static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
@@ -505,8 +515,8 @@ static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const floa
     // a handful of rows (question-side projections, the non-text embedding): one wave per output column, exact f32 (gemm_skinny.hip)
     if (gemm_skinny_fits(M, K, lda, ldw)) return launch_gemm_skinny(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
     if (use_f32_gemm()) return launch_gemm_nt(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
-    if (wplanes) return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wplanes, N, bias, act, C, ldc, st);
-    return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st);
+    if (wplanes) return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wplanes, N, bias, act, C, ldc, st, t_gemm_single);
+    return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st, t_gemm_single);
 }
 
 // Everything the forward derives from the WEIGHTS alone, kept across calls by callers whose weights do not change between
@@ -771,7 +781,7 @@ static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, flo
         int64_t Ks;
         int S;
         gemm_tn_plan(M, N, K, kTnMaxSlices, &Ks, &S);
-        int rc = launch_gemm_tn_bf16x3(A, M, M, Bm, N, N, K, Ks, (int)S, part, st);
+        int rc = launch_gemm_tn_bf16x3(A, M, M, Bm, N, N, K, Ks, (int)S, part, st, t_gemm_single);
         if (rc) return rc;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, part, (int)S,
                            (int64_t)M * N, C, accumulate ? 1 : 0);
@@ -890,6 +900,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     EVI_REQUIRE(b->dropout_p >= 0.f && b->dropout_p < 1.f, "dropout probability has to be between 0 and 1, but got %g", (double)b->dropout_p);
     uint32_t drop_thr = (uint32_t)lrintf(b->dropout_p * 65536.0f);
     if (drop_thr > 65535u) drop_thr = 65535u;
+    EVI_REQUIRE(b->matmul_precision == 0 || b->matmul_precision == 1, "matmul_precision must be 0 (split-bf16, three products) or 1 (one bf16 product), got %d",
+                b->matmul_precision);
+    const SingleProductScope precision_scope(b->matmul_precision);
     const int S = 1 + w->dde_rounds + w->dde_reverse_rounds;
     const int F = 2 * 2 * S;
     const FwdLayout L = fwd_layout(N, E, B, D, H, F, b->num_relations, 2);

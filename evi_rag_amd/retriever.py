@@ -23,6 +23,7 @@ from . import _lib, ops
 _NUM_TOPICS_BINARY = 2
 _MAX_DDE_ROUNDS = 4
 _DIRECTION_CODE = {"bidirectional": 0, "forward": 1, "backward": 2}
+_MATMUL_PRECISION_CODE = {"split": 0, "bf16": 1}  # EviRetrieverBatch.matmul_precision
 
 
 @dataclass
@@ -125,6 +126,7 @@ class Retriever(nn.Module):
         hide_seek_cfg: Optional[Dict[str, Any]] = None,
         dedupe_relations: bool = True,
         emit_edge_embeddings: bool = True,
+        matmul_precision: str = "split",
         **_: Any,
     ) -> None:
         super().__init__()
@@ -137,6 +139,12 @@ class Retriever(nn.Module):
         self.differentiable: Optional[bool] = None
         # training: keep the per-edge intermediates of the forward for the backward (memory for time: ≈ 16 (D + H) bytes per edge)
         self.keep_forward_intermediates = True
+        # "split" (default): every large product as three bf16 MFMA products of the split f32 operands (f32-grade results);
+        # "bf16": one bf16 product with f32 accumulation and results, forward and backward — the arithmetic class of
+        # Lightning's `precision: bf16-mixed` (configs/trainer/default.yaml:13-14), opt-in for training runs
+        self.matmul_precision = str(matmul_precision)
+        if self.matmul_precision not in _MATMUL_PRECISION_CODE:
+            raise ValueError(f"matmul_precision must be one of {sorted(_MATMUL_PRECISION_CODE)}, got {matmul_precision!r}")
         self.emb_dim = int(emb_dim)
         self.hidden_dim = int(hidden_dim)
         self.use_topic_pe = bool(topic_pe)
@@ -265,6 +273,7 @@ class Retriever(nn.Module):
         b.topic_one_hot, b.topic_stride = pack["topic_one_hot"].data_ptr(), int(pack["topic_one_hot"].size(1))
         b.edge_bias = pack["edge_bias"].data_ptr() if pack["edge_bias"] is not None else None
         b.dropout_p, b.dropout_seed = float(pack.get("dropout_p", 0.0)), int(pack.get("dropout_seed", 0))
+        b.matmul_precision = int(pack.get("matmul_precision", 0))
         return b
 
     def _status_word(self, dev: torch.device) -> torch.Tensor:
@@ -493,6 +502,9 @@ class Retriever(nn.Module):
                     topic_one_hot=topic_one_hot,
                     edge_bias=self._compute_hide_seek_bias(batch, edge_index=edge_index),  # None unless apply_in_eval
                     want_features=return_features or self.emit_edge_embeddings)
+        if self.matmul_precision not in _MATMUL_PRECISION_CODE:
+            raise ValueError(f"matmul_precision must be one of {sorted(_MATMUL_PRECISION_CODE)}, got {self.matmul_precision!r}")
+        pack["matmul_precision"] = _MATMUL_PRECISION_CODE[self.matmul_precision]  # the backward of this call uses the same
         drop_p = float(self.state_net[3].p) if self.training else 0.0
         if drop_p > 0.0:
             # nn.Dropout between state_net's GELU and state_net.4 (:179): the mask is a counter-based hash of a per-call seed

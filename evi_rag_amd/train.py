@@ -127,11 +127,30 @@ class CosineSchedule:
         self.opt.lr = self.eta_min + (base - self.eta_min) * (1.0 + math.cos(math.pi * self.last_epoch / self.t_max)) / 2.0
 
 
+def matmul_precision_for(precision: Any) -> str:
+    """Lightning's `trainer.precision` (configs/trainer/default.yaml:13-14) -> Retriever.matmul_precision.
+
+    `bf16-mixed` (what the reference's comment recommends where the GPU has bf16) -> "bf16": the large products of the forward
+    and the backward multiply one bf16 product with f32 accumulation; results, LayerNorm, GELU, the loss and the optimiser stay
+    f32 (bf16 autocast rounds the Linear results to bf16 as well, so this is at least its arithmetic).  Everything else —
+    `32-true`, and the reference's default `16-mixed` — -> "split" (three bf16 products, f32-grade): f16 autocast is not
+    mirrored (it needs Lightning's dynamic loss scaling to keep gradients inside f16's range; the split products are more
+    precise than f16 and need none)."""
+    p = str(precision).strip().lower()
+    if p in ("bf16-mixed", "bf16", "bf16-true"):
+        return "bf16"
+    if p in ("32", "32-true", "16", "16-mixed", "16-true", "64", "64-true", "none"):
+        return "split"
+    raise ValueError(f"Unsupported trainer.precision {precision!r}")
+
+
 class RetrieverTrainer:
     def __init__(self, model, *, loss: Optional[RetrieverLoss] = None, optimizer_cfg: Optional[Mapping[str, Any]] = None,
                  scheduler_cfg: Optional[Mapping[str, Any]] = None, gradient_clip_val: Optional[float] = 1.0,
-                 process_group=None) -> None:
+                 process_group=None, precision: Any = None) -> None:
         self.model = model
+        if precision is not None and matmul_precision_for(precision) == "bf16":
+            model.matmul_precision = "bf16"  # other values leave the model's own setting (`model.retriever.matmul_precision`) alone
         self.loss = loss if loss is not None else RetrieverLoss()
         self.optimizer = setup_optimizer(model, optimizer_cfg if optimizer_cfg is not None else
                                          {"type": "adamw", "lr": 1e-3, "weight_decay": 1e-4})

@@ -8,6 +8,8 @@ reduced to what changes numbers or files:
     shuffled with `seed`; one process per GPU shares the split by rank;
   * model / loss: `model.retriever`, `model.loss` through `hydra_lite.instantiate` (mapped to the mirrors);
   * optimiser / schedule / clipping: `model.optimizer_cfg`, `model.scheduler_cfg`, `trainer.gradient_clip_val` -> `RetrieverTrainer`;
+  * `trainer.precision`: `bf16-mixed` -> single-product bf16 GEMMs in the scorer (forward, backward and the validation inside the
+    run); `32-true` and the default `16-mixed` -> the split-bf16 (f32-grade) GEMMs (`train.matmul_precision_for`);
   * validation every `trainer.check_val_every_n_epoch` epochs with `RetrieverEvaluator` (metrics under `val/`, summed over ranks);
   * `callbacks.model_checkpoint` (`dirpath`, `filename` with `{epoch:03d}`, `monitor`, `mode`, `save_last`): the best checkpoint by the
     monitored validation metric and `last.ckpt`, in Lightning's layout as far as `src/eval.py` reads it;
@@ -71,7 +73,7 @@ def fit(cfg: Mapping[str, Any], *, device: Optional[str] = None) -> Dict[str, An
     loss = hl.instantiate(model_cfg["loss"]) if isinstance(model_cfg.get("loss"), Mapping) else None
     tr_cfg = cfg.get("trainer") or {}
     trainer = RetrieverTrainer(model, loss=loss, optimizer_cfg=model_cfg.get("optimizer_cfg"), scheduler_cfg=model_cfg.get("scheduler_cfg"),
-                               gradient_clip_val=tr_cfg.get("gradient_clip_val"))
+                               gradient_clip_val=tr_cfg.get("gradient_clip_val"), precision=tr_cfg.get("precision"))
     if cfg.get("ckpt_path"):
         trainer.load_checkpoint(cfg["ckpt_path"])
         log.info("resumed from %s at epoch %d", cfg["ckpt_path"], trainer.current_epoch)

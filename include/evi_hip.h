@@ -585,6 +585,12 @@ typedef struct EviRetrieverBatch {
                                          * regenerates it from the same seed.  Not torch's Philox stream: masks are equal in
                                          * distribution (keep probability 1 - round(p 2^16) / 2^16, kept values scaled by its
                                          * reciprocal), not bit for bit */
+    int matmul_precision;               /* 0 (default): every large product runs as three bf16 MFMA products of the split f32
+                                         * operands (f32-grade results; what evaluation and the parity tests use).  1: ONE bf16
+                                         * product with f32 accumulation and f32 results, forward and backward — at least the
+                                         * arithmetic of Lightning's `precision: bf16-mixed` (bf16 autocast rounds the results
+                                         * to bf16 as well), which configs/trainer/default.yaml:13-14 recommends for training
+                                         * on GPUs that have it; the few-row products (question side) stay exact f32 */
 } EviRetrieverBatch;
 
 /* RetrieverOutput (src/models/components/retriever.py:80-99); any pointer but logits may be NULL. */
@@ -611,7 +617,8 @@ typedef struct EviRetrieverOutput {
  * batch.edge_bias carries the hide-and-seek penalty, output.saved keeps the per-edge intermediates for
  * evi_retriever_backward.  direction_mode: 0 bidirectional, 1 forward, 2 backward.
  * Dense contractions run on the split-bf16 GEMM (evi_gemm_nt_bf16x3) unless the environment
- * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM. */
+ * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM; batch.matmul_precision = 1 opts a training run into
+ * single-product bf16 (see the field). */
 /* C [M, N] (+)= A^T B for A [K, M], B [K, N] f32 row-major (row strides lda, ldb) and K long: the weight-gradient product of
  * a Linear layer over K rows (autograd's `grad_out.t() @ input` behind every nn.Linear of src/models/components/retriever.py).
  * Split-bf16 arithmetic like evi_gemm_nt_bf16x3, split-K with an ordered reduction (deterministic, no float atomics). */

@@ -344,3 +344,43 @@ def test_backward_narrow_model_many_edges(dev, monkeypatch):
     for n in grads["f32"]:
         scale = float(grads["f32"][n].abs().max()) + 1e-6
         assert float((grads["bf16"][n] - grads["f32"][n]).abs().max()) / scale < 3e-4, n
+
+
+def test_bf16_matmul_precision_tracks_the_split_products(dev):
+    """`matmul_precision = "bf16"` (EviRetrieverBatch.matmul_precision = 1; Lightning's `precision: bf16-mixed`,
+    configs/trainer/default.yaml:13-14): the large products multiply one bf16 product instead of three, forward and backward.
+    Against the default on the same weights, batch and dropout seed: logits within bf16's rounding of the default's (and not equal:
+    the mode is really on), every large gradient within 2 % of its norm and at cosine >= 0.999; an unknown value is refused."""
+    from evi_rag_amd.retriever import Retriever
+
+    D, H = 128, 160
+    sb = synthetic.make_batch(8, nodes_per_graph=300, edges_per_graph=2000, emb_dim=D, num_relations=40, seed=5)
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = 40
+    torch.manual_seed(11)
+    model = Retriever(emb_dim=D, hidden_dim=H, dropout_p=0.1, hide_seek_cfg={"enabled": False}).to(dev).train()
+    g = torch.randn(sb.num_edges, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) / sb.num_edges ** 0.5
+    runs = {}
+    for mode in ("split", "bf16"):
+        model.matmul_precision = mode
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        out = model(batch)
+        (out.logits * g).sum().backward()
+        runs[mode] = (out.logits.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()})
+    ls, lb = runs["split"][0], runs["bf16"][0]
+    scale = float(ls.std())
+    err = float((ls - lb).abs().max())
+    assert 1e-6 * scale < err <= 0.05 * scale, (err, scale)
+    for n, gs in runs["split"][1].items():
+        gb = runs["bf16"][1][n]
+        assert bool(torch.isfinite(gb).all()), n
+        norm = float(gs.norm())
+        if gs.numel() < 1024 or norm < 1e-6:
+            continue  # biases / LayerNorm vectors: sums of many rounded rows, checked through the matrices they feed
+        rel = float((gs - gb).norm()) / norm
+        cos = float((gs * gb).sum()) / (norm * float(gb.norm()))
+        assert rel <= 0.02 and cos >= 0.999, (n, rel, cos)
+    model.matmul_precision = "fp8"
+    with pytest.raises(ValueError, match="matmul_precision"):
+        model(batch)

@@ -213,3 +213,14 @@ def test_records_to_samples_is_the_lmdb_free_hand_over(tmp_path):
         records_to_samples([empty], [[1]], [[1]], qe[:1])
     with pytest.raises(ValueError, match="seed_entity_ids is null"):
         records_to_samples([g1], [None], [[8]], qe[:1])
+
+
+def test_trainer_precision_maps_to_matmul_precision():
+    """`trainer.precision` of the reference's trainer configs (configs/trainer/default.yaml:14 `16-mixed`, predict.yaml:8 `32-true`)."""
+    from evi_rag_amd.train import matmul_precision_for
+
+    assert matmul_precision_for("bf16-mixed") == "bf16"
+    assert matmul_precision_for("32-true") == "split" and matmul_precision_for(32) == "split"
+    assert matmul_precision_for("16-mixed") == "split"  # f16 autocast is not mirrored; the split products are more precise
+    with pytest.raises(ValueError, match="precision"):
+        matmul_precision_for("fp8-mixed")

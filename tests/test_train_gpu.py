@@ -137,6 +137,36 @@ def test_trainer_step_equals_the_torch_optimizer_loop(dev):
         RetrieverTrainer(w.make_model(dev), optimizer_cfg={"type": "lion"})
 
 
+def test_bf16_mixed_trainer_learns_like_the_default(dev):
+    """`trainer.precision: bf16-mixed` (configs/trainer/default.yaml:13-14) -> single-product bf16 GEMMs in the forward and the
+    backward: from the same initial weights on the same batch the loss falls like the default's (step by step within 5 %), and
+    the values Lightning's other precisions map to leave the model's setting alone."""
+    sys.path.insert(0, HERE)
+    import train_rank_worker as w
+    from evi_rag_amd.loss import RetrieverLoss
+    from evi_rag_amd.train import RetrieverTrainer
+
+    batch = w.make_batch(0, dev)
+    curves = {}
+    for precision in ("32-true", "bf16-mixed"):
+        model = w.make_model(dev)
+        trainer = RetrieverTrainer(model, loss=RetrieverLoss(infonce_temperature=0.5), precision=precision,
+                                   optimizer_cfg={"type": "adamw", "lr": 1e-2, "weight_decay": 1e-4}, gradient_clip_val=1.0)
+        assert model.matmul_precision == ("bf16" if precision == "bf16-mixed" else "split")
+        curves[precision] = [float(trainer.training_step(batch)) for _ in range(6)]
+    a, b = curves["32-true"], curves["bf16-mixed"]
+    assert b[-1] < b[0] - 0.05, b
+    assert a != b  # the mode is on
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 0.05 * abs(x), (a, b)
+    model = w.make_model(dev)
+    model.matmul_precision = "bf16"
+    RetrieverTrainer(model, precision="16-mixed")
+    assert model.matmul_precision == "bf16"
+    with pytest.raises(ValueError, match="precision"):
+        RetrieverTrainer(w.make_model(dev), precision="fp8")
+
+
 # InfoNCE's logit gradients sum to zero inside every graph, so the gradients of the two biases behind the logits
 # (state_net.4.bias, score_head.bias) are pure rounding noise — which Adam normalises to steps of size lr.  Their values
 # are compared only to within the distance such steps can cover.

@@ -47,7 +47,7 @@ def main():
                        hide_seek_cfg={"enabled": os.environ.get("EVI_PROFILE_HIDE_SEEK", "1") == "1", "p_near": 0.7, "p_far": 0.1,
                                       "bias_near": -2.0, "bias_far": -0.5}).to(dev)
         tm.emit_edge_embeddings = False
-        tr = RetrieverTrainer(tm, loss=RetrieverLoss(infonce_temperature=0.07))
+        tr = RetrieverTrainer(tm, loss=RetrieverLoss(infonce_temperature=0.07), precision=os.environ.get("EVI_PROFILE_PRECISION", "32-true"))
         for _ in range(2):
             tr.training_step(batch)
         torch.cuda.synchronize()
