@@ -381,6 +381,17 @@ def test_bf16_matmul_precision_tracks_the_split_products(dev):
         rel = float((gs - gb).norm()) / norm
         cos = float((gs * gb).sum()) / (norm * float(gb.norm()))
         assert rel <= 0.02 and cos >= 0.999, (n, rel, cos)
+    # evaluation (weights prepared once and cached: the hi planes are the single product's operands) honours it too
+    model.eval()
+    with torch.no_grad():
+        ev = {}
+        for mode in ("split", "bf16"):
+            model.matmul_precision = mode
+            ev[mode] = model(batch).logits.clone()
+    err = float((ev["split"] - ev["bf16"]).abs().max())
+    assert 1e-6 * scale < err <= 0.05 * scale, (err, scale)
     model.matmul_precision = "fp8"
     with pytest.raises(ValueError, match="matmul_precision"):
         model(batch)
+    with pytest.raises(ValueError, match="matmul_precision"):
+        Retriever(emb_dim=D, hidden_dim=H, matmul_precision="fp8")

@@ -237,6 +237,28 @@ def test_retriever_forward_other_dims(dev, D, H):
     np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=3e-4)
 
 
+@pytest.mark.parametrize("graphs", [1, 2, 5, 17, 31, 32, 33])
+def test_question_side_projections_for_every_row_count(dev, graphs):
+    """query_proj / q_gate / q_bias run on `graphs` rows: up to 32 rows on the one-wave-per-column f32 kernel (gemm_skinny.hip,
+    whose row sums are scattered over the lane pairs by a butterfly), beyond that on the MFMA tile.  Every row count around the
+    kernel's edges against the numpy oracle (src/models/components/retriever.py:214-223)."""
+    from evi_rag_amd.retriever import Retriever
+
+    D, H = 96, 64
+    sb = synthetic.make_batch(graphs, nodes_per_graph=30, edges_per_graph=70, emb_dim=D, num_relations=11, seed=graphs)
+    torch.manual_seed(graphs)
+    model = Retriever(emb_dim=D, hidden_dim=H).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    w = {k: v.numpy() for k, v in model.state_dict().items()}
+    ref = oscorer.retriever_forward(w, sb, num_rounds=2, num_reverse_rounds=2)
+    out = model.to(dev)(synthetic.as_namespace(sb, device=dev))
+    np.testing.assert_allclose(out.logits.cpu().numpy(), ref["logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=1e-4)
+
+
 def test_retriever_forward_multi_chunk_batch(dev):
     """More than 65 536 edges: the scorer processes the batch in edge chunks; one big graph with a
     hub node (DDE hub path) and a small one."""
