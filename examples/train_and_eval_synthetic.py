@@ -3,7 +3,7 @@
 defaults: dropout 0.1, hide-and-seek, AdamW 1e-3 / 1e-4, cosine schedule, gradient clipping at 1.0) -> a Lightning-layout
 checkpoint -> strict load into a fresh Retriever (what src/eval.py does) -> RetrieverEvaluator with the top-k artifact writer.
 
-    python examples/train_and_eval_synthetic.py [--graphs 256] [--dim 64] [--epochs 5] [--out /tmp/evi_example]
+    python examples/train_and_eval_synthetic.py [--graphs 256] [--dim 64] [--epochs 5] [--out /tmp/evi_example] [--precision bf16-mixed]
 
 Everything between the loader and the metric dictionary runs in hand-written HIP kernels (libevi_hip.so); there is no CPU path.
 Under `python -m torch.distributed.run --nproc-per-node N` each rank trains on its share of the graphs and the flat gradient
@@ -40,6 +40,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--out", default="/tmp/evi_example")
+    ap.add_argument("--precision", default="32-true", help="trainer.precision: 32-true (split-bf16, f32-grade GEMMs) or bf16-mixed (one bf16 product)")
     args = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -63,7 +64,8 @@ def main(argv=None):
     model = Retriever(emb_dim=D, hidden_dim=D, dropout_p=0.1, hide_seek_cfg=HIDE_SEEK).to(dev)
     loss = RetrieverLoss(infonce_weight=1.0, bce_weight=0.0)  # configs/experiment/train_retriever.yaml
     trainer = RetrieverTrainer(model, loss=loss, optimizer_cfg={"type": "adamw", "lr": 1e-3, "weight_decay": 1e-4},
-                               scheduler_cfg={"type": "cosine", "t_max": max(args.epochs, 1), "eta_min": 1e-6}, gradient_clip_val=1.0)
+                               scheduler_cfg={"type": "cosine", "t_max": max(args.epochs, 1), "eta_min": 1e-6}, gradient_clip_val=1.0,
+                               precision=args.precision)
     log = trainer.fit(pd.PackedLoader(ds, batch_size=args.batch_size, shuffle=True, random_seed=0, rank=rank, world_size=world),
                       max_epochs=args.epochs)
     if rank == 0:
