@@ -10,7 +10,6 @@ the two-stage method — also when one rank's two-stage proof fails (its shard h
 device-side fallback repairs that rank's record before the exchange and `two_stage_failed()` reports it on EVERY rank.
 """
 import os
-import socket
 import subprocess
 import sys
 
@@ -22,31 +21,17 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+sys.path.insert(0, HERE)
+from _procs import free_port as _free_port, run_ranks  # noqa: E402
 
 
 @pytest.mark.timeout(900)
 def test_two_ranks_real_kernels_equal_one_rank_bit_for_bit(dev, tmp_path):
     world = 2
-    port = _free_port()
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "4")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(world), str(port), str(tmp_path)],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=800)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(o.decode(errors="replace"))
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-4000:]}"
+    run_ranks(lambda r, port: [sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(world), str(port), str(tmp_path)],
+              world, env=env, timeout=600)
     z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for tag in ("plain", "clustered"):
         want_s, want_i = z[0][f"{tag}_want_s"], z[0][f"{tag}_want_i"]

@@ -8,8 +8,6 @@ average of the two ranks' gradients.
 """
 import math
 import os
-import socket
-import subprocess
 import sys
 
 import numpy as np
@@ -180,30 +178,17 @@ def _close(name, a, b, steps, lr):
     return bool(np.allclose(a, b, rtol=1e-4, atol=2e-5))
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+sys.path.insert(0, HERE)
+from _procs import run_ranks  # noqa: E402
 
 
 @pytest.mark.timeout(600)
 def test_two_rank_training_averages_gradients(dev, tmp_path):
-    world, port = 2, _free_port()
+    world = 2
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "4")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "train_rank_worker.py"), str(r), str(world), str(port), str(tmp_path)],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=500)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(o.decode(errors="replace"))
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-4000:]}"
+    run_ranks(lambda r, port: [sys.executable, os.path.join(HERE, "train_rank_worker.py"), str(r), str(world), str(port), str(tmp_path)],
+              world, env=env, timeout=400)
     z = [np.load(tmp_path / f"train_rank{r}.npz") for r in range(world)]
     sys.path.insert(0, HERE)
     import train_rank_worker as w

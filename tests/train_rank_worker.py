@@ -5,6 +5,7 @@ summed over ranks through `gloo` (RCCL refuses two ranks on one device) exactly 
 
 usage: train_rank_worker.py RANK WORLD PORT OUT_DIR
 """
+import datetime
 import os
 import sys
 
@@ -38,7 +39,7 @@ def make_batch(rank, dev):
 def main():
     rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     dev = torch.device("cuda:0")
     from evi_rag_amd.loss import RetrieverLoss
     from evi_rag_amd.train import RetrieverTrainer

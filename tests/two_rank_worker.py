@@ -7,6 +7,7 @@ buffers (`ShardedIndex(exchange=...)`).  Everything else is the code path `bench
 
 usage: two_rank_worker.py RANK WORLD PORT OUT_DIR
 """
+import datetime
 import os
 import sys
 
@@ -47,7 +48,7 @@ def build_index(dev, clustered_tail: bool):
 def main():
     rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     from evi_rag_amd import ops
