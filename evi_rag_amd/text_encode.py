@@ -92,21 +92,61 @@ class TextEncoder:
     # torch.autocast on the device; the pooling kernel takes the half-precision hidden states as they are.
     autocast: Optional[torch.dtype] = None
 
+    # hipGraph replay of the transformer forward + pooling (opt-in).  A batch of questions is a few dozen short rows: the ~200
+    # kernels of a 12-layer forward finish faster than PyTorch can launch them, so the stage runs at the speed of the host.
+    # With use_graphs the forward of every (batch, padded length) shape met is captured once (torch.cuda.CUDAGraph over static
+    # input buffers, the pooling kernel included) and replayed afterwards: one launch per batch, the same kernels on the same
+    # shapes — results equal the eager path's.  Shapes are cached up to max_graphs (oldest dropped).
+    use_graphs: bool = False
+    max_graphs: int = 64
+
+    def _forward_pooled(self, inputs) -> torch.Tensor:
+        if self.autocast is not None:
+            with torch.autocast(device_type="cuda", dtype=self.autocast):
+                hidden = self.model(**inputs).last_hidden_state
+        else:
+            hidden = self.model(**inputs).last_hidden_state
+        return masked_mean_pool(hidden, inputs["attention_mask"], fp16=self.dtype == torch.float16)
+
+    def _forward_pooled_graphed(self, host_inputs) -> torch.Tensor:
+        dev = torch.device(self.device)
+        key = (tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in host_inputs.items())), str(self.autocast), str(self.dtype))
+        cache = self.__dict__.setdefault("_graphs", {})
+        entry = cache.get(key)
+        if entry is None:
+            static = {k: v.to(dev) for k, v in host_inputs.items()}
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up outside the capture: library handles, workspaces, autotuning
+                for _ in range(2):
+                    self._forward_pooled(static)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_pooled(static)
+            while cache and len(cache) >= max(int(self.max_graphs), 1):
+                cache.pop(next(iter(cache)))
+            entry = cache[key] = (graph, static, out)
+        graph, static, out = entry
+        for k, v in host_inputs.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out.clone()
+
     @torch.no_grad()
     def encode_to_device(self, texts: Sequence[str], batch_size: int) -> torch.Tensor:
         """As `encode`, but the result stays in HBM: no per-batch device-to-host sync."""
         if not texts:
             return torch.empty((0, 0), dtype=torch.float32, device=self.device)
         pooled: List[torch.Tensor] = []
+        graphed = bool(self.use_graphs) and torch.device(self.device).type == "cuda"
         for start, end in _iter_batches(len(texts), batch_size):
             inputs = self.tokenizer(list(texts[start:end]), padding=True, truncation=True, return_tensors="pt")
+            if graphed:
+                pooled.append(self._forward_pooled_graphed(dict(inputs)))
+                continue
             inputs = {k: v.to(self.device) for k, v in inputs.items()}
-            if self.autocast is not None:
-                with torch.autocast(device_type="cuda", dtype=self.autocast):
-                    hidden = self.model(**inputs).last_hidden_state
-            else:
-                hidden = self.model(**inputs).last_hidden_state
-            pooled.append(masked_mean_pool(hidden, inputs["attention_mask"], fp16=self.dtype == torch.float16))
+            pooled.append(self._forward_pooled(inputs))
         return torch.cat(pooled, dim=0)
 
     @torch.no_grad()

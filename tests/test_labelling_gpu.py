@@ -181,6 +181,47 @@ def test_text_encoder_mirror_end_to_end(dev, tmp_path):
         T.encode_to_memmap(enc, texts, [1], 4, 12, out, None, False)
 
 
+def test_text_encoder_graph_replay_equals_eager(dev):
+    """`TextEncoder.use_graphs`: the transformer forward + pooling of each (batch, padded length) shape is captured once in a
+    hipGraph and replayed — the same kernels on the same shapes, so the embeddings equal the eager path's (a random-init
+    4-layer BERT stands in for the checkpoint that does not exist offline), for f32 and under bf16 autocast, for shapes met
+    again (replay) and for new ones (capture), with the cache bounded."""
+    transformers = pytest.importorskip("transformers")
+    from evi_rag_amd import text_encode as T
+
+    torch.manual_seed(0)
+    model = transformers.BertModel(transformers.BertConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=4, num_attention_heads=4,
+                                                           intermediate_size=256, max_position_embeddings=64),
+                                   add_pooling_layer=False).to(dev).eval()
+
+    class Tok:
+        def __call__(self, texts, padding=True, truncation=True, return_tensors="pt"):
+            lens = [3 + (len(t) * 7) % 20 for t in texts]
+            L = max(lens)
+            g = torch.Generator().manual_seed(sum(map(len, texts)))
+            mask = (torch.arange(L).view(1, L) < torch.tensor(lens).view(-1, 1)).to(torch.int64)
+            ids = torch.randint(1, 1000, (len(texts), L), generator=g) * mask
+            return {"input_ids": ids, "attention_mask": mask, "token_type_ids": torch.zeros_like(ids)}
+
+    texts = ["q" * (1 + (i * 5) % 23) for i in range(50)]
+    enc = T.TextEncoder.from_components(Tok(), model, str(dev), fp16=False)
+    for autocast in (None, torch.bfloat16):
+        enc.autocast = autocast
+        enc.use_graphs = False
+        eager = enc.encode_to_device(texts, 8)
+        enc.use_graphs = True
+        first = enc.encode_to_device(texts, 8)    # captures
+        again = enc.encode_to_device(texts, 8)    # replays
+        assert torch.equal(first, again)
+        assert torch.allclose(first, eager, rtol=0, atol=1e-6 if autocast is None else 1e-3), float((first - eager).abs().max())
+        other = enc.encode_to_device(texts[::-1], 7)  # new shapes on a warm cache
+        enc.use_graphs = False
+        assert torch.allclose(other, enc.encode_to_device(texts[::-1], 7), rtol=0, atol=1e-6 if autocast is None else 1e-3)
+    enc.use_graphs, enc.max_graphs = True, 2
+    enc.encode_to_device(texts, 5)  # shapes not met before: every capture evicts down to the bound
+    assert len(enc._graphs) <= 2
+
+
 def test_canonical_edge_selection_matches_reference_golden(dev):
     """C2-C4: keep indices / filtered pair lists produced by the reference's own functions."""
     from evi_rag_amd import labelling as L
