@@ -97,6 +97,15 @@ def parse_args():
     ap.add_argument("--no-encode", action="store_true", help="skip the text-encoding leg (random-init BERT + pooling kernel)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the sustained leg and the BASELINE config 3 / 4 / 5 legs of the default line")
+    ap.add_argument("--config4-rows", type=int, default=100_000_000,
+                    help="rows of the BASELINE configs[3] / configs[4] index (100 M): row-sharded over the ranks in the "
+                         "`config4_sharded` / `config5_sharded` legs of an N > 1 run, whole on the one GPU in `config4_full` at N = 1")
+    ap.add_argument("--no-config4-full", action="store_true",
+                    help="N = 1: skip the one-GPU comparator of the 1 -> 8 scaling target (the whole 100 M x 768 f16 index, 154 GB)")
+    ap.add_argument("--dist-timeout", type=float, default=600.0,
+                    help="seconds a collective (or the rendezvous) may take before the process group aborts the rank")
+    ap.add_argument("--deadline", type=float, default=2700.0,
+                    help="seconds after which a rank that is still running gives up with exit code 124 (a hang must not outlive the run)")
     return ap.parse_args()
 
 
@@ -105,11 +114,15 @@ def build_shard(dev, row_begin, row_end, D, seed, dtype=torch.float32):
     that the content of a global row does not depend on the number of ranks.  N(0,1) entries,
     global row 0 all-zero (eps clamp), 1 % of each chunk's rows duplicated (exact ties).  Every chunk is
     normalised (C1) and stored in `dtype` as it is made, so a 100 M-row f16 index (154 GB, BASELINE config 4) is
-    built on one 288 GB GPU without ever holding its f32 form."""
+    built on one 288 GB GPU without ever holding its f32 form.  dtype "fp8": every chunk is quantised as it is made
+    (OCP e4m3 bytes + one f32 scale per row; the codec is row-wise, so chunking changes nothing) and
+    (bytes [n, D] uint8, scale [n] f32) is returned."""
     from evi_rag_amd import ops
 
     n = row_end - row_begin
-    shard = torch.empty((n, D), dtype=dtype, device=dev)
+    fp8 = dtype == "fp8"
+    shard = torch.empty((n, D), dtype=torch.uint8 if fp8 else dtype, device=dev)
+    scale = torch.empty(n, dtype=torch.float32, device=dev) if fp8 else None
     c0 = row_begin // CHUNK_ROWS
     c1 = (row_end + CHUNK_ROWS - 1) // CHUNK_ROWS
     gen = torch.Generator(device=dev)
@@ -125,9 +138,14 @@ def build_shard(dev, row_begin, row_end, D, seed, dtype=torch.float32):
         ops.normalize_embeddings(chunk, EPS, out=chunk)  # C1, in place: the resident index is normalised
         lo = max(row_begin, c * CHUNK_ROWS)
         hi = min(row_end, (c + 1) * CHUNK_ROWS)
-        shard[lo - row_begin: hi - row_begin] = chunk[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS]
+        if fp8:
+            b8, s8 = ops.quantize_rows_fp8(chunk[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS])
+            shard[lo - row_begin: hi - row_begin] = b8
+            scale[lo - row_begin: hi - row_begin] = s8
+        else:
+            shard[lo - row_begin: hi - row_begin] = chunk[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS]
         del chunk
-    return shard
+    return (shard, scale) if fp8 else shard
 
 
 def gold_row(step, qi, n_total):
@@ -135,10 +153,11 @@ def gold_row(step, qi, n_total):
     return (1 + (step * 7919 + qi * 104729) * 2654435761) % n_total
 
 
-def build_queries(dev, shard, row_begin, row_end, n_total, n_batches, Q, D, seed, world):
+def build_queries(dev, shard, row_begin, row_end, n_total, n_batches, Q, D, seed, world, row_scale=None):
     """Each query = normalise(gold index row + 0.5 * noise): Hits@k of the gold row is the
     size-independent correctness signal at full scale.  The rank that owns the gold row
-    contributes it; an all-reduce SUM assembles the batch on every rank."""
+    contributes it; an all-reduce SUM assembles the batch on every rank.  An e4m3 shard (uint8 + row_scale)
+    contributes the DEQUANTISED gold rows."""
     from evi_rag_amd import ops
 
     gold = torch.tensor([[gold_row(s, i, n_total) for i in range(Q)] for s in range(n_batches)], dtype=torch.int64)
@@ -146,7 +165,10 @@ def build_queries(dev, shard, row_begin, row_end, n_total, n_batches, Q, D, seed
     mine = (gold >= row_begin) & (gold < row_end)
     if bool(mine.any()):
         local = (gold[mine] - row_begin).to(dev)
-        base[mine.to(dev)] = shard.index_select(0, local).float()
+        rows = shard.index_select(0, local)
+        if rows.dtype == torch.uint8:  # OCP e4m3 = torch.float8_e4m3fn
+            rows = rows.view(torch.float8_e4m3fn).float() * row_scale.index_select(0, local).view(-1, 1)
+        base[mine.to(dev)] = rows.float()
     if world > 1:
         all_reduce_(base, dist.ReduceOp.SUM)
     gen = torch.Generator(device=dev)
@@ -426,33 +448,37 @@ def bench_encode(dev, D, *, texts=4096, batch_size=64, iters=3, autocast=None, f
     if autocast is not None:
         enc.autocast = {"bf16": torch.bfloat16, "f16": torch.float16}[autocast]
     names = [str(i) for i in range(texts)]
-    enc.encode_to_device(names[: 4 * batch_size], batch_size)
-    torch.cuda.synchronize(dev)
-    best = float("inf")
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        out = enc.encode_to_device(names, batch_size)
-        torch.cuda.synchronize(dev)
-        best = min(best, time.perf_counter() - t0)
     tokens = int(sum(max(lengths[b: b + batch_size]) * len(lengths[b: b + batch_size]) for b in range(0, texts, batch_size)))
     params = sum(p.numel() for n, p in model.named_parameters() if "embeddings" not in n)
     flops = 2.0 * params * tokens
-    res = {"workload": f"{texts} texts of 8..32 tokens in batches of {batch_size}; random-init BERT {layers}L/{D}H, "
-                       f"{'f32' if autocast is None else autocast + ' autocast'}; PyTorch-ROCm forward + evi_masked_mean_pool",
-           "texts_per_s": texts / best, "ms_per_batch": best / (texts / batch_size) * 1e3, "padded_tokens": tokens,
-           "encoder_tflops": flops / best / 1e12, "out_shape": list(out.shape)}
-    # the same pass with the forward + pooling of each (batch, padded length) shape replayed as one hipGraph (TextEncoder.use_graphs)
-    enc.use_graphs = True
-    out_g = enc.encode_to_device(names, batch_size)  # captures every shape of the pass
+
+    def best_of(n):
+        best, out = float("inf"), None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = enc.encode_to_device(names, batch_size)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        return best, out
+
+    # eager launches (TextEncoder.use_graphs = False): what the reference's wrapper does
+    enc.use_graphs = False
+    enc.encode_to_device(names[: 4 * batch_size], batch_size)
     torch.cuda.synchronize(dev)
-    best_g = float("inf")
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        out_g = enc.encode_to_device(names, batch_size)
-        torch.cuda.synchronize(dev)
-        best_g = min(best_g, time.perf_counter() - t0)
-    res["graph_replay"] = {"texts_per_s": texts / best_g, "ms_per_batch": best_g / (texts / batch_size) * 1e3,
-                           "graphs_captured": len(enc._graphs), "max_abs_diff_to_eager": float((out_g - out).abs().max().item())}
+    best, out = best_of(iters)
+    # the encoder's DEFAULT: the forward + pooling of each (batch, padded length) shape replayed as one hipGraph
+    enc.use_graphs = True
+    enc.encode_to_device(names, batch_size)  # every shape of the pass was met in the eager passes: all captured here, untimed
+    torch.cuda.synchronize(dev)
+    best_g, out_g = best_of(iters)
+    res = {"workload": f"{texts} texts of 8..32 tokens in batches of {batch_size}; random-init BERT {layers}L/{D}H, "
+                       f"{'f32' if autocast is None else autocast + ' autocast'}; PyTorch-ROCm forward + evi_masked_mean_pool; "
+                       "the TextEncoder default: one hipGraph replay per (batch, padded length) shape",
+           "texts_per_s": texts / best_g, "ms_per_batch": best_g / (texts / batch_size) * 1e3, "padded_tokens": tokens,
+           "encoder_tflops": flops / best_g / 1e12, "out_shape": list(out_g.shape), "graphs_captured": len(enc._graphs),
+           "max_abs_diff_to_eager": float((out_g - out).abs().max().item()),
+           "eager": {"what": "use_graphs = False: every kernel launched from Python", "texts_per_s": texts / best,
+                     "ms_per_batch": best / (texts / batch_size) * 1e3, "encoder_tflops": flops / best / 1e12}}
     enc.use_graphs = False
     if fp8_table:
         k = 100
@@ -480,18 +506,26 @@ def _lib_load():
 
 
 def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3, nodes=1500, edges=4096, relations=4096):
-    """ONE query = one question, one stream, one timed loop (SURVEY.md §8d restated metric): a batch of 32 question texts ->
-    `TextEncoder.encode_to_device` (random-init bge-base-shaped BERT + pooling kernel) -> L2 normalise -> exact cosine
-    top-500 over the resident index -> `Retriever.forward` on the batch's WebQSP-shaped subgraphs (with the encoded
-    questions as `question_emb`) -> fused ranking metrics.  The index candidates do not choose the subgraphs (the
-    reference has no such link either: its graphs come from the dataset), so the stages are chained in time, not in data,
-    except for the question embeddings.  Per-stage times come from events on the same stream; the slowest is named."""
+    """ONE query = one question (SURVEY.md §8d restated metric): a batch of 32 question texts -> `TextEncoder.encode_to_device`
+    (random-init bge-base-shaped BERT + pooling kernel) -> L2 normalise -> exact cosine top-500 over the resident index ->
+    `Retriever.forward` on the batch's WebQSP-shaped subgraphs (with the encoded questions as `question_emb`) -> fused
+    ranking metrics.  The index candidates do not choose the subgraphs (the reference has no such link either: its graphs
+    come from the dataset), so the stages are chained in time, not in data, except for the question embeddings.
+
+    `queries_per_s` (top level) is the PIPELINE with the library's defaults: the three stages on three HIP streams with two
+    buffer slots, the encoder replayed as hipGraphs (TextEncoder.use_graphs, default), the top-k through
+    `ops.cosine_topk` (method "auto": the two-stage exact scan, because the index's f16 shadow is resident).  Sub-objects:
+    `serial` = the same defaults issued on ONE stream (per-stage event times; the slowest stage is named), and
+    `serial_eager_f32_scan` = round 2's settings (eager encoder launches, f32 scan) for continuity.  Every variant's last
+    top-k must equal the f32 scan's bit for bit."""
+    import copy as _copy
+
     from evi_rag_amd import metrics as M, ops, synthetic
     from evi_rag_amd.retriever import Retriever
     from evi_rag_amd.text_encode import TextEncoder
 
     index = build_shard(dev, 0, rows, D, seed)
-    ws = torch.empty(ops.cosine_topk_workspace_bytes(questions, rows, D, k), dtype=torch.uint8, device=dev)
+    shadow = ops.index_shadow_f16(index)  # attaches itself to `index`: cosine_topk(method="auto") finds it
     out_topk = (torch.empty((questions, k), dtype=torch.float32, device=dev), torch.empty((questions, k), dtype=torch.int64, device=dev))
     model, layers = _random_bert(dev, D)
     rng = np.random.default_rng(1)
@@ -505,30 +539,31 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
     torch.manual_seed(0)
     scorer = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
     scorer.emit_edge_embeddings = False  # what the evaluation keeps: logits
-    coll = M.RetrieverMetricCollection(K_WINDOW)
     target = batch.labels > 0.5
     stages = ["encode", "topk", "scorer", "metrics"]
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iters)]
+    name_list = lambda it: [str(it * questions + j) for j in range(questions)]  # noqa: E731
 
-    def one(it, marks=None):
-        names = [str(it * questions + j) for j in range(questions)]
-        if marks:
-            marks[0].record()
-        q = ops.normalize_embeddings(enc.encode_to_device(names, questions), EPS)
-        if marks:
-            marks[1].record()
-        ops.cosine_topk(q, index, k, workspace=ws, out=out_topk)
-        if marks:
-            marks[2].record()
-        batch.question_emb = q
-        out = scorer(batch)
-        if marks:
-            marks[3].record()
-        coll.update(preds=out.logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=questions)
-        if marks:
-            marks[4].record()
+    def run_serial(method):
+        coll = M.RetrieverMetricCollection(K_WINDOW)
 
-    def run_serial():
+        def one(it, marks=None):
+            if marks:
+                marks[0].record()
+            q = ops.normalize_embeddings(enc.encode_to_device(name_list(it), questions), EPS)
+            if marks:
+                marks[1].record()
+            ops.cosine_topk(q, index, k, out=out_topk, method=method)
+            if marks:
+                marks[2].record()
+            batch.question_emb = q
+            out = scorer(batch)
+            if marks:
+                marks[3].record()
+            coll.update(preds=out.logits, target=target, indexes=out.query_ids, batch=batch, num_graphs=questions)
+            if marks:
+                marks[4].record()
+
         for it in range(warmup):
             one(it)
         torch.cuda.synchronize(dev)
@@ -537,29 +572,34 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
             one(warmup + it, ev[it])
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
-        return wall, {s: sum(ev[it][j].elapsed_time(ev[it][j + 1]) for it in range(iters)) / iters for j, s in enumerate(stages)}
+        per = {s: sum(ev[it][j].elapsed_time(ev[it][j + 1]) for it in range(iters)) / iters for j, s in enumerate(stages)}
+        metrics = {kk: float(v) for kk, v in coll.compute().items()}
+        return {"queries_per_s": questions * iters / wall, "ms_per_batch": wall / iters * 1e3, "stage_ms_per_batch": per,
+                "slowest_stage": max(per, key=per.get), "host_gap_ms_per_batch": wall / iters * 1e3 - sum(per.values()),
+                "topk_method": ops.cosine_topk.last_method, "reachability@100": metrics.get("answer/reachability@100")}
 
-    wall, per = run_serial()
-    metrics = {kk: float(v) for kk, v in coll.compute().items()}
-    slowest = max(per, key=per.get)
-    res = {"workload": f"{questions} questions per batch: encode (random-init BERT {layers}L/{D}H, f32) -> top-{k} over {rows} x {D} f32 "
-                       f"-> scorer on {questions} WebQSP-shaped graphs (E={sb.num_edges}, D=H={D}, logits only) -> fused metrics",
-           "queries_per_s": questions * iters / wall, "ms_per_batch": wall / iters * 1e3,
-           "stage_ms_per_batch": per, "slowest_stage": slowest,
-           "host_gap_ms_per_batch": wall / iters * 1e3 - sum(per.values()),
-           "reachability@100": metrics.get("answer/reachability@100"), "best_score_mean": float(out_topk[0][:, 0].mean().item())}
+    # ---- round 2's settings: eager encoder launches, f32 scan; its last top-k is the reference for the others
+    enc.use_graphs = False
+    legacy = run_serial("scan")
+    scan_topk = (out_topk[0].clone(), out_topk[1].clone())
+    # ---- the defaults on one stream.  Every (batch, length) shape of the run was met in the eager loop: captured in this
+    # untimed priming pass (a capture costs tens of ms, once per shape per process)
+    enc.use_graphs = True
+    for it in range(warmup + iters):
+        enc.encode_to_device(name_list(it), questions)
+    torch.cuda.synchronize(dev)
+    serial = run_serial("auto")
+    serial["last_topk_identical_to_f32_scan"] = bool(torch.equal(out_topk[1], scan_topk[1]) and torch.equal(out_topk[0], scan_topk[0]))
+    serial["what"] = ("one stream, library defaults: encoder forward + pooling replayed as one hipGraph per shape; ops.cosine_topk "
+                      "method 'auto' = the two-stage exact scan over the resident f16 shadow (device-side repair of a failed proof)")
+    legacy["what"] = "one stream, round 2's settings: eager encoder launches, f32 scan (method='scan')"
 
-    # The same work as a three-stream pipeline: encode on one HIP stream, the index top-k (HBM-bound; the two-stage exact
-    # scan: same ids and scores at half the bytes) on a second, scorer + metrics (MFMA-bound) on a third.  Batch i's top-k
-    # and scorer both wait for its encode; nothing else orders them, so the HBM-bound scan of one batch runs under the
-    # matrix-bound encode / scorer of its neighbours.  Two slots of buffers; results are compared with the serial loop's.
-    import copy as _copy
-
-    shadow = ops.index_shadow_f16(index)
+    # ---- The same work as a three-stream pipeline: encode on one HIP stream, the index top-k (HBM-bound) on a second, scorer +
+    # metrics (MFMA-bound) on a third.  Batch i's top-k and scorer both wait for its encode; nothing else orders them, so the
+    # HBM-bound scan of one batch runs under the matrix-bound encode / scorer of its neighbours.  Two slots of buffers.
     ts_ws = torch.empty(int(_lib_load().evi_cosine_topk_two_stage_workspace_bytes(questions, rows, D, k)), dtype=torch.uint8, device=dev)
     s_enc, s_topk, s_sc = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1)
     slots = 2
-    q_slot = [None] * slots
     topk_slot = [(torch.empty((questions, k), dtype=torch.float32, device=dev), torch.empty((questions, k), dtype=torch.int64, device=dev))
                  for _ in range(slots)]
     batches = [_copy.copy(batch) for _ in range(slots)]
@@ -571,17 +611,15 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
 
     def pipelined(it):
         sl = it % slots
-        names = [str(it * questions + j) for j in range(questions)]
         with torch.cuda.stream(s_enc):
             s_enc.wait_event(topk_done[sl])  # the slot's previous consumers are done with its query buffer
             s_enc.wait_event(sc_done[sl])
-            q = ops.normalize_embeddings(enc.encode_to_device(names, questions), EPS)
-            q_slot[sl] = q
+            q = ops.normalize_embeddings(enc.encode_to_device(name_list(it), questions), EPS)
             keep.append(q)
             enc_done[sl].record(s_enc)
         with torch.cuda.stream(s_topk):
             s_topk.wait_event(enc_done[sl])
-            ops.cosine_topk_two_stage(q, index, shadow, k, workspace=ts_ws, out=topk_slot[sl])
+            ops.cosine_topk_two_stage(q, index, shadow, k, workspace=ts_ws, out=topk_slot[sl])  # what method="auto" calls, own workspace
             topk_done[sl].record(s_topk)
         with torch.cuda.stream(s_sc):
             s_sc.wait_event(enc_done[sl])
@@ -592,48 +630,32 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
             keep.append(o)
             sc_done[sl].record(s_sc)
 
-    def run_pipelined():
-        torch.cuda.synchronize(dev)
-        for it in range(warmup):
-            pipelined(it)
-        torch.cuda.synchronize(dev)
-        keep.clear()
-        t0 = time.perf_counter()
-        for it in range(iters):
-            pipelined(warmup + it)
-        torch.cuda.synchronize(dev)
-        wall_p = time.perf_counter() - t0
-        last = topk_slot[(warmup + iters - 1) % slots]
-        return wall_p, bool(torch.equal(last[1], out_topk[1]) and torch.equal(last[0], out_topk[0]))
-
-    wall_p, same_topk = run_pipelined()
-    res["pipelined"] = {"what": "encode | two-stage exact top-k | scorer + metrics on three HIP streams, two buffer slots; the HBM-bound scan "
-                                "runs under the MFMA-bound encoder and scorer of the neighbouring batches",
-                        "queries_per_s": questions * iters / wall_p, "ms_per_batch": wall_p / iters * 1e3,
-                        "last_topk_identical_to_serial_loop": same_topk,
-                        "speedup_over_serial_loop": (wall / iters) / (wall_p / iters)}
-    # The encoder stage is launch-bound (32 short questions: ~200 kernels that finish faster than PyTorch issues them), and in
-    # the pipeline the one Python thread issues all three stages.  TextEncoder.use_graphs replays the forward + pooling of
-    # each (batch, padded length) shape as ONE hipGraph launch — the same kernels on the same shapes.  Every shape of the run
-    # is captured before the clock starts (a capture costs tens of ms, once per shape per process).
-    eager_topk = (out_topk[0].clone(), out_topk[1].clone())
-    enc.use_graphs = True
-    for it in range(warmup + iters):
-        enc.encode_to_device([str(it * questions + j) for j in range(questions)], questions)
     torch.cuda.synchronize(dev)
-    wall_g, per_g = run_serial()
-    same_g = bool(torch.equal(out_topk[1], eager_topk[1]) and torch.allclose(out_topk[0], eager_topk[0], rtol=0, atol=1e-6))
-    wall_pg, same_pg = run_pipelined()
-    res["graphed_encoder"] = {"what": "the same two loops with TextEncoder.use_graphs: encoder forward + pooling replayed as one hipGraph per "
-                                      "(batch, padded length) shape",
-                              "queries_per_s": questions * iters / wall_g, "ms_per_batch": wall_g / iters * 1e3,
-                              "stage_ms_per_batch": per_g, "graphs_captured": len(enc._graphs),
-                              "last_topk_identical_to_eager_loop": same_g,
-                              "pipelined": {"queries_per_s": questions * iters / wall_pg, "ms_per_batch": wall_pg / iters * 1e3,
-                                            "last_topk_identical_to_serial_loop": same_pg}}
-    enc.use_graphs = False
-    del shadow, ts_ws
-    del index, ws
+    for it in range(warmup):
+        pipelined(it)
+    torch.cuda.synchronize(dev)
+    keep.clear()
+    t0 = time.perf_counter()
+    for it in range(iters):
+        pipelined(warmup + it)
+    torch.cuda.synchronize(dev)
+    wall_p = time.perf_counter() - t0
+    last = topk_slot[(warmup + iters - 1) % slots]
+    same_p = bool(torch.equal(last[1], scan_topk[1]) and torch.equal(last[0], scan_topk[0]))
+    res = {"workload": f"{questions} questions per batch: encode (random-init BERT {layers}L/{D}H, f32) -> top-{k} over {rows} x {D} f32 "
+                       f"-> scorer on {questions} WebQSP-shaped graphs (E={sb.num_edges}, D=H={D}, logits only) -> fused metrics",
+           "what": "encode | exact top-k | scorer + metrics on three HIP streams, two buffer slots, library defaults (graph-replayed "
+                   "encoder, two-stage exact scan): the HBM-bound scan runs under the MFMA-bound encoder and scorer of the "
+                   "neighbouring batches",
+           "queries_per_s": questions * iters / wall_p, "ms_per_batch": wall_p / iters * 1e3,
+           "last_topk_identical_to_f32_scan": same_p,
+           "last_topk_identical_to_serial_loop": same_p and serial["last_topk_identical_to_f32_scan"],
+           "speedup_over_serial_loop": serial["ms_per_batch"] / (wall_p / iters * 1e3),
+           "graphs_captured": len(enc._graphs),
+           "serial": serial, "serial_eager_f32_scan": legacy,
+           "best_score_mean": float(scan_topk[0][:, 0].mean().item())}
+    ops.drop_shadow_f16(index)
+    del shadow, ts_ws, index
     torch.cuda.empty_cache()
     return res
 
@@ -819,13 +841,49 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    # a session of its own: if the ranks outlive the deadline the whole group (launcher + ranks) is killed — fresh
+    # children only, this process is never replaced
+    import signal
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    limit = float(args.deadline) + 120.0  # the ranks' own deadline fires first; this one covers a launcher that hangs
+    try:
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run gave no result within {limit:.0f} s: its process group was killed\n")
+        raise SystemExit(124)
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
     if proc.returncode != 0 or not lines:
         sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode}, {len(lines)} result lines)\n")
         raise SystemExit(proc.returncode or 1)
     print(lines[-1], flush=True)
     raise SystemExit(0)
+
+
+def arm_deadline(seconds, rank):
+    """A rank that is still running after `seconds` gives up loudly (exit code 124) instead of sitting in a collective
+    or a rendezvous that will never complete: a daemon timer thread, `os._exit` so that no atexit / destructor can block."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py: rank {rank} still running after {seconds:.0f} s (--deadline): giving up, exit code 124\n")
+        sys.stderr.flush()
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 class Ctx:
@@ -854,17 +912,23 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
     dev, world, rank, lib = ctx.dev, ctx.world, ctx.rank, ctx.lib
     row_begin = N * rank // world
     row_end = N * (rank + 1) // world
-    shard = build_shard(dev, row_begin, row_end, D, seed, torch.float16 if index_dtype == "f16" else torch.float32)
-    elem_bytes = 2 if index_dtype == "f16" else 4
-    n_batches = warmup + steps
-    queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, seed, world)
+    t_build = time.perf_counter()
     row_scale = None
     f32_sample = None
     if index_dtype == "fp8":
-        f32_sample = shard[: max(cpu_rows, 1 << 20)].clone()  # CPU baseline / overlap@k reference rows
-        shard, row_scale = ops.quantize_rows_fp8(shard)
+        # quantised chunk by chunk as it is generated: the f32 form of the shard never exists (a 50 M x 1024 shard of a
+        # 2-rank run would be 205 GB of f32); the first rows are generated once more in f32 as the overlap@k / CPU reference
+        shard, row_scale = build_shard(dev, row_begin, row_end, D, seed, "fp8")
+        if world == 1:
+            f32_sample = build_shard(dev, row_begin, min(row_end, row_begin + max(cpu_rows, 1 << 20)), D, seed)
         elem_bytes = 1
-        torch.cuda.empty_cache()
+    else:
+        shard = build_shard(dev, row_begin, row_end, D, seed, torch.float16 if index_dtype == "f16" else torch.float32)
+        elem_bytes = 2 if index_dtype == "f16" else 4
+    n_batches = warmup + steps
+    queries, gold = build_queries(dev, shard, row_begin, row_end, N, n_batches, Q, D, seed, world, row_scale=row_scale)
+    torch.cuda.synchronize(dev)
+    t_build = time.perf_counter() - t_build
     ws = torch.empty(ops.cosine_topk_workspace_bytes(Q, row_end - row_begin, D, k), dtype=torch.uint8, device=dev)
     if method == "two_stage" and index_dtype != "f32":
         raise SystemExit("--topk-method two_stage goes with the f32 index (its f16 shadow is built here)")
@@ -874,9 +938,16 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
     index = ShardedIndex(shard, N, row_scale=row_scale, method=method, shadow=shadow, fp8_mfma=fp8_mfma and index_dtype == "fp8",
                          exchange=xchg)
     index.workspace = ws
+    # every rank takes the same pipeline form: if the lane-1 communicator or the first two-lane step fails on ANY rank,
+    # all ranks drop IN-PROCESS to one communicator driven from one side stream (ShardedIndex.agree_on_lanes)
+    if world > 1:
+        index.agree_on_lanes(queries[0], k)
+    lane_fallback = index.lane_fallback
 
-    def timed_run(index, steps=steps, warmup=warmup):
+    def timed_run(index, steps=steps, warmup=warmup, queries=queries):
         """W untimed + K timed steps of `index`; returns (seconds — max over ranks, kernel ms per class, launches, last result)."""
+        n_batches = queries.shape[0]
+
         def step(b):
             # per-shard exact top-k; for world > 1 ONE all-gather of the packed [Q, k] (score, id) records + merge,
             # pipelined with the next batch's scan (every result is complete at the closing fence)
@@ -998,6 +1069,8 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         shadow = ops.index_shadow_f16(shard)
         idx2 = ShardedIndex(shard, N, method="two_stage", shadow=shadow, exchange=xchg)
         idx2.workspace = ws
+        if world > 1:
+            idx2.agree_on_lanes(queries[0], k)
         e2, ms2, l2, out2 = timed_run(idx2)
         failed = idx2.two_stage_failed()
         same = bool(torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1]))
@@ -1024,6 +1097,8 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
     if index_dtype == "fp8" and fp8_ab and not fp8_mfma:
         idx3 = ShardedIndex(shard, N, row_scale=row_scale, method="scan", fp8_mfma=True, exchange=xchg)
         idx3.workspace = ws
+        if world > 1:
+            idx3.agree_on_lanes(queries[0], k)
         e3, ms3, l3, out3 = timed_run(idx3)
         b3 = (row_end - row_begin) * D + Q * D * 4 + Q * k * 12 + (row_end - row_begin) * 4
         sc3 = ms3[0] / steps
@@ -1068,6 +1143,26 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
                 "identical_ids": bool(torch.equal(r_scan[1], r_gemm[1])), "identical_scores": bool(torch.equal(r_scan[0], r_gemm[0])),
                 "planted_row_in_top10": found}
         del mq, r_scan, r_gemm
+    elif many_query and world > 1 and index_dtype in ("f32", "f16"):
+        # N > 1: Q = 512 per step over the row-sharded index.  Every rank runs the GEMM-shaped pass (ops.cosine_topk
+        # method "auto": split-bf16 selection + exact re-scoring, the scan's result bit for bit) over ITS rows for ALL the
+        # queries, then the same single all-gather of the packed [Q, k] records + merge.  That pass reads its proof flag
+        # back once per call (a stream synchronisation), so this leg runs the one-communicator side-stream form.
+        m_steps, m_warm = max(2, steps // 4), 1
+        mq, mgold = build_queries(dev, shard, row_begin, row_end, N, m_steps + m_warm, many_query, D, seed + 77, world,
+                                  row_scale=row_scale)
+        idxm = ShardedIndex(shard, N, row_scale=row_scale, method="auto", exchange=xchg)
+        idxm.two_lanes = False
+        em, msm, lm, outm = timed_run(idxm, steps=m_steps, warmup=m_warm, queries=mq)
+        gm = mgold[(m_warm + m_steps - 1) % (m_steps + m_warm)].to(dev).view(many_query, 1)
+        found = float((outm[1][:, :10] == gm).any(dim=1).float().mean().item())
+        many = {"queries_per_step": many_query, "value": many_query * m_steps / em, "unit": "queries/s", "steps": m_steps,
+                "ms_per_step": em / m_steps * 1e3, "method": "auto (GEMM-shaped pass per shard; the scan if its proof fails)",
+                "pipeline": "one communicator, side stream (the pass synchronises its stream once per call)",
+                "selection_products": ops.cosine_topk_gemm.last_products,
+                "executed_TFLOPs_per_rank_lower_bound": 2.0 * many_query * (row_end - row_begin) * D / (em / m_steps) / 1e12,
+                "planted_row_in_top10": found, "sorted_ok": bool((outm[0][:, 1:] <= outm[0][:, :-1]).all().item())}
+        del mq, idxm, outm
 
     # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
     s_last, i_last = out
@@ -1085,6 +1180,18 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         inter = (i8.unsqueeze(2) == i32.unsqueeze(1)).any(dim=2).float().sum(dim=1)
         overlap = {"rows": int(nr), "overlap_at_k": float((inter / k).mean().item()), "k": k,
                    "max_abs_score_diff_on_common_rows": float((s8[:, 0] - s32[:, 0]).abs().max().item())}
+
+    # who took part: every rank reports its device (a collective; rank 0 prints it)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": dev.index, "name": props.name, "rows": [row_begin, row_end],
+          "hbm_GiB": round(props.total_memory / 2 ** 30, 1), "pid": os.getpid()}
+    if hasattr(props, "uuid"):
+        me["uuid"] = str(props.uuid)
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+    else:
+        everyone = [me]
 
     result = None
     if rank == 0:
@@ -1120,6 +1227,9 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
                 "topk_method": method,
                 "sharding": f"rows/{world}" if world > 1 else "none",
             },
+            "ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "devices": everyone,
+            "index_build_seconds": t_build,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -1137,6 +1247,10 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         }
         result["roofline"].update(pmc_traffic(N, D, Q, k, world, score_ms_per_step, method) if index_dtype == "f32"
                                   else {"traffic": None, "traffic_source": None})
+        if bool(getattr(index, "_exchange", False)) and not index.two_lanes:
+            result["config"]["pipeline"] = ("one communicator: scan on the main stream, all-gather + merge of the previous batch on a "
+                                            "high-priority side stream" +
+                                            (f" (FALLBACK from two lanes: {lane_fallback})" if lane_fallback else ""))
         if bool(getattr(index, "_exchange", False) and getattr(index, "two_lanes", False)):
             result["config"]["pipeline"] = "two lanes (two hardware queues): scan, selections, all-gather and merge of a batch on its lane"
             result["roofline"]["timed_in"] = ("warm-up steps that run the shard's scan and selections alone on one stream: kernel event "
@@ -1196,11 +1310,17 @@ def main():
     # EVI_FORCE_EXCHANGE=1 under torch.distributed.run with ONE rank rehearses the multi-rank path (all-gather + merge
     # on the side stream) on a single GPU
     rehearse = world == 1 and os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and "MASTER_ADDR" in os.environ
+    arm_deadline(float(args.deadline), rank)
     if world > 1 or rehearse:
+        from datetime import timedelta
+
+        # bounded rendezvous and collectives: a rank that never arrives makes the others fail after --dist-timeout
+        # (RCCL's watchdog aborts the communicator and the process) instead of waiting for ever
+        tmo = timedelta(seconds=float(args.dist_timeout))
         if REHEARSAL_BACKEND == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
 
     from evi_rag_amd import _lib
 
@@ -1216,8 +1336,42 @@ def main():
                            method=args.topk_method, steps=args.steps, warmup=args.warmup, seed=args.seed,
                            want_two_stage=not args.no_two_stage, sustained_s=2.0 if extra else 0.0,
                            cpu_rows=args.cpu_rows, cpu_seconds=cpu_s, fp8_mfma=args.fp8_mfma)
+    # ---- N > 1: the BASELINE scaling target is quoted on the 100 M-triple index (configs[3]) — measure THAT, row-sharded
+    # over the ranks of this run, and configs[4] (e4m3, D = 1024, native fp8 MFMA) the same way.  Every rank takes part
+    # (the legs are collective); rank 0 holds the objects.  N = 1 runs the same index whole on the one GPU (`config4_full`
+    # below), so the 1 -> N ratio has both ends in the driver's own lines.
+    if world > 1 and not args.no_extra_legs:
+        torch.cuda.empty_cache()
+        c4 = run_index_leg(
+            ctx, N=args.config4_rows, D=768, Q=32, k=args.k, index_dtype="f16", method="scan", steps=args.steps,
+            warmup=args.warmup, seed=3, many_query=512,
+            workload=f"configs[3]: {args.config4_rows} x 768 index, f16 storage, row-sharded over {world} MI355X, per-shard exact "
+                     "top-k + ONE RCCL all-gather of the packed [Q, k] records + merge on every rank; Q = 32 (and Q = 512 in many_query)")
+        torch.cuda.empty_cache()
+        c5 = run_index_leg(
+            ctx, N=args.config4_rows, D=1024, Q=32, k=args.k, index_dtype="fp8", method="scan", steps=args.steps,
+            warmup=args.warmup, seed=4, fp8_mfma=True,
+            workload=f"configs[4]: {args.config4_rows} x 1024 index, OCP e4m3 storage + f32 row scale (bge-large dim), native fp8 "
+                     f"MFMA scoring, row-sharded over {world} MI355X + RCCL all-gather merge")
+        if rank == 0:
+            result["config4_sharded"] = c4
+            result["config5_sharded"] = c5
     if rank == 0:
         D = args.dim
+        if extra and not args.no_config4_full:
+            # the one-GPU end of the 1 -> 8 target: the WHOLE configs[3] index (100 M x 768 f16 = 154 GB of the 288 GB) on this GPU
+            free_b, _total = torch.cuda.mem_get_info(dev)
+            need_b = args.config4_rows * 768 * 2 + (12 << 30)
+            if free_b >= need_b:
+                result["config4_full"] = run_index_leg(
+                    ctx, N=args.config4_rows, D=768, Q=32, k=args.k, index_dtype="f16", method="scan", steps=min(args.steps, 10),
+                    warmup=min(args.warmup, 2), seed=3, many_query=512 if args.config4_rows <= 100_000_000 else 0,
+                    workload=f"configs[3] on ONE GPU: the whole {args.config4_rows} x 768 index, f16 storage "
+                             f"({args.config4_rows * 768 * 2 / 1e9:.1f} GB resident), brute-force cosine top-k — the N = 1 end of the "
+                             "1 -> 8 scaling target (`config4_sharded` in the N > 1 lines is the other)")
+            else:
+                result["config4_full"] = {"skipped": f"needs {need_b / 1e9:.0f} GB of free HBM, {free_b / 1e9:.0f} GB free"}
+            torch.cuda.empty_cache()
         if extra:
             # BASELINE configs 4 and 5 as far as ONE GPU can show them: the shard one of 8 ranks holds of the 100 M-row index
             # (12.5 M rows), in the storage type the config names, through the same scan — each with its own roofline

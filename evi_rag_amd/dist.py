@@ -124,19 +124,69 @@ class ShardedIndex:
         # EVI_FORCE_EXCHANGE=1 runs the exchange even with one rank (rehearses the multi-rank path on one GPU)
         self._exchange = self.world > 1 or (os.environ.get("EVI_FORCE_EXCHANGE", "") == "1" and dist.is_initialized())
         self._lane_groups = [group, group]
+        # why this index runs the one-communicator side-stream pipeline although two lanes were asked for (None: it does not)
+        self.lane_fallback: Optional[str] = None
+        inject = os.environ.get("EVI_INJECT_LANE_FAILURE", "")  # tests: "group" | "step" | "step:<rank>"
         if lane_groups is not None:
             if len(lane_groups) != 2:
                 raise ValueError("lane_groups must hold two process groups (one per pipeline lane)")
             self._lane_groups = list(lane_groups)
-        elif exchange is None and self._exchange and self.two_lanes and dist.is_initialized():
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            key = (tuple(ranks), dist.get_backend(group))
-            if key not in _LANE1_GROUPS:  # one extra communicator per set of ranks for the life of the process
-                _LANE1_GROUPS[key] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
-            self._lane_groups[1] = _LANE1_GROUPS[key]
+        elif self._exchange and self.two_lanes and dist.is_initialized() and (exchange is None or inject == "group"):
+            # The second communicator is an optimisation, not a requirement: if it cannot be created (RCCL out of
+            # channels / memory, a launcher that forbids a second communicator), this rank falls back to ONE communicator
+            # driven from ONE side stream; `agree_on_lanes` then makes every rank take the same form.
+            try:
+                if inject == "group":
+                    raise RuntimeError("injected: the lane-1 communicator could not be created (EVI_INJECT_LANE_FAILURE=group)")
+                ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+                key = (tuple(ranks), dist.get_backend(group))
+                if key not in _LANE1_GROUPS:  # one extra communicator per set of ranks for the life of the process
+                    _LANE1_GROUPS[key] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+                self._lane_groups[1] = _LANE1_GROUPS[key]
+            except Exception as exc:  # noqa: BLE001 - whatever the backend raises
+                self.two_lanes = False
+                self.lane_fallback = f"lane-1 communicator: {type(exc).__name__}: {exc}"
+        self._inject_step_failure = inject.startswith("step") and (":" not in inject or int(inject.split(":")[1]) == self.rank)
 
     def _rccl_all_gather(self, all_records: torch.Tensor, local_record: torch.Tensor, lane: int = 0) -> None:
         dist.all_gather_into_tensor(all_records, local_record, group=self._lane_groups[lane] if hasattr(self, "_lane_groups") else self.group)
+
+    def _any_rank(self, flag: bool) -> bool:
+        """MAX of a boolean over the ranks of `group` (a collective on the MAIN communicator; host-staged unless RCCL)."""
+        if not (self.world > 1 and dist.is_initialized()):
+            return bool(flag)
+        if dist.get_backend(self.group) == "nccl":
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.shard.device)
+        else:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
+    def agree_on_lanes(self, queries: Optional[torch.Tensor] = None, k: Optional[int] = None) -> bool:
+        """Make every rank run the SAME pipeline form (a collective: every rank calls it at the same point).
+
+        A rank whose lane-1 communicator could not be created has already dropped to the one-communicator side-stream
+        form; if `queries` is given, one batch per lane is pushed through the two-lane path first (the first collective
+        on a communicator is where RCCL builds its channels — and where it fails if it is going to).  If ANY rank failed
+        either step, all ranks drop to the side-stream form, in-process: the lanes' buffers are released, nothing is
+        re-launched.  Returns True when two lanes are in use afterwards."""
+        if not self._exchange:
+            return False
+        failed = self.lane_fallback
+        if failed is None and self.two_lanes and queries is not None and queries.is_cuda:
+            try:
+                for _ in range(2):  # one batch per lane
+                    self.topk_async(queries, int(k))
+                torch.cuda.synchronize(queries.device)
+            except Exception as exc:  # noqa: BLE001
+                failed = f"first two-lane step: {type(exc).__name__}: {exc}"
+        anyone = self._any_rank(failed is not None or not self.two_lanes)
+        if anyone:
+            self.two_lanes = False
+            self._lanes = None
+            if self.lane_fallback is None:
+                self.lane_fallback = failed or "another rank could not run two lanes"
+        return bool(self.two_lanes)
 
     def _two_stage_workspace(self, queries: torch.Tensor, k: int, lane: int = 0) -> torch.Tensor:
         from . import _lib
@@ -288,6 +338,9 @@ def _topk_async_lanes(self: "ShardedIndex", queries: torch.Tensor, k: int, main)
                            "done": [torch.cuda.Event() for _ in range(2)]}
     slot = p["slot"]
     p["slot"] = slot ^ 1
+    if slot == 1 and self._inject_step_failure:
+        self._inject_step_failure = False
+        raise RuntimeError("injected: the first lane-1 step failed (EVI_INJECT_LANE_FAILURE=step)")
     lane = p["streams"][slot]
     lane.wait_stream(main)  # the queries (and whatever else the caller enqueued) are ready
     queries.record_stream(lane)

@@ -146,24 +146,38 @@ def cosine_topk(
     row_id_base: int = 0,
     workspace: Optional[torch.Tensor] = None,
     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-    method: str = "scan",
-    fp8_mfma: bool = False,
+    method: str = "auto",
+    fp8_mfma: Optional[bool] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Top-k rows of `index` per query by dot product (cosine when both are L2-normalised, or when
     `index` is raw and row_scale = row_inv_norm(index)).  Returns (scores [Q,k] f32, ids [Q,k] i64),
     ordered (score desc, id asc); slots past min(k, N) hold (-inf, -1).
-    method: "scan" (default: 32 queries per pass over the index, never synchronises), "gemm" (many queries in
-    one GEMM-shaped pass, same result, one synchronisation — see cosine_topk_gemm) or "auto" (gemm for
-    Q >= 96 on an f32 index of unit rows when its limits allow, else scan).
-    fp8_mfma (e4m3 index only): feed the index bytes to the native fp8 matrix instruction with the query as two e4m3
-    pieces (evi_cosine_topk_fp8_mfma) instead of widening them to f16 — no conversion work on the stream; scores carry
-    8 significant query bits, far inside the index's own quantisation noise."""
+    method — every choice returns the SAME ids and scores, bit for bit (tested):
+      "auto" (default): the fastest exact path the inputs allow —
+          * Q >= 96 on an f32 / f16 index of unit rows: the GEMM-shaped pass (cosine_topk_gemm; one synchronisation);
+          * an f32 index whose f16 shadow is resident (built by `index_shadow_f16(index)`, which attaches it to the
+            tensor): the two-stage scan — half the HBM bytes per batch; a batch whose exactness proof fails is re-done
+            by the gated f32 scan ON THE DEVICE, nothing is read back (2.36 vs 4.57 ms per batch at 2^23 x 768);
+          * else the scan.
+      "scan": 32 queries per pass over the index, never synchronises.
+      "gemm": force the GEMM-shaped pass (see cosine_topk_gemm).
+    fp8_mfma (e4m3 index only; default None = True): feed the index bytes to the native fp8 matrix instruction with the
+    query as two e4m3 pieces (evi_cosine_topk_fp8_mfma) — no conversion work on the stream (5.86 vs 5.43 TB/s); scores
+    carry 16 significant query bits, ~20x inside the index's own quantisation noise (overlap@500 with the widening
+    variant 0.999).  False: widen the index bytes to f16 in registers and keep the f32 query exact."""
     if method not in ("scan", "gemm", "auto"):
         raise ValueError(f"method must be 'scan', 'gemm' or 'auto', got {method!r}")
     if method != "scan" and index.dtype in (torch.float32, torch.float16) and queries.dim() == 2 and index.dim() == 2:
         eligible = index.size(1) % (32 if index.dtype == torch.float16 else 16) == 0 and k + max(256, k // 2) <= 2048 and index.size(0) >= 1 and queries.size(0) >= 1
         if method == "gemm" or (eligible and queries.size(0) >= 96):
+            cosine_topk.last_method = "gemm"
             return cosine_topk_gemm(queries, index, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
+        shadow = resident_shadow_f16(index) if (method == "auto" and row_scale is None and index.dtype == torch.float32) else None
+        if shadow is not None and queries.size(0) >= 1 and index.size(0) >= 1 and k + max(256, k // 2) <= 2048 and index.size(1) % 32 == 0 \
+                and queries.dtype == torch.float32 and queries.size(1) == index.size(1):
+            cosine_topk.last_method = "two_stage"
+            return cosine_topk_two_stage(queries, index, shadow, k, row_id_base=row_id_base, out=out, fallback="device")
+    cosine_topk.last_method = "scan"
     dev = _require_gpu(queries, index, row_scale, workspace)
     if queries.dim() != 2 or index.dim() != 2:
         raise ValueError("queries and index must be 2D")
@@ -200,6 +214,8 @@ def cosine_topk(
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     if fp8_mfma and x.dtype != torch.uint8:
         raise ValueError("fp8_mfma goes with an e4m3 (uint8) index")
+    if fp8_mfma is None:
+        fp8_mfma = x.dtype == torch.uint8
     fn = {torch.float16: lib.evi_cosine_topk_f16,
           torch.uint8: lib.evi_cosine_topk_fp8_mfma if fp8_mfma else lib.evi_cosine_topk_fp8}.get(x.dtype, lib.evi_cosine_topk)
     _lib.check(
@@ -210,6 +226,9 @@ def cosine_topk(
         )
     )
     return out_score, out_index
+
+
+cosine_topk.last_method = None  # which path the last call took: "scan" | "gemm" | "two_stage" (introspection / tests)
 
 
 def index_shadow_bf16(index: torch.Tensor) -> torch.Tensor:
@@ -225,16 +244,45 @@ def index_shadow_bf16(index: torch.Tensor) -> torch.Tensor:
     return out
 
 
-_UNIT_ROWS_VERIFIED: dict = {}
+def _tensor_cache(t: torch.Tensor) -> dict:
+    """Per-tensor-OBJECT cache (an attribute of the tensor): it dies with the tensor, so a later tensor that the caching
+    allocator places at the same address never inherits a verdict; entries carry the tensor's `_version` so in-place edits
+    are seen."""
+    c = t.__dict__.get("_evi_cache")
+    if c is None:
+        c = {}
+        t.__dict__["_evi_cache"] = c
+    return c
+
+
+def resident_shadow_f16(index: torch.Tensor) -> Optional[torch.Tensor]:
+    """The f16 shadow `index_shadow_f16(index)` attached to this index tensor, if it is still valid (same version, same
+    storage), else None."""
+    ent = index.__dict__.get("_evi_cache", {}).get("shadow_f16") if isinstance(index, torch.Tensor) else None
+    if ent is None:
+        return None
+    version, ptr, shadow = ent
+    if version != index._version or ptr != index.data_ptr() or shadow.shape != index.shape:
+        return None
+    return shadow
 
 
 def rows_are_unit_norm(index: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> bool:
     """True when every (scaled) row of `index` has norm <= 1 + 1e-4 (1 + 1e-3 for an f16-stored index) — what the exactness proofs of the GEMM-shaped and
     two-stage paths assume (their error bounds are kEps * |q| * |x| with |x| <= 1).  One pass over the index and one
-    read-back, cached per (storage, shape, version): in-place edits of the tensor are seen."""
-    key = (index.data_ptr(), tuple(index.shape), index.dtype, index._version,
-           None if row_scale is None else (row_scale.data_ptr(), row_scale._version))
-    hit = _UNIT_ROWS_VERIFIED.get(key)
+    read-back, cached ON the index tensor per (version, row_scale object + version): in-place edits are seen, and the
+    verdict cannot outlive the tensor (a new tensor at a recycled address starts unverified)."""
+    import weakref
+
+    cache = _tensor_cache(index)
+    ent = cache.get("unit_rows")
+    hit = None
+    if ent is not None:
+        version, ptr, rs_ref, rs_version, verdict = ent
+        same_rs = (rs_ref is None and row_scale is None) or (rs_ref is not None and row_scale is not None and rs_ref() is row_scale
+                                                             and rs_version == row_scale._version)
+        if version == index._version and ptr == index.data_ptr() and same_rs:
+            hit = verdict
     if hit is None:
         if index.numel() == 0:
             hit = True
@@ -248,9 +296,8 @@ def rows_are_unit_norm(index: torch.Tensor, row_scale: Optional[torch.Tensor] = 
                 norms = norms * row_scale.view(-1).abs()
             # f16 storage: rounding a unit row element by element moves its norm by up to 2^-11 (5e-4)
             hit = bool((norms.max() <= 1.0 + (1e-4 if index.dtype == torch.float32 else 1e-3)).item())
-        if len(_UNIT_ROWS_VERIFIED) > 64:
-            _UNIT_ROWS_VERIFIED.clear()
-        _UNIT_ROWS_VERIFIED[key] = hit
+        cache["unit_rows"] = (index._version, index.data_ptr(), None if row_scale is None else weakref.ref(row_scale),
+                              None if row_scale is None else row_scale._version, hit)
     return hit
 
 
@@ -328,10 +375,12 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
 cosine_topk_gemm.last_products = None
 
 
-def index_shadow_f16(index: torch.Tensor, *, check_norms: bool = True) -> torch.Tensor:
+def index_shadow_f16(index: torch.Tensor, *, check_norms: bool = True, attach: bool = True) -> torch.Tensor:
     """f16 copy (round to nearest) of an f32 index of unit rows (+ 50 % memory) for cosine_topk_two_stage.
     The exactness proof of the two-stage scan bounds the f16 rounding of a row by 2^-11 of its norm and assumes
-    norm <= 1 (normalize_embeddings output): check_norms verifies that once here (one pass + one read-back)."""
+    norm <= 1 (normalize_embeddings output): check_norms verifies that once here (one pass + one read-back).
+    attach (default): the shadow is remembered ON the index tensor, and `cosine_topk(queries, index, k)` (method "auto")
+    then takes the two-stage scan by itself for as long as the index is not edited in place."""
     dev = _require_gpu(index)
     x = _f32c(index, "index")
     if x.dim() != 2:
@@ -344,7 +393,14 @@ def index_shadow_f16(index: torch.Tensor, *, check_norms: bool = True) -> torch.
     out = torch.empty(x.shape, dtype=torch.float16, device=dev)
     if x.numel():
         _lib.check(_lib.load().evi_index_shadow_f16(_ptr(x), x.size(0), x.size(1), _ptr(out), _stream(dev)))
+    if attach and x is index and check_norms:
+        _tensor_cache(index)["shadow_f16"] = (index._version, index.data_ptr(), out)
     return out
+
+
+def drop_shadow_f16(index: torch.Tensor) -> None:
+    """Forget (and so free) the shadow attached to `index`."""
+    index.__dict__.get("_evi_cache", {}).pop("shadow_f16", None)
 
 
 def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: torch.Tensor, k: int, *, row_id_base: int = 0,

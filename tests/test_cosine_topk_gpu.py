@@ -128,7 +128,7 @@ def test_cosine_topk_fp8_index_matches_oracle(dev, Q, N, D, k):
     xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
     qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
     codes, scale = ops.quantize_rows_fp8(xn)
-    sc, ids = ops.cosine_topk(qn, codes, k, row_scale=scale, row_id_base=7)
+    sc, ids = ops.cosine_topk(qn, codes, k, row_scale=scale, row_id_base=7, fp8_mfma=False)  # widening variant: f32 query kept exact
     deq = ocos.e4m3_decode_table()[codes.cpu().numpy()].astype(np.float64)
     ref_full = ((qn.cpu().numpy().astype(np.float64) @ deq.T) * scale.cpu().numpy().astype(np.float64)).astype(np.float32)
     check_topk_against_scores(sc.cpu().numpy(), ids.cpu().numpy(), ref_full, k, id_base=7, score_tol=2e-6)
@@ -164,7 +164,9 @@ def test_cosine_topk_fp8_native_mfma_variant(dev, Q, N, D, k):
     qd = torch.from_numpy(q).to(dev)
     codes, scale = ops.quantize_rows_fp8(xn)
     sc, ids = ops.cosine_topk(qd, codes, k, row_scale=scale, row_id_base=7, fp8_mfma=True)
-    sw, iw = ops.cosine_topk(qd, codes, k, row_scale=scale, row_id_base=7)
+    sw, iw = ops.cosine_topk(qd, codes, k, row_scale=scale, row_id_base=7, fp8_mfma=False)
+    sd, idd = ops.cosine_topk(qd, codes, k, row_scale=scale, row_id_base=7)  # the default for an e4m3 index IS the native variant
+    assert torch.equal(idd, ids) and torch.equal(sd, sc)
     deq = ocos.e4m3_decode_table()[codes.cpu().numpy()].astype(np.float64) * scale.cpu().numpy().astype(np.float64)[:, None]
     exact = q.astype(np.float64) @ deq.T  # [Q, N]
     bound = (2.0 ** -8) * np.abs(q).max(axis=1, keepdims=True) * np.abs(deq).sum(axis=1)[None, :]  # [Q, N]
@@ -366,7 +368,10 @@ def test_reduced_precision_index_at_shard_size(dev, storage):
     else:
         index, row_scale = x, None
     torch.cuda.empty_cache()
-    s, i = ops.cosine_topk(q, index, k, row_scale=row_scale)
+    # fp8: the widening variant (f32 query exact) carries the tight re-scoring check below; the native fp8-MFMA variant —
+    # the default for an e4m3 index — is checked after it with its own (two-piece query) tolerance
+    kw = {"fp8_mfma": False} if storage == "fp8" else {}
+    s, i = ops.cosine_topk(q, index, k, row_scale=row_scale, **kw)
     assert torch.equal(i[:, 0], gold)                                     # Hits@1 of the planted rows
     assert bool((s[:, 1:] <= s[:, :-1]).all())                            # sorted
     tie = s[:, 1:] == s[:, :-1]
@@ -374,7 +379,7 @@ def test_reduced_precision_index_at_shard_size(dev, storage):
     assert int(i.min()) >= 0 and int(i.max()) < N
     # shard invariance: three uneven shards merged == the single pass, bit for bit
     cuts = [0, 4_000_001, 9_999_984, N]
-    parts = [ops.cosine_topk(q, index[a:b], k, row_scale=None if row_scale is None else row_scale[a:b], row_id_base=a)
+    parts = [ops.cosine_topk(q, index[a:b], k, row_scale=None if row_scale is None else row_scale[a:b], row_id_base=a, **kw)
              for a, b in zip(cuts[:-1], cuts[1:])]
     ms, mi = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(mi, i) and torch.equal(ms, s)
@@ -389,6 +394,17 @@ def test_reduced_precision_index_at_shard_size(dev, storage):
         deq = rows.float()
     ref = (deq.view(Q, 50, D).double() * q.double().view(Q, 1, D)).sum(-1).float()
     assert float((ref - s[:, :50]).abs().max()) < 3e-6
+    if storage == "fp8":
+        sn, i_n = ops.cosine_topk(q, index, k, row_scale=row_scale)       # default = native fp8 MFMA, two e4m3 query pieces
+        assert torch.equal(i_n[:, 0], gold) and bool((sn[:, 1:] <= sn[:, :-1]).all())
+        tie = sn[:, 1:] == sn[:, :-1]
+        assert bool((i_n[:, 1:][tie] > i_n[:, :-1][tie]).all())
+        inter = (i_n.unsqueeze(2) == i.unsqueeze(1)).any(dim=2).float().sum(dim=1) / k
+        assert float(inter.mean()) > 0.99, float(inter.mean())
+        rows_n = index[i_n[:, :50].reshape(-1)]
+        deq_n = tab[rows_n.long()] * row_scale[i_n[:, :50].reshape(-1)].view(-1, 1)
+        ref_n = (deq_n.view(Q, 50, D).double() * q.double().view(Q, 1, D)).sum(-1).float()
+        assert float((ref_n - sn[:, :50]).abs().max()) < 1e-4            # query pieces carry 16 significant bits
 
 
 @pytest.mark.parametrize("Q,N,D,k,scaled", [(512, 400000, 768, 500, False), (130, 50000, 128, 100, True), (96, 3000, 64, 10, False),
@@ -471,9 +487,22 @@ def test_cosine_topk_two_stage_equals_scan_bit_for_bit(dev, Q, N, D, k):
     qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
     shadow = ops.index_shadow_f16(idx)
     assert torch.equal(shadow, idx.to(torch.float16))  # round to nearest even, element by element
-    s0, i0 = ops.cosine_topk(qn, idx, k, row_id_base=5)
+    s0, i0 = ops.cosine_topk(qn, idx, k, row_id_base=5, method="scan")
     s1, i1 = ops.cosine_topk_two_stage(qn, idx, shadow, k, row_id_base=5, fallback=False)
     assert torch.equal(i1, i0) and torch.equal(s1, s0)
+    # the default method ("auto") finds the shadow that index_shadow_f16 attached to the index tensor and takes the two-stage
+    # scan by itself; an in-place edit of the index invalidates the attachment (the scan runs again), as does dropping it
+    if D % 32 == 0 and k + max(256, k // 2) <= 2048:
+        assert ops.resident_shadow_f16(idx) is shadow
+        sa, ia = ops.cosine_topk(qn, idx, k, row_id_base=5)
+        assert torch.equal(ia, i0) and torch.equal(sa, s0)
+        assert ops.cosine_topk.last_method == "two_stage"
+        idx.add_(0.0)
+        assert ops.resident_shadow_f16(idx) is None
+        sb, ib = ops.cosine_topk(qn, idx, k, row_id_base=5)
+        assert torch.equal(ib, i0) and torch.equal(sb, s0) and ops.cosine_topk.last_method == "scan"
+        other = idx.clone()
+        assert ops.resident_shadow_f16(other) is None  # a verdict / shadow never travels to another tensor object
     # without a read-back: the flag lands in the caller's tensor (default: device-side fallback; raw contract: fallback=False)
     for fb in ("device", False):
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -493,7 +522,7 @@ def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
     idx = ops.normalize_embeddings(torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
     qn = ops.normalize_embeddings(torch.randn(Q, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
     shadow = ops.index_shadow_f16(idx)
-    s32, i32 = ops.cosine_topk(qn, idx, k)
+    s32, i32 = ops.cosine_topk(qn, idx, k, method="scan")
     s16, i16 = ops.cosine_topk(qn, shadow, N if N <= 2048 else 2048)
     # compare row by row where both lists hold the row
     pos = {}
@@ -513,8 +542,10 @@ def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
         ops.cosine_topk_two_stage(qn, clustered, sh, 50, fallback=False)
     s, i = ops.cosine_topk_two_stage(qn, clustered, sh, 50, fallback="host")
     assert ops.cosine_topk_two_stage.last_status == 1
-    s0, i0 = ops.cosine_topk(qn, clustered, 50)
+    s0, i0 = ops.cosine_topk(qn, clustered, 50, method="scan")
     assert torch.equal(i, i0) and torch.equal(s, s0)
+    sa, ia = ops.cosine_topk(qn, clustered, 50)  # auto: two-stage, proof fails, repaired by the gated f32 scan on the device
+    assert torch.equal(ia, i0) and torch.equal(sa, s0)
     # raw contract (fallback=False + status): the unproven result is handed out, the flag says so
     flag = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky: a failure stays visible after a later success
     ops.cosine_topk_two_stage(qn, clustered, sh, 50, status=flag, fallback=False)
@@ -530,7 +561,7 @@ def test_cosine_topk_two_stage_error_bound_and_refusal(dev):
     assert int(flag.item()) == 1 and torch.equal(out[1], i0 + 11) and torch.equal(out[0], s0)
     # ... and a batch whose proof holds right after a repaired one is untouched by the (closed) gate
     s_ok, i_ok = ops.cosine_topk_two_stage(qn, idx, shadow, 50)
-    s_ref, i_ref = ops.cosine_topk(qn, idx, 50)
+    s_ref, i_ref = ops.cosine_topk(qn, idx, 50, method="scan")
     assert torch.equal(i_ok, i_ref) and torch.equal(s_ok, s_ref)
     with pytest.raises(ValueError):
         ops.cosine_topk_two_stage(qn, clustered, sh, 1500)  # k + reserve exceeds the selector's capacity

@@ -73,6 +73,22 @@ def _worker(rank, world, port, out_dir):
             assert everyone.view(world, 16)[:, 0].tolist() == [r * 10 + lane for r in range(world)]
         s, i = idx.topk(torch.from_numpy(qn), K)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), i=i.numpy())
+        # pipeline-form agreement (a collective): both ranks got their lane-1 communicator -> two lanes stay
+        assert idx.lane_fallback is None and idx.agree_on_lanes() is True and idx.two_lanes
+        # ONE rank could not (here: rank 1 says so) -> EVERY rank drops to the one-communicator side-stream form, in-process
+        if rank == 1:
+            idx.two_lanes, idx.lane_fallback = False, "lane-1 communicator: RuntimeError: simulated on rank 1"
+        assert idx.agree_on_lanes() is False and not idx.two_lanes and idx.lane_fallback
+        # the communicator refuses on every rank (EVI_INJECT_LANE_FAILURE=group): no second group, fallback recorded
+        os.environ["EVI_INJECT_LANE_FAILURE"] = "group"
+        try:
+            idx2 = edist.ShardedIndex(torch.from_numpy(xn[b[rank]: b[rank + 1]]), N, local_topk=_oracle_local_topk, merge=_oracle_merge)
+        finally:
+            del os.environ["EVI_INJECT_LANE_FAILURE"]
+        assert not idx2.two_lanes and "injected" in idx2.lane_fallback and idx2._lane_groups[1] is None
+        assert idx2.agree_on_lanes() is False
+        s2, i2 = idx2.topk(torch.from_numpy(qn), K)
+        assert torch.equal(i2, i) and torch.equal(s2, s)
         # metric states: each rank saw a different subset of graphs
         m = EdgeRecallAtK(k_values=[1, 10])
         graphs = edist.shard_graphs(7, rank, world)

@@ -112,3 +112,59 @@ def test_bench_two_rank_control_flow_on_one_gpu(dev):
     assert line["n_gpus"] == 2 and line["config"]["sharding"] == "rows/2" and line["scaling"] == "strong"
     assert line["hits_at_k"]["hits@1"] == 1.0 and line["hits_at_k"]["hits@50"] == 1.0 and line["sorted_ok"]
     assert line["value"] > 0 and line["two_stage"]["identical_to_f32_scan"] and not line["two_stage"]["proof_failed"]
+    assert line["ranks_seen"] == 2 and [d["rank"] for d in line["devices"]] == [0, 1]
+    assert "two lanes" in line["config"]["pipeline"]
+
+
+def _rehearse(extra_env, args):
+    import json
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["EVI_BENCH_BACKEND"] = "gloo"
+    env.update(extra_env)
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + args,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_config4_and_config5_sharded_legs(dev):
+    """An N > 1 run must measure the BASELINE scaling target, not only the config-2 index: the `config4_sharded` leg
+    (configs[3]: f16 index row-sharded over the ranks, Q = 32 and Q = 512, ONE all-gather of packed records + merge) and the
+    `config5_sharded` leg (configs[4]: e4m3 index, native fp8 MFMA) — here with a miniature row count, two ranks on the one
+    GPU, gloo + host-staged exchange (replaces src/callbacks/retriever_topk_edge_writer.py:450-462)."""
+    line = _rehearse({}, ["--steps", "4", "--warmup", "2", "--rows", "200001", "--dim", "128", "--k", "50", "--no-cpu-baseline",
+                          "--no-graph-eval", "--no-encode", "--config4-rows", "300001"])
+    for key, D, dt in (("config4_sharded", 768, "f16"), ("config5_sharded", 1024, "fp8")):
+        leg = line[key]
+        assert leg["ranks_seen"] == 2 and leg["n_gpus"] == 2 and leg["config"]["sharding"] == "rows/2"
+        assert leg["config"]["index_rows"] == 300001 and leg["config"]["dim"] == D and leg["config"]["index_dtype"] == dt
+        assert [d["rows"] for d in leg["devices"]] == [[0, 150000], [150000, 300001]]
+        assert leg["hits_at_k"]["hits@1"] == 1.0 and leg["hits_at_k"]["hits@50"] == 1.0 and leg["sorted_ok"]
+        assert leg["value"] > 0 and leg["roofline"]["bound"] == "hbm" and leg["roofline"]["achieved"] > 0
+        assert "two lanes" in leg["config"]["pipeline"]
+    many = line["config4_sharded"]["many_query"]
+    assert many["queries_per_step"] == 512 and many["value"] > 0 and many["planted_row_in_top10"] == 1.0 and many["sorted_ok"]
+    assert "native fp8 MFMA" in line["config5_sharded"]["dtype"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("where", ["group", "step"])
+def test_bench_two_rank_lane_failure_falls_back_in_process(dev, where):
+    """If the lane-1 communicator cannot be created, or the first two-lane step raises, every rank drops IN-PROCESS to the
+    one-communicator side-stream pipeline (ShardedIndex.agree_on_lanes), says so in `config.pipeline`, and the results
+    stay exact — the run neither hangs nor dies."""
+    line = _rehearse({"EVI_INJECT_LANE_FAILURE": where},
+                     ["--steps", "4", "--warmup", "2", "--rows", "200001", "--dim", "128", "--k", "50", "--no-cpu-baseline",
+                      "--no-graph-eval", "--no-encode", "--no-extra-legs"])
+    pipe = line["config"]["pipeline"]
+    assert "FALLBACK from two lanes" in pipe and "injected" in pipe and "one communicator" in pipe
+    assert line["ranks_seen"] == 2 and line["hits_at_k"]["hits@1"] == 1.0 and line["hits_at_k"]["hits@50"] == 1.0 and line["sorted_ok"]
+    assert line["two_stage"]["identical_to_f32_scan"]

@@ -210,16 +210,47 @@ def test_text_encoder_graph_replay_equals_eager(dev):
         enc.use_graphs = False
         eager = enc.encode_to_device(texts, 8)
         enc.use_graphs = True
-        first = enc.encode_to_device(texts, 8)    # captures
+        assert T.TextEncoder.use_graphs is True and T.TextEncoder.graph_after == 2  # replay is the default; a shape is captured
+        first = enc.encode_to_device(texts, 8)    # captures (every shape was met once in the eager pass above)    # the 2nd time it is met
         again = enc.encode_to_device(texts, 8)    # replays
+        assert len(enc._graphs) > 0
         assert torch.equal(first, again)
         assert torch.allclose(first, eager, rtol=0, atol=1e-6 if autocast is None else 1e-3), float((first - eager).abs().max())
         other = enc.encode_to_device(texts[::-1], 7)  # new shapes on a warm cache
         enc.use_graphs = False
         assert torch.allclose(other, enc.encode_to_device(texts[::-1], 7), rtol=0, atol=1e-6 if autocast is None else 1e-3)
-    enc.use_graphs, enc.max_graphs = True, 2
+    enc.use_graphs, enc.max_graphs, enc.graph_after = True, 2, 1
     enc.encode_to_device(texts, 5)  # shapes not met before: every capture evicts down to the bound
     assert len(enc._graphs) <= 2
+    # a shape met once is not captured under the default graph_after = 2; a forward that cannot be captured (a host
+    # read-back of a device value inside the model) switches the encoder to the eager path with a warning, results intact
+    fresh = T.TextEncoder.from_components(Tok(), model, str(dev), fp16=False)
+    one = fresh.encode_to_device(texts[:8], 8)
+    assert not fresh.__dict__.get("_graphs")
+    assert torch.allclose(one, eager_ref(T, Tok(), model, dev, texts[:8]), rtol=0, atol=1e-6)
+
+    class Syncing(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, **kw):
+            out = self.inner(**kw)
+            float(out.last_hidden_state.sum().item())  # device -> host inside the forward: illegal during capture
+            return out
+
+    bad = T.TextEncoder.from_components(Tok(), Syncing(model), str(dev), fp16=False)
+    bad.graph_after = 1
+    with pytest.warns(RuntimeWarning, match="capture of the encoder forward failed"):
+        got = bad.encode_to_device(texts[:16], 8)
+    assert bad.use_graphs is False
+    assert torch.allclose(got, eager_ref(T, Tok(), model, dev, texts[:16]), rtol=0, atol=1e-6)
+
+
+def eager_ref(T, tok, model, dev, texts):
+    enc = T.TextEncoder.from_components(tok, model, str(dev), fp16=False)
+    enc.use_graphs = False
+    return enc.encode_to_device(texts, 8)
 
 
 def test_canonical_edge_selection_matches_reference_golden(dev):

@@ -1,5 +1,6 @@
 """CPU: the rank runner the two-ranks-on-one-GPU tests use (tests/_procs.py) fails fast instead of waiting out a dead peer."""
 import os
+import subprocess
 import sys
 import time
 
@@ -36,3 +37,17 @@ def test_port_race_is_retried_once(tmp_path):
 def test_timeout_is_reported():
     with pytest.raises(AssertionError, match="no result after"):
         run_ranks(lambda r, port: [sys.executable, "-c", "import time; time.sleep(60)"], 1, timeout=1)
+
+
+def test_bench_deadline_kills_a_run_that_hangs():
+    """`--deadline`: a rank that is still running after the limit exits with code 124 by itself (no GPU needed: the timer is
+    armed before any device work)."""
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench; "
+            "bench.arm_deadline(0.5, 0); time.sleep(30)" % root)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 124 and time.monotonic() - t0 < 60
+    assert b"giving up" in r.stderr
