@@ -166,6 +166,8 @@ def evaluate(cfg: Mapping[str, Any], *, device: Optional[str] = None) -> Tuple[D
         torch.manual_seed(int(cfg["seed"]))
     split = str(run.get("split", "test"))
     dev = torch.device(device or "cuda:0")
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)  # the evi_* kernels launch on the current device's stream
 
     data_cfg = cfg.get("data") or {}
     ds_cfg = cfg["dataset"]

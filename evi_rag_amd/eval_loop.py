@@ -177,7 +177,13 @@ class RetrieverEvaluator:
         for cb in self.callbacks:
             if hasattr(cb, "on_predict_start"):
                 cb.on_predict_start(None, self)
-        torch.cuda.synchronize()
+        try:  # the device the model lives on, not whatever device happens to be current
+            sync_dev = next(self.model.parameters()).device
+        except (StopIteration, AttributeError):
+            sync_dev = None
+        if sync_dev is not None and sync_dev.type != "cuda":
+            sync_dev = None
+        torch.cuda.synchronize(sync_dev)
         t0 = time.perf_counter()
         for i, batch in enumerate(loader):
             self.step(batch, i)
@@ -188,7 +194,7 @@ class RetrieverEvaluator:
         if check is not None:
             check()  # relation ids outside batch.num_relations seen by a forward (scored clamped, reported here)
         metrics = self.epoch_end(sync=sync)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(sync_dev)
         seconds = time.perf_counter() - t0
         for cb in self.callbacks:
             if hasattr(cb, "on_predict_end"):

@@ -26,35 +26,42 @@ def _dev() -> torch.device:
 
 
 class GraphBatch:
-    """Several graphs flattened PyG-style on the device, with their CSR."""
+    """Several graphs flattened PyG-style on the device, with their CSR.  The per-graph edge lists are concatenated once
+    and filtered / offset with whole-batch numpy operations (no per-graph arithmetic)."""
 
     def __init__(self, num_nodes: Sequence[int], edge_src: Sequence[np.ndarray], edge_dst: Sequence[np.ndarray],
                  device: Optional[torch.device] = None):
         dev = device or _dev()
         self.device = dev
-        self.B = len(num_nodes)
-        self.node_ptr_h = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(num_nodes, np.int64), 0))]).astype(np.int64)
-        srcs, dsts, self.valid_ids, self.orig_counts = [], [], [], []
-        counts = []
-        for g in range(self.B):
-            s = np.asarray(edge_src[g], np.int64).reshape(-1)
-            d = np.asarray(edge_dst[g], np.int64).reshape(-1)
-            n = int(num_nodes[g])
-            self.orig_counts.append(int(s.shape[0]))
-            ok = np.nonzero((s >= 0) & (d >= 0) & (s < n) & (d < n))[0]  # _valid_edge_indices (:638-647)
-            self.valid_ids.append(ok)
-            srcs.append(s[ok] + self.node_ptr_h[g])
-            dsts.append(d[ok] + self.node_ptr_h[g])
-            counts.append(ok.shape[0])
+        self.B = B = len(num_nodes)
+        nn = np.maximum(np.asarray(num_nodes, np.int64).reshape(-1), 0)
+        self.node_ptr_h = np.concatenate([[0], np.cumsum(nn)]).astype(np.int64)
+        srcs = [np.asarray(a, np.int64).reshape(-1) for a in edge_src]
+        dsts = [np.asarray(a, np.int64).reshape(-1) for a in edge_dst]
+        cnt0 = np.asarray([a.shape[0] for a in srcs], np.int64)
+        self.orig_counts = cnt0.tolist()
+        off0 = np.concatenate([[0], np.cumsum(cnt0)]).astype(np.int64)
+        s_all = np.concatenate(srcs) if B else np.empty(0, np.int64)
+        d_all = np.concatenate(dsts) if B else np.empty(0, np.int64)
+        if s_all.shape[0] != d_all.shape[0]:
+            raise ValueError("edge_src and edge_dst differ in length")
+        g_of = np.repeat(np.arange(B, dtype=np.int64), cnt0)
+        n_of = np.asarray(num_nodes, np.int64).reshape(-1)[g_of] if B else np.empty(0, np.int64)
+        ok = (s_all >= 0) & (d_all >= 0) & (s_all < n_of) & (d_all < n_of)  # _valid_edge_indices (:638-647)
+        keep = np.nonzero(ok)[0]
+        g_keep = g_of[keep]
+        counts = np.bincount(g_keep, minlength=B).astype(np.int64) if B else np.empty(0, np.int64)
         self.edge_ptr_h = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        ei = np.stack([np.concatenate(srcs) if srcs else np.empty(0, np.int64),
-                       np.concatenate(dsts) if dsts else np.empty(0, np.int64)])
+        pos = keep - off0[g_keep]  # position of every kept edge in its own graph's original list
+        self.valid_ids = np.split(pos, self.edge_ptr_h[1:-1]) if B else []
+        base = self.node_ptr_h[g_keep]
+        ei = np.stack([s_all[keep] + base, d_all[keep] + base]) if B else np.empty((2, 0), np.int64)
         self.edge_index = torch.from_numpy(np.ascontiguousarray(ei)).to(dev)
         self.node_ptr = torch.from_numpy(self.node_ptr_h).to(dev)
         self.edge_ptr = torch.from_numpy(self.edge_ptr_h).to(dev)
         self.N = int(self.node_ptr_h[-1])
         self.E = int(self.edge_ptr_h[-1])
-        self.csr = ops.graph_csr(self.edge_index, self.node_ptr, self.edge_ptr) if self.B > 0 else None
+        self.csr = ops.graph_csr(self.edge_index, self.node_ptr, self.edge_ptr, num_nodes=self.N) if self.B > 0 else None
 
 
 def _bfs(gb: GraphBatch, job_graph: np.ndarray, sources: List[np.ndarray], mode: int):
@@ -99,93 +106,208 @@ def bfs_dist(num_nodes: int, edge_src: Sequence[int], edge_dst: Sequence[int], s
     return bfs_dist_batch(gb, [sources], mode=1 if directed else 0)[0].tolist()
 
 
+def _upload_packed(dev: torch.device, arrays: Sequence[np.ndarray]) -> List[torch.Tensor]:
+    """Several small host arrays -> device tensors with ONE host-to-device copy (8-byte aligned segments of one buffer)."""
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 7) // 8 * 8
+    host = np.empty(max(total, 8), np.uint8)
+    for a, o in zip(arrays, offs):
+        host[o: o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    buf = torch.from_numpy(host).to(dev, non_blocking=True)
+    out = []
+    for a, o in zip(arrays, offs):
+        dt = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32}[a.dtype]
+        out.append(buf[o: o + a.nbytes].view(dt))
+    return out
+
+
+def _unique_in_graph(ptr: np.ndarray, idx: np.ndarray, node_ptr_h: np.ndarray):
+    """Sorted unique batch-global node ids that lie inside their own graph, and the graph of each.  Global ids of
+    different graphs are disjoint, so one np.unique orders them by (graph, local id) — `sorted(set(...))` per graph."""
+    ptr = np.asarray(ptr, np.int64).reshape(-1)
+    idx = np.asarray(idx, np.int64).reshape(-1)
+    B = node_ptr_h.shape[0] - 1
+    if ptr.shape[0] != B + 1 or int(ptr[-1]) != idx.shape[0]:
+        raise ValueError("seed / answer ptr must have B + 1 entries and end at len(idx)")
+    g = np.repeat(np.arange(B, dtype=np.int64), np.diff(ptr))
+    ok = (idx >= node_ptr_h[g]) & (idx < node_ptr_h[g + 1])
+    u = np.unique(idx[ok])
+    ug = np.searchsorted(node_ptr_h, u, side="right") - 1
+    return u, ug
+
+
+class FlatPairLabels:
+    """Shortest-path labels of a whole batch as FLAT arrays (no per-graph Python objects).
+
+    Pair SLOTS are dense: every (seed, answer) combination of every graph that has edges, in (graph, seed asc, answer asc)
+    order — `pair_ptr_h[g] .. pair_ptr_h[g + 1]` are graph g's slots.  A slot without a path has pair_len = -1 and
+    pair_count = 0 (the reference emits no pair for it, scripts/build_retrieval_pipeline.py:722-724).
+
+      device:  mask [E] u8 (positive edges, batch-global edge order) · pair_len [P] i32 · pair_count [P] i32 ·
+               pair_edge_off [P + 1] i64 (exclusive cumsum of the counts) · pair_edge_ids [capacity] i64 (batch-global
+               edge ids, ascending inside a pair; the first pair_edge_off[P] entries are valid)
+      host:    pair_graph_h [P] · pair_start_h / pair_answer_h [P] (graph-LOCAL node ids) · pair_ptr_h [B + 1]
+
+    Nothing has been read back when the object is returned; `per_graph()` does the D2H copies and builds the
+    reference's per-graph 6-tuples on demand."""
+
+    def __init__(self, B, E, edge_ptr_h, mask, pair_len, pair_count, pair_edge_off, pair_edge_ids, pair_graph_h,
+                 pair_start_h, pair_answer_h, pair_ptr_h):
+        self.B, self.E, self.P = int(B), int(E), int(pair_graph_h.shape[0])
+        self.edge_ptr_h = edge_ptr_h
+        self.mask, self.pair_len, self.pair_count = mask, pair_len, pair_count
+        self.pair_edge_off, self.pair_edge_ids = pair_edge_off, pair_edge_ids
+        self.pair_graph_h, self.pair_start_h, self.pair_answer_h, self.pair_ptr_h = pair_graph_h, pair_start_h, pair_answer_h, pair_ptr_h
+
+    def per_graph(self, valid_ids: Optional[Sequence[np.ndarray]] = None, orig_counts: Optional[Sequence[int]] = None):
+        """[(mask bool [E_g], pair_start, pair_answer, pair_edge_ids, pair_edge_counts, pair_lengths)] — the reference's
+        return value per graph (edge ids graph-local).  valid_ids / orig_counts (GraphBatch): map the ids back to the
+        positions of the caller's unfiltered edge lists."""
+        B, P = self.B, self.P
+        mask_h = self.mask[: self.E].cpu().numpy().astype(bool)
+        if P > 0:
+            len_h = self.pair_len.cpu().numpy().astype(np.int64)
+            cnt_h = self.pair_count.cpu().numpy().astype(np.int64)
+            off_h = self.pair_edge_off.cpu().numpy()
+            ids_h = self.pair_edge_ids[: int(off_h[-1])].cpu().numpy()
+        results = []
+        for g in range(B):
+            e0, e1 = int(self.edge_ptr_h[g]), int(self.edge_ptr_h[g + 1])
+            if valid_ids is not None:
+                full = np.zeros(int(orig_counts[g]), dtype=bool)
+                full[valid_ids[g]] = mask_h[e0:e1]
+            else:
+                full = mask_h[e0:e1]
+            p0, p1 = int(self.pair_ptr_h[g]), int(self.pair_ptr_h[g + 1])
+            if p1 == p0:
+                results.append((full, [], [], [], [], []))
+                continue
+            sel = np.nonzero(len_h[p0:p1] >= 0)[0] + p0
+            if sel.shape[0] == p1 - p0:      # every slot has a path: the graph's ids are one contiguous run
+                local = ids_h[int(off_h[p0]): int(off_h[p1])] - e0
+            else:
+                local = np.concatenate([ids_h[int(off_h[p]): int(off_h[p + 1])] for p in sel]) - e0 if sel.shape[0] else np.empty(0, np.int64)
+            if valid_ids is not None:
+                local = valid_ids[g][local]
+            results.append((full, self.pair_start_h[sel].tolist(), self.pair_answer_h[sel].tolist(), local.tolist(),
+                            cnt_h[sel].tolist(), len_h[sel].tolist()))
+        return results
+
+
+def label_pairs_flat(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr: torch.Tensor, seed_ptr, seed_idx, answer_ptr,
+                     answer_idx, *, directed: bool = False, csr=None, node_ptr_host: Optional[np.ndarray] = None,
+                     edge_ptr_host: Optional[np.ndarray] = None) -> FlatPairLabels:
+    """Shortest-path (seed, answer) labelling of a whole batch from flat arrays, results as flat device arrays
+    (`FlatPairLabels`) — `_shortest_path_union_mask_by_pair(_directed)` for every graph of the batch at once
+    (scripts/build_retrieval_pipeline.py:691-815).
+
+      edge_index [2, E] i64 (batch-global node ids, every endpoint inside its own graph: what `build_graph` / the PyG
+      collation produce), node_ptr / edge_ptr [B + 1] i64 — device tensors, as they lie in a collated batch;
+      seed_ptr / seed_idx, answer_ptr / answer_idx — HOST arrays (a handful of entries per graph): batch-global node ids
+      grouped by graph, the form `q_local_indices` / `a_local_indices` have after collation
+      (src/data/g_retrieval_dataset.py:29-37).  Duplicates and ids outside their graph are dropped like the reference's
+      `sorted({s for s in sources if 0 <= s < num_nodes})`.
+
+    Host work: whole-batch numpy on the seed / answer lists (job and pair tables), ONE packed host-to-device copy.
+    Device work: CSR (unless given), one BFS job per unique seed and per unique answer, evi_shortest_path_pairs pass 0
+    (lengths, counts, mask), a device cumsum, pass 1 (edge ids).  No device-to-host read-back: the id buffer is sized by
+    the host-side bound sum over pair slots of E_g."""
+    dev = ops._require_gpu(edge_index, node_ptr, edge_ptr)
+    ei = ops._i64c(edge_index, "edge_index")
+    nptr = ops._i64c(node_ptr.view(-1), "node_ptr")
+    eptr = ops._i64c(edge_ptr.view(-1), "edge_ptr")
+    B = nptr.numel() - 1
+    node_ptr_h = np.asarray(node_ptr_host, np.int64) if node_ptr_host is not None else nptr.cpu().numpy()
+    edge_ptr_h = np.asarray(edge_ptr_host, np.int64) if edge_ptr_host is not None else eptr.cpu().numpy()
+    N, E = int(node_ptr_h[-1]), int(edge_ptr_h[-1])
+    if ei.size(1) != E:
+        raise ValueError(f"edge_ptr ends at {E} but edge_index holds {ei.size(1)} edges")
+    seeds_u, sg = _unique_in_graph(seed_ptr, seed_idx, node_ptr_h)
+    ans_u, ag = _unique_in_graph(answer_ptr, answer_idx, node_ptr_h)
+    S, A = seeds_u.shape[0], ans_u.shape[0]
+    s_cnt = np.bincount(sg, minlength=B).astype(np.int64)
+    a_cnt = np.bincount(ag, minlength=B).astype(np.int64)
+    e_cnt = np.diff(edge_ptr_h)
+    ppg = np.where(e_cnt > 0, s_cnt * a_cnt, 0)  # a graph without edges yields no pairs (:705-706)
+    pair_ptr_h = np.concatenate([[0], np.cumsum(ppg)]).astype(np.int64)
+    P = int(pair_ptr_h[-1])
+    mask = torch.zeros(max(E, 1), dtype=torch.uint8, device=dev)
+    empty = lambda dt: torch.empty(0, dtype=dt, device=dev)  # noqa: E731
+    if P == 0:
+        z = np.empty(0, np.int64)
+        return FlatPairLabels(B, E, edge_ptr_h, mask, empty(torch.int32), empty(torch.int32), torch.zeros(1, dtype=torch.int64, device=dev),
+                              empty(torch.int64), z, z, z, pair_ptr_h)
+    s_start = np.concatenate([[0], np.cumsum(s_cnt)])[:-1]
+    a_start = np.concatenate([[0], np.cumsum(a_cnt)])[:-1]
+    pg = np.repeat(np.arange(B, dtype=np.int64), ppg)
+    r = np.arange(P, dtype=np.int64) - pair_ptr_h[pg]
+    ac = a_cnt[pg]
+    seed_job = s_start[pg] + r // ac
+    ans_slot = a_start[pg] + r % ac
+    pan = ans_u[ans_slot]                                   # batch-global answer node of the slot
+    job_graph = np.concatenate([sg, ag]).astype(np.int32)   # jobs: all seeds, then all answers
+    J = S + A
+    sizes = np.diff(node_ptr_h)[job_graph]
+    dist_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    cap = int((ppg * e_cnt).sum())                          # bound on the pair edge ids: every slot could hold all its graph's edges
+    d_jg, d_sp, d_si, d_do, d_pg, d_ps, d_pa, d_pan = _upload_packed(dev, [
+        job_graph, np.arange(J + 1, dtype=np.int64), np.concatenate([seeds_u, ans_u]).astype(np.int64), dist_off[:-1].copy(),
+        pg.astype(np.int32), seed_job.astype(np.int32), (S + ans_slot).astype(np.int32), pan.astype(np.int64)])
+    if csr is None:
+        csr = ops.graph_csr(ei, nptr, eptr, num_nodes=N)
+    lib = _lib.load()
+    st = ops._stream(dev)
+    dist = ops._workspace(dev, "label_dist", 4 * max(int(dist_off[-1]), 1)).view(torch.int32)
+
+    def bfs(j0, j1, mode):
+        if j1 > j0:  # sub-ranges address the same tables: the offsets inside src_ptr / dist_off are absolute
+            _lib.check(lib.evi_bfs_levels(d_jg[j0:].data_ptr(), d_sp[j0:].data_ptr(), d_si.data_ptr(), d_do[j0:].data_ptr(), j1 - j0,
+                                          ops._ptr(nptr), csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
+                                          csr.out_nbr.data_ptr(), int(mode), dist.data_ptr(), st))
+
+    if directed:
+        bfs(0, S, 1)   # forward from the seeds
+        bfs(S, J, 2)   # backward from the answers
+    else:
+        bfs(0, J, 0)
+    plen = torch.empty(P, dtype=torch.int32, device=dev)
+    pcnt = torch.empty(P, dtype=torch.int32, device=dev)
+    args = (d_pg.data_ptr(), d_ps.data_ptr(), d_pa.data_ptr(), d_pan.data_ptr(), P, d_do.data_ptr(), dist.data_ptr(),
+            ops._ptr(ei), E, ops._ptr(nptr), ops._ptr(eptr), int(bool(directed)))
+    _lib.check(lib.evi_shortest_path_pairs(0, *args, plen.data_ptr(), pcnt.data_ptr(), mask.data_ptr(), None, None, st))
+    poff = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(pcnt, 0, dtype=torch.int64, out=poff[1:])
+    pids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+    _lib.check(lib.evi_shortest_path_pairs(1, *args, plen.data_ptr(), pcnt.data_ptr(), mask.data_ptr(), poff.data_ptr(),
+                                           pids.data_ptr(), st))
+    return FlatPairLabels(B, E, edge_ptr_h, mask, plen, pcnt, poff, pids, pg, seeds_u[seed_job] - node_ptr_h[pg],
+                          pan - node_ptr_h[pg], pair_ptr_h)
+
+
 def shortest_path_union_mask_by_pair_batch(gb: GraphBatch, sources: Sequence[Sequence[int]],
                                            targets: Sequence[Sequence[int]], *, directed: bool = False):
-    """Per graph: (mask list[bool] over the ORIGINAL edge list, pair_start, pair_answer, pair_edge_ids,
-    pair_edge_counts, pair_lengths) — the reference's 6-tuple."""
-    dev = gb.device
-    starts, answers = [], []
-    for g in range(gb.B):
-        n = int(gb.node_ptr_h[g + 1] - gb.node_ptr_h[g])
-        starts.append(sorted({int(s) for s in sources[g] if 0 <= int(s) < n}))
-        answers.append(sorted({int(t) for t in targets[g] if 0 <= int(t) < n}))
-    # BFS jobs: all seeds (mode fwd / undirected), then all answers (mode bwd / undirected)
-    jobs_g, jobs_src, seed_job, ans_job = [], [], [], []
-    for g in range(gb.B):
-        seed_job.append([])
-        for s in starts[g]:
-            seed_job[g].append(len(jobs_g))
-            jobs_g.append(g)
-            jobs_src.append(np.asarray([s + gb.node_ptr_h[g]], np.int64))
-    n_seed_jobs = len(jobs_g)
-    for g in range(gb.B):
-        ans_job.append([])
-        for a in answers[g]:
-            ans_job[g].append(len(jobs_g))
-            jobs_g.append(g)
-            jobs_src.append(np.asarray([a + gb.node_ptr_h[g]], np.int64))
-    jobs_g = np.asarray(jobs_g, np.int32)
-    if directed:
-        d1, off1 = _bfs(gb, jobs_g[:n_seed_jobs], jobs_src[:n_seed_jobs], 1)
-        d2, off2 = _bfs(gb, jobs_g[n_seed_jobs:], jobs_src[n_seed_jobs:], 2)
-        dist = torch.cat([d1[: int(off1[-1])], d2[: max(int(off2[-1]), 1)]])
-        dist_off = np.concatenate([off1[:-1], off2[:-1] + off1[-1]]).astype(np.int64)
-    else:
-        dist, off = _bfs(gb, jobs_g, jobs_src, 0)
-        dist_off = off[:-1].astype(np.int64)
-    # dense pair slots in (graph, seed asc, answer asc) order
-    pg, ps, pa, pan, pmeta = [], [], [], [], []
-    for g in range(gb.B):
-        if gb.edge_ptr_h[g + 1] == gb.edge_ptr_h[g]:
-            continue  # no valid edges: the reference returns no pairs (:705-706)
-        for i, s in enumerate(starts[g]):
-            for j, a in enumerate(answers[g]):
-                pg.append(g)
-                ps.append(seed_job[g][i])
-                pa.append(ans_job[g][j])
-                pan.append(a + gb.node_ptr_h[g])
-                pmeta.append((g, s, a))
-    P = len(pg)
-    mask = torch.zeros(max(gb.E, 1), dtype=torch.uint8, device=dev)
-    if P > 0:
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a))).to(device=dev, dtype=dt)  # noqa: E731
-        pg_t, ps_t, pa_t, pan_t = t(pg, torch.int32), t(ps, torch.int32), t(pa, torch.int32), t(pan, torch.int64)
-        doff_t = t(dist_off, torch.int64)
-        plen = torch.empty(P, dtype=torch.int32, device=dev)
-        pcnt = torch.empty(P, dtype=torch.int32, device=dev)
-        lib = _lib.load()
-        args = (ops._ptr(pg_t), ops._ptr(ps_t), ops._ptr(pa_t), ops._ptr(pan_t), P, ops._ptr(doff_t), dist.data_ptr(),
-                ops._ptr(gb.edge_index), gb.E, ops._ptr(gb.node_ptr), ops._ptr(gb.edge_ptr), int(bool(directed)))
-        _lib.check(lib.evi_shortest_path_pairs(0, *args, plen.data_ptr(), pcnt.data_ptr(), mask.data_ptr(), None, None,
-                                               ops._stream(dev)))
-        cnt_h = pcnt.cpu().numpy().astype(np.int64)
-        len_h = plen.cpu().numpy().astype(np.int64)
-        poff = np.concatenate([[0], np.cumsum(cnt_h)]).astype(np.int64)
-        pids = torch.empty(max(int(poff[-1]), 1), dtype=torch.int64, device=dev)
-        poff_t = t(poff[:-1], torch.int64)
-        _lib.check(lib.evi_shortest_path_pairs(1, *args, plen.data_ptr(), pcnt.data_ptr(), mask.data_ptr(),
-                                               poff_t.data_ptr(), pids.data_ptr(), ops._stream(dev)))
-        pids_h = pids.cpu().numpy()
-    mask_h = mask.cpu().numpy().astype(bool)
-    per_graph = [dict(ps=[], pa=[], pe=[], pc=[], pl=[]) for _ in range(gb.B)]
-    for p in range(P):
-        g, s, a = pmeta[p]
-        if len_h[p] < 0:
-            continue
-        r = per_graph[g]
-        r["ps"].append(s)
-        r["pa"].append(a)
-        r["pl"].append(int(len_h[p]))
-        r["pc"].append(int(cnt_h[p]))
-        local = pids_h[poff[p]: poff[p + 1]] - gb.edge_ptr_h[g]
-        r["pe"].extend(gb.valid_ids[g][local].tolist())  # back to positions in the caller's edge list
-    results = []
-    for g in range(gb.B):
-        r = per_graph[g]
-        full = np.zeros(gb.orig_counts[g], dtype=bool)
-        full[gb.valid_ids[g]] = mask_h[gb.edge_ptr_h[g]: gb.edge_ptr_h[g + 1]]
-        results.append((full, r["ps"], r["pa"], r["pe"], r["pc"], r["pl"]))
-    return results
+    """Per graph: (mask bool over the ORIGINAL edge list, pair_start, pair_answer, pair_edge_ids,
+    pair_edge_counts, pair_lengths) — the reference's 6-tuple.  sources / targets: LOCAL node ids per graph.
+    A thin wrapper: the work is `label_pairs_flat`; the tuples are built from its flat result."""
+    def flat(lists):
+        cnt = np.asarray([len(x) for x in lists], np.int64)
+        ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        loc = np.asarray([int(v) for x in lists for v in x], np.int64)
+        g = np.repeat(np.arange(gb.B, dtype=np.int64), cnt)
+        n = np.diff(gb.node_ptr_h)[g]
+        # a local id outside [0, n) must not alias a neighbour graph's node once offset: mark it out of range (-1)
+        glob = np.where((loc >= 0) & (loc < n), loc + gb.node_ptr_h[g], -1)
+        return ptr, glob
+
+    sp, si = flat(sources)
+    tp, ti = flat(targets)
+    if gb.B == 0:
+        return []
+    res = label_pairs_flat(gb.edge_index, gb.node_ptr, gb.edge_ptr, sp, si, tp, ti, directed=directed, csr=gb.csr,
+                           node_ptr_host=gb.node_ptr_h, edge_ptr_host=gb.edge_ptr_h)
+    return res.per_graph(gb.valid_ids, gb.orig_counts)
 
 
 def shortest_path_union_mask_by_pair(num_nodes: int, edge_src: Sequence[int], edge_dst: Sequence[int],
@@ -430,7 +552,7 @@ def seed_onehop_stats(heads: torch.Tensor, tails: torch.Tensor, labels: torch.Te
     return [(int(s), int(d), int(p)) for s, d, p in zip(uniq.tolist(), deg.tolist(), pdeg.tolist()) if d >= 0]
 
 
-__all__ = ["GraphBatch", "canonicalize_positive_edges", "bfs_dist", "bfs_dist_batch", "shortest_path_union_mask_by_pair",
+__all__ = ["GraphBatch", "FlatPairLabels", "label_pairs_flat", "canonicalize_positive_edges", "bfs_dist", "bfs_dist_batch", "shortest_path_union_mask_by_pair",
            "shortest_path_single", "shortest_path_single_batch", "has_connectivity",
            "shortest_path_union_mask_by_pair_batch", "node_softmax_logit", "select_topk_edges", "select_start_edges",
            "seed_onehop_stats"]

@@ -330,7 +330,7 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         if row_scale.numel() != N:
             raise ValueError(f"row_scale length {row_scale.numel()} != N {N}")
     if Q == 0 or N == 0:
-        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out, method="scan")
     # the proof's error bound is kApproxEps * |q| * |row|, with |row| <= 1 built in: an index of longer rows would pass
     # the gap test with true top-k rows discarded.  Verified once per index (cached); such an index goes to the scan.
     if check_norms and not rows_are_unit_norm(x, row_scale):
@@ -338,7 +338,7 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
             raise ValueError("cosine_topk_gemm needs rows of norm <= 1 (normalize_embeddings, or row_scale = row_inv_norm): "
                              "its exactness proof assumes them")
         cosine_topk_gemm.last_products = 0
-        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out, method="scan")
     lib = _lib.load()
     ws = _workspace(dev, "cosine_topk_gemm", int(lib.evi_cosine_topk_gemm_workspace_bytes(Q, N, D, int(k))))
     if out is not None:
@@ -368,7 +368,7 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         cosine_topk_gemm.last_products = 0  # the scan produced the result
         if not fallback:
             raise RuntimeError(f"evi_cosine_topk_gemm could not prove exactness (status {st}): run cosine_topk")
-        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out)
+        return cosine_topk(q, x, k, row_scale=row_scale, row_id_base=row_id_base, out=out, method="scan")
     return out_score, out_index
 
 
@@ -437,7 +437,7 @@ def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: to
     if status is not None and (status.dtype != torch.int32 or status.numel() != 1):
         raise ValueError("status must be an int32 tensor with one element")
     if Q == 0 or N == 0:
-        return cosine_topk(q, x, k, row_id_base=row_id_base, out=out)
+        return cosine_topk(q, x, k, row_id_base=row_id_base, out=out, method="scan")
     lib = _lib.load()
     need = int(lib.evi_cosine_topk_two_stage_workspace_bytes(Q, N, D, int(k)))
     if need == 0:
@@ -465,7 +465,7 @@ def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: to
     if st != 0:
         if fallback is False:
             raise RuntimeError(f"evi_cosine_topk_two_stage could not prove exactness (status {st}): run cosine_topk")
-        return cosine_topk(q, x, k, row_id_base=row_id_base, out=out)
+        return cosine_topk(q, x, k, row_id_base=row_id_base, out=out, method="scan")
     return out_score, out_index
 
 

@@ -247,8 +247,15 @@ class PackedLoader:
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), bool(shuffle), bool(drop_last)
         self.rank, self.world_size = int(rank), int(world_size)
         self._gen = torch.Generator()
+        self._seed = None if random_seed is None else int(random_seed)
         if random_seed is not None:
             self._gen.manual_seed(int(random_seed))
+
+    def set_epoch(self, epoch: int) -> None:
+        """The permutation of epoch e is a function of (random_seed, e) (DistributedSampler.set_epoch's contract), so a run
+        resumed at epoch e shuffles like the uninterrupted run did.  Without a seed the running generator is kept."""
+        if self._seed is not None:
+            self._gen.manual_seed(self._seed * 1_000_003 + int(epoch))
 
     def _order(self) -> torch.Tensor:
         n = len(self.dataset)

@@ -14,8 +14,10 @@ coefficient is formed on the device from the norm.  The backward is one library 
 overlap with it; at 9.4 M parameters the all-reduce is a single 38 MB ring pass (latency-bound over xGMI), issued on the
 training stream right behind the backward.
 
-Mixed precision (`precision: 16-mixed`) is not mirrored: the scorer's contractions run as split-bf16 products with f32
-accumulation (~1e-5 relative), i.e. at least the reference's precision, and need no loss scaling.
+Precision: `trainer.precision: bf16-mixed` -> ONE bf16 product per GEMM with f32 accumulation, forward and backward (the
+single-product instantiations of the NT / TN kernels; no loss scaling needed, bf16 has f32's exponent range).  `32-true` and
+`16-mixed` -> split-bf16 products with f32 accumulation (~1e-5 relative): at least the reference's precision.  Parity of the
+mixed modes with the reference's torch.autocast numerics is UNPINNED (no reference fixture covers autocast runs).
 """
 from __future__ import annotations
 
@@ -168,7 +170,11 @@ class RetrieverTrainer:
         self.current_epoch = 0
         self._loss_dev = None   # sum over steps of loss * num_graphs (device, f64)
         self._graphs = 0
-        self._ungrouped = None  # OR of "edges were not grouped by graph" (checked at epoch end)
+        self._ungrouped = None  # OR of "edges were not grouped by graph" (checked every `check_every` steps and at epoch end)
+        # the sticky device flags (ungrouped edges; relation ids / seed / answer indices out of range, which the forward clamps)
+        # are read back every `check_every` optimiser steps: a malformed loader is reported after at most that many updates, at
+        # the price of one host-device synchronisation per `check_every` steps (0: at epoch end only)
+        self.check_every = 64
 
     # -- distributed ----------------------------------------------------------------------------------------
     def _world(self) -> int:
@@ -192,6 +198,8 @@ class RetrieverTrainer:
         num_graphs = int(getattr(batch, "num_graphs", 0) or (batch.ptr.numel() - 1))
         if num_graphs <= 0:
             raise ValueError(f"num_graphs must be positive, got {num_graphs}")
+        if int(batch.edge_index.size(1)) == 0:
+            raise ValueError("training batch without edges: nothing to score, no gradient to take (filter edge-less samples out of the split)")
         targets = getattr(batch, "labels", None)
         if targets is None:
             raise ValueError("Batch missing labels required for retriever loss.")
@@ -228,7 +236,16 @@ class RetrieverTrainer:
         self._loss_dev = term if self._loss_dev is None else self._loss_dev + term
         self._graphs += num_graphs
         self.global_step += 1
+        if self.check_every and self.global_step % int(self.check_every) == 0:
+            self._check_sticky_flags()
         return scalars[2]
+
+    def _check_sticky_flags(self) -> None:
+        if self._ungrouped is not None and bool(self._ungrouped.item()):
+            raise ValueError("edge_batch is not sorted by graph in a training batch; the loader must group edges by graph.")
+        check = getattr(self.model, "check_deferred", None)
+        if check is not None:
+            check()  # deferred range checks of the forwards so far (relation ids, seed / answer indices)
 
     def _common_steps(self, loader) -> Optional[int]:
         """With more than one rank: the smallest number of batches any rank's loader holds this epoch (one small MIN
@@ -244,11 +261,7 @@ class RetrieverTrainer:
     def on_train_epoch_end(self) -> Dict[str, float]:
         """The epoch's `train/loss` (batch-size-weighted mean, summed over ranks like sync_dist=True) + scheduler step."""
         loss_sum = float(self._loss_dev.item()) if self._loss_dev is not None else 0.0
-        if self._ungrouped is not None and bool(self._ungrouped.item()):
-            raise ValueError("edge_batch is not sorted by graph in a training batch; the loader must group edges by graph.")
-        check = getattr(self.model, "check_deferred", None)
-        if check is not None:
-            check()  # deferred range checks of the epoch's forwards (relation ids, seed / answer indices)
+        self._check_sticky_flags()
         graphs = float(self._graphs)
         if self._world() > 1:
             from .dist import all_reduce_sum_
@@ -295,7 +308,7 @@ class RetrieverTrainer:
             self.scheduler.last_epoch = int(sd.get("scheduler_last_epoch", 0))
 
 
-def _save_checkpoint(self, path) -> None:
+def _save_checkpoint(self, path, callbacks: Optional[Mapping[str, Any]] = None) -> None:
     """A checkpoint in Lightning's layout as far as the reference reads it: `state_dict` with the retriever under the
     `model.` prefix of `RetrieverModule` (retriever_module.py:59) — what `src/eval.py:_load_checkpoint_strict` (:80-111) and
     `evi_rag_amd.eval` load — plus `epoch`, `global_step` and this trainer's optimiser / schedule state for resuming.
@@ -305,14 +318,20 @@ def _save_checkpoint(self, path) -> None:
             "global_step": self.global_step,
             "optimizer_states": [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in sd["optimizer"].items()}],
             "lr_schedulers": [{"last_epoch": sd["scheduler_last_epoch"]}]}
+    if callbacks:
+        # the run's selection state (Lightning keeps it under the same key): best score / path of model_checkpoint, best score /
+        # wait count / latched stop of early_stopping — plain scalars and strings, so weights_only=True still loads the file
+        blob["callbacks"] = {str(k): (v if isinstance(v, (int, float, str, bool)) or v is None else str(v)) for k, v in callbacks.items()}
     torch.save(blob, str(path))
 
 
-def _load_checkpoint(self, path) -> None:
+def _load_checkpoint(self, path) -> Dict[str, Any]:
+    """Restores weights, optimiser, schedule, epoch and step; returns the `callbacks` entry of the file ({} if none)."""
     blob = torch.load(str(path), map_location="cpu", weights_only=True)
     self.load_state_dict({"model": {k[len("model."):]: v for k, v in blob["state_dict"].items() if k.startswith("model.")},
                           "optimizer": blob["optimizer_states"][0], "global_step": blob["global_step"], "current_epoch": blob["epoch"],
                           "scheduler_last_epoch": blob["lr_schedulers"][0]["last_epoch"]})
+    return dict(blob.get("callbacks") or {})
 
 
 RetrieverTrainer.save_checkpoint = _save_checkpoint

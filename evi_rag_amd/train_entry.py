@@ -49,6 +49,8 @@ def fit(cfg: Mapping[str, Any], *, device: Optional[str] = None) -> Dict[str, An
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     dev = torch.device(device or f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)  # the evi_* kernels launch on the CURRENT device's stream: make `--device cuda:1` that device
     seed = cfg.get("seed")
     if seed is not None:
         torch.manual_seed(int(seed))  # every rank: the same initial weights and the same shuffling stream (shares are disjoint)
@@ -74,8 +76,9 @@ def fit(cfg: Mapping[str, Any], *, device: Optional[str] = None) -> Dict[str, An
     tr_cfg = cfg.get("trainer") or {}
     trainer = RetrieverTrainer(model, loss=loss, optimizer_cfg=model_cfg.get("optimizer_cfg"), scheduler_cfg=model_cfg.get("scheduler_cfg"),
                                gradient_clip_val=tr_cfg.get("gradient_clip_val"), precision=tr_cfg.get("precision"))
+    resumed: Dict[str, Any] = {}
     if cfg.get("ckpt_path"):
-        trainer.load_checkpoint(cfg["ckpt_path"])
+        resumed = trainer.load_checkpoint(cfg["ckpt_path"]) or {}
         log.info("resumed from %s at epoch %d", cfg["ckpt_path"], trainer.current_epoch)
 
     cbs = cfg.get("callbacks") or {}
@@ -90,11 +93,29 @@ def fit(cfg: Mapping[str, Any], *, device: Optional[str] = None) -> Dict[str, An
     every = max(int(tr_cfg.get("check_val_every_n_epoch", 1) or 1), 1)
     min_epochs, max_epochs = int(tr_cfg.get("min_epochs", 0) or 0), int(tr_cfg.get("max_epochs", 1) or 1)
 
-    history, best, best_path, es_best, bad_checks = [], None, None, None, 0
+    # selection state of model_checkpoint / early_stopping: restored from the checkpoint a run resumes from (Lightning keeps it
+    # in the checkpoint's `callbacks` entry), so the first validation after a resume competes with the best one so far
+    history = []
+    best = resumed.get("best")
+    best_path = Path(str(resumed["best_path"])) if resumed.get("best_path") else None
+    es_best, bad_checks = resumed.get("es_best"), int(resumed.get("bad_checks") or 0)
+    stop_latched = bool(resumed.get("stop_latched", False))
+
+    def cb_state():
+        return {"best": best, "best_path": str(best_path) if best_path is not None else None, "es_best": es_best,
+                "bad_checks": bad_checks, "stop_latched": stop_latched}
+
     if rank == 0:
         ckpt_dir.mkdir(parents=True, exist_ok=True)
     while trainer.current_epoch < max_epochs:
         epoch = trainer.current_epoch
+        if stop_latched and epoch >= min_epochs:
+            log.info("early stopping: patience was exhausted before the resume point")
+            break
+        if seed is not None:
+            # the dropout-seed stream (drawn from torch's CPU generator per step) is a function of (seed, epoch) too: epoch e of a
+            # resumed run draws what epoch e of the uninterrupted run drew
+            torch.manual_seed(int(seed) * 1_000_003 + epoch)
         entry = dict(trainer.fit(train_loader, max_epochs=1)["epochs"][-1], epoch=epoch)
         stop = False
         if val_ds is not None and (epoch + 1) % every == 0:
@@ -103,25 +124,27 @@ def fit(cfg: Mapping[str, Any], *, device: Optional[str] = None) -> Dict[str, An
             with torch.no_grad():
                 res = evaluator.run(PackedLoader(val_ds, batch_size=bs, rank=rank, world_size=world), sync=world > 1)
             entry.update(res["metrics"])
-            if monitor is not None:
-                if monitor not in res["metrics"]:
-                    raise KeyError(f"model_checkpoint.monitor {monitor!r} is not among the validation metrics {sorted(res['metrics'])}")
-                if _better(float(res["metrics"][monitor]), best, mode):
-                    best = float(res["metrics"][monitor])
-                    if rank == 0:
-                        name = str(mc.get("filename") or "epoch_{epoch:03d}").format(epoch=epoch) + ".ckpt"
-                        if best_path is not None and best_path.exists() and int(mc.get("save_top_k", 1) or 1) == 1:
-                            best_path.unlink()
-                        best_path = ckpt_dir / name
-                        trainer.save_checkpoint(best_path)
+            # early stopping first, so that the checkpoint written below carries this check's counters
             if es_monitor is not None and es_monitor in res["metrics"]:
                 if _better(float(res["metrics"][es_monitor]), es_best, es_mode, min_delta):
                     es_best, bad_checks = float(res["metrics"][es_monitor]), 0
                 else:
                     bad_checks += 1
-                    stop = bad_checks >= patience and (epoch + 1) >= min_epochs
+                    stop_latched = stop_latched or bad_checks >= patience  # Lightning latches should_stop ...
+            if monitor is not None:
+                if monitor not in res["metrics"]:
+                    raise KeyError(f"model_checkpoint.monitor {monitor!r} is not among the validation metrics {sorted(res['metrics'])}")
+                if _better(float(res["metrics"][monitor]), best, mode):
+                    best = float(res["metrics"][monitor])
+                    name = str(mc.get("filename") or "epoch_{epoch:03d}").format(epoch=epoch) + ".ckpt"
+                    old_path, best_path = best_path, ckpt_dir / name
+                    if rank == 0:
+                        if old_path is not None and old_path != best_path and old_path.exists() and int(mc.get("save_top_k", 1) or 1) == 1:
+                            old_path.unlink()
+                        trainer.save_checkpoint(best_path, callbacks=cb_state())
+        stop = stop_latched and (epoch + 1) >= min_epochs  # ... and acts on it as soon as min_epochs allows, improving check or not
         if rank == 0 and bool(mc.get("save_last", False)):
-            trainer.save_checkpoint(ckpt_dir / "last.ckpt")
+            trainer.save_checkpoint(ckpt_dir / "last.ckpt", callbacks=cb_state())
         history.append(entry)
         log.info("epoch %d: %s", epoch, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in entry.items()})
         if stop:

@@ -107,3 +107,100 @@ def test_hip_forward_then_hip_metrics_equal_the_reference_values(dev, tag, gemm,
         else:
             assert v == pytest.approx(ref[name], abs=5e-4), name   # float functions of the scores (margins, probabilities)
     assert checked_sets >= 5 * len(K_VALUES)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("D", [768, 1024])
+def test_chain_at_webqsp_shape_every_set_change_is_a_near_tie(dev, D):
+    """The "Hits@k unchanged" claim at the size the bench times (32 graphs x E_g ~ 4 096, D = H = 768, and the reference's
+    default width 1 024 — configs/model/retriever_module.yaml:10-17): HIP forward (default split-bf16 GEMM) -> HIP `rank_batch`
+    + `RetrieverMetricCollection`, against oracle forward -> oracle metrics (src/metrics/reachability.py:296-381,
+    src/metrics/retriever_metrics.py:117-166).
+
+    A random-init scorer spreads a graph's ~4 096 logits over a range of ~1, so neighbouring ranks are ~2e-4 apart and some
+    of the 32 x 9 = 288 (graph, k) boundaries are closer than the GEMM's ~1e-5 error: a changed top-k SET is then not a bug but
+    a near-tie, and the bar is (a) every edge that enters or leaves a top-k set has an oracle score within 2 x the measured
+    max |delta logit| of the oracle's k-th score, (b) where no set changed at a k, every set metric at that k is EQUAL, and
+    elsewhere differs by at most (changed graphs at that k) / (graphs), (c) the HIP metric kernels fed the ORACLE's logits
+    reproduce the oracle's metrics exactly — so any difference in (b) is the logits', not the metric kernels'."""
+    from evi_rag_amd import metrics as M, synthetic
+    from evi_rag_amd.retriever import Retriever
+    from oracle import metrics as omet
+    from oracle import scorer as oscorer
+
+    B = 32
+    sb = synthetic.make_batch(B, nodes_per_graph=1500, edges_per_graph=4096, emb_dim=D, num_relations=4096, num_entities=1 << 17, seed=21)
+    torch.manual_seed(5)
+    model = Retriever(emb_dim=D, hidden_dim=D).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    w = {k: v.numpy() for k, v in model.state_dict().items()}
+    ref = oscorer.retriever_forward(w, sb, num_rounds=2, num_reverse_rounds=2)
+    ref_logits = ref["logits"]
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.answer_entity_ids_ptr = torch.from_numpy(sb.answer_ptr).to(dev)
+    model = model.to(dev)
+    model.emit_edge_embeddings = False  # what the evaluation keeps (score_head folded into state_net.4)
+    with torch.no_grad():
+        out = model(batch)
+    logits = out.logits
+    err = float(np.max(np.abs(logits.cpu().numpy() - ref_logits)))
+    assert err <= 3e-4, err
+    target_h = np.asarray(sb.labels) > 0.5
+    target = batch.labels > 0.5
+    eptr = np.asarray(sb.edge_ptr, np.int64)
+
+    # ---- (a) top-k sets per graph and k
+    rb = M.rank_batch(logits, target, batch, K_VALUES, want_topk=True)
+    ridx, _, rcnt = oracle_segment_topk(ref_logits, eptr, K_VALUES[-1])
+    got_idx, got_cnt = rb.topk_index.cpu().numpy(), rb.topk_count.cpu().numpy()
+    assert np.array_equal(got_cnt, rcnt)
+    changed_at_k = {k: 0 for k in K_VALUES}
+    worst_gap = 0.0
+    for g in range(B):
+        m = int(rcnt[g])
+        s = ref_logits[int(eptr[g]): int(eptr[g + 1])]
+        a, b = got_idx[g, :m], ridx[g, :m]
+        for k in K_VALUES:
+            kk = min(k, m)
+            sa, sb_ = set(a[:kk].tolist()), set(b[:kk].tolist())
+            if sa != sb_:
+                changed_at_k[k] += 1
+                kth = float(s[b[kk - 1]])
+                for e in sa ^ sb_:  # every edge that entered or left the set is a near-tie of the oracle's k-th score
+                    worst_gap = max(worst_gap, abs(float(s[e]) - kth))
+    assert worst_gap <= 2.0 * err + 1e-7, (worst_gap, err, changed_at_k)
+    graphs_changed = sum(changed_at_k.values())
+    print(f"\nchain@WebQSP D=H={D}: max |dlogit| {err:.2e}; (graph, k) sets changed {graphs_changed} of {B * len(K_VALUES)} "
+          f"{changed_at_k}; worst swapped gap {worst_gap:.2e}")
+
+    # ---- oracle metrics on the oracle's logits
+    want = {}
+    sums, cnt = omet.edge_recall_at_k(ref_logits, target_h, eptr, K_VALUES)
+    want.update(omet.edge_recall_compute(sums, cnt))
+    hits, valid = omet.answer_reachability(ref_logits, sb, K_VALUES)
+    want.update(omet.answer_reachability_compute(hits, valid))
+
+    def hip_metrics(scores):
+        coll = M.RetrieverMetricCollection(K_VALUES)
+        coll.update(preds=scores, target=target, indexes=out.query_ids, batch=batch, num_graphs=B)
+        return {k: float(v) for k, v in coll.compute().items()}
+
+    # ---- (c) the metric kernels on the oracle's own logits: exact
+    on_ref = hip_metrics(torch.from_numpy(ref_logits).to(dev))
+    n_checked = 0
+    for name, v in want.items():
+        if name in on_ref:
+            assert on_ref[name] == pytest.approx(v, abs=2e-6), name
+            n_checked += 1
+    assert n_checked >= 2 * len(K_VALUES)
+    # ---- (b) the whole HIP chain
+    got = hip_metrics(logits)
+    for name, v in want.items():
+        if name not in got:
+            continue
+        k = int(name.rsplit("@", 1)[1])
+        slack = changed_at_k[k] / max(1.0, min(float(cnt), float(valid)))  # a changed set moves one graph's term by at most 1
+        assert abs(got[name] - v) <= slack + 2e-6, (name, got[name], v, changed_at_k[k])

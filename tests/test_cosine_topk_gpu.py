@@ -422,7 +422,7 @@ def test_cosine_topk_gemm_equals_scan_bit_for_bit(dev, Q, N, D, k, scaled):
         idx, scale = xd, ops.row_inv_norm(xd, EPS)
     else:
         idx, scale = ops.normalize_embeddings(xd, EPS), None
-    s0, i0 = ops.cosine_topk(qn, idx, k, row_scale=scale, row_id_base=11)
+    s0, i0 = ops.cosine_topk(qn, idx, k, row_scale=scale, row_id_base=11, method="scan")
     for products in (3, 1, None):  # split-bf16 selection, plain-bf16 selection, the automatic plan
         s1, i1 = ops.cosine_topk_gemm(qn, idx, k, row_scale=scale, row_id_base=11, fallback=False, products=products)
         assert torch.equal(i1, i0), products
@@ -445,11 +445,11 @@ def test_cosine_topk_gemm_refuses_what_it_cannot_prove(dev):
     with pytest.raises(RuntimeError, match="could not prove"):
         ops.cosine_topk_gemm(qn, idx, k, fallback=False)
     s, i = ops.cosine_topk_gemm(qn, idx, k)
-    s0, i0 = ops.cosine_topk(qn, idx, k)
+    s0, i0 = ops.cosine_topk(qn, idx, k, method="scan")
     assert torch.equal(i, i0) and torch.equal(s, s0)
     big_q = ops.normalize_embeddings(torch.randn(100, D, device=dev))
     sa, ia = ops.cosine_topk(big_q, idx, k, method="auto")  # 100 queries: routed to the GEMM path, which falls back here
-    sb, ib = ops.cosine_topk(big_q, idx, k)
+    sb, ib = ops.cosine_topk(big_q, idx, k, method="scan")
     assert torch.equal(ia, ib) and torch.equal(sa, sb)
     with pytest.raises(NotImplementedError):
         ops.cosine_topk_gemm(qn, idx, 1500)  # k + reserve exceeds the selector's capacity
@@ -466,7 +466,7 @@ def test_cosine_topk_gemm_f16_index_equals_f16_scan(dev, Q, N, D, k):
     q = np.random.default_rng(Q + 1).standard_normal((Q, D), dtype=np.float32)
     x16 = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS).to(torch.float16)
     qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
-    s0, i0 = ops.cosine_topk(qn, x16, k, row_id_base=3)
+    s0, i0 = ops.cosine_topk(qn, x16, k, row_id_base=3, method="scan")
     for products in (3, 1):
         s1, i1 = ops.cosine_topk_gemm(qn, x16, k, row_id_base=3, fallback=False, products=products)
         assert torch.equal(i1, i0) and torch.equal(s1, s0), products

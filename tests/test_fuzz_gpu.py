@@ -39,7 +39,7 @@ def test_fuzz_cosine_topk_paths_agree(dev):
         q = rng.standard_normal((Q, D), dtype=np.float32)
         xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), EPS)
         qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), EPS)
-        s, i = ops.cosine_topk(qn, xn, k, row_id_base=5)
+        s, i = ops.cosine_topk(qn, xn, k, row_id_base=5, method="scan")
         check_topk_against_scores(s.cpu().numpy(), i.cpu().numpy(), ocos.cosine_scores(q, x, EPS), k, id_base=5)
         if k <= 1000 and D % 16 == 0:
             s2, i2 = ops.cosine_topk_gemm(qn, xn, k, row_id_base=5)  # falls back by itself when it cannot prove exactness

@@ -177,6 +177,17 @@ def test_lmdb_to_packed_reading_loop(tmp_path, monkeypatch):
     assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_node.npy"), base.ptr)
     assert np.array_equal(np.load(tmp_path / "test.packed" / "ptr_edge.npy"), base.edge_ptr)
     assert mod.main(["--lmdb", str(tmp_path / "test.lmdb"), "--out", str(tmp_path / "two"), "--limit", "2"])["num_samples"] == 2
+    # the reader's unpickler admits the sample types only: a record that names another callable is refused, not executed
+    import pickle as _pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned",))
+
+    with pytest.raises(_pickle.UnpicklingError, match="refusing to unpickle"):
+        mod.loads_sample(_pickle.dumps({"edge_index": Evil()}))
+    ok = mod.loads_sample(_pickle.dumps({"a": torch.arange(3), "b": np.arange(4, dtype=np.int32), "c": [1, 2.5, "x", None], "d": np.float32(2)}))
+    assert ok["a"].tolist() == [0, 1, 2] and ok["b"].tolist() == [0, 1, 2, 3] and float(ok["d"]) == 2.0
 
 
 def test_records_to_samples_is_the_lmdb_free_hand_over(tmp_path):
@@ -224,3 +235,33 @@ def test_trainer_precision_maps_to_matmul_precision():
     assert matmul_precision_for("16-mixed") == "split"  # f16 autocast is not mirrored; the split products are more precise
     with pytest.raises(ValueError, match="precision"):
         matmul_precision_for("fp8-mixed")
+
+
+def test_packed_loader_shuffle_is_a_function_of_seed_and_epoch():
+    """A run resumed at epoch e must shuffle like the uninterrupted run did (PackedLoader.set_epoch; the trainer calls it with
+    its current epoch): the permutation depends on (random_seed, epoch) only, not on how many epochs this process has drawn."""
+    from evi_rag_amd.packed_dataset import PackedLoader
+
+    class Ds:
+        def __len__(self):
+            return 37
+
+    a = PackedLoader(Ds(), batch_size=4, shuffle=True, random_seed=11)
+    orders = []
+    for e in range(3):
+        a.set_epoch(e)
+        orders.append(a._order().tolist())
+    assert orders[0] != orders[1] != orders[2] and all(sorted(o) == list(range(37)) for o in orders)
+    b = PackedLoader(Ds(), batch_size=4, shuffle=True, random_seed=11)  # a fresh process resuming at epoch 2
+    b.set_epoch(2)
+    assert b._order().tolist() == orders[2]
+    c = PackedLoader(Ds(), batch_size=4, shuffle=True, random_seed=12)
+    c.set_epoch(2)
+    assert c._order().tolist() != orders[2]
+    # rank shares of one epoch are disjoint and cover the split
+    shares = []
+    for r in range(3):
+        d = PackedLoader(Ds(), batch_size=4, shuffle=True, random_seed=11, rank=r, world_size=3)
+        d.set_epoch(1)
+        shares += d._order().tolist()
+    assert sorted(shares) == list(range(37))

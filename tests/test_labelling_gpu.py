@@ -65,6 +65,73 @@ def test_batched_labelling_matches_oracle(dev):
             assert tuple(res[g][1:]) == tuple(ref[1:]), (g, directed)
 
 
+def test_flat_labelling_entry_point_matches_oracle(dev):
+    """`labelling.label_pairs_flat` (row G3 / §8f-3, scripts/build_retrieval_pipeline.py:691-815): the collated batch's
+    device arrays + host seed / answer CSR in, flat device arrays out — dense pair slots with -1 for "no path", counts,
+    offsets and ascending edge ids; the tuples built from them equal the oracle's for every graph, both path modes, with
+    duplicate / out-of-graph seeds, an answer that is a seed, a graph without edges, one without seeds and an empty graph."""
+    from evi_rag_amd import labelling as L
+
+    rng = np.random.default_rng(5)
+    nn = [40, 7, 0, 25, 12, 300]
+    edges = []
+    for g, n in enumerate(nn):
+        m = [120, 0, 0, 30, 14, 900][g]
+        if n == 0 or m == 0:
+            edges.append((np.empty(0, np.int64), np.empty(0, np.int64)))
+            continue
+        src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+        if g == 3:  # two components: some pairs have no path
+            src, dst = src % 12, dst % 12
+        edges.append((src.astype(np.int64), dst.astype(np.int64)))
+    seeds = [[3, 3, 1, 999, -2], [0, 1], [], [0, 20], [], [5, 17, 250]]
+    answers = [[1, 8, 39], [2], [], [3, 24, 24], [4], [17, 0, 299, 123]]
+    node_ptr = np.concatenate([[0], np.cumsum(nn)]).astype(np.int64)
+    edge_ptr = np.concatenate([[0], np.cumsum([e[0].shape[0] for e in edges])]).astype(np.int64)
+    ei = np.stack([np.concatenate([e[0] + node_ptr[g] for g, e in enumerate(edges)]),
+                   np.concatenate([e[1] + node_ptr[g] for g, e in enumerate(edges)])])
+
+    def csr(lists):  # batch-global ids; an id outside its graph stays outside after the offset (or lands in ANOTHER graph)
+        ptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        idx = np.asarray([v + node_ptr[g] if 0 <= v < nn[g] else -7 for g, x in enumerate(lists) for v in x], np.int64)
+        return ptr, idx
+
+    sp, si = csr(seeds)
+    ap, ai = csr(answers)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    for directed in (False, True):
+        flat = L.label_pairs_flat(t(ei), t(node_ptr), t(edge_ptr), sp, si, ap, ai, directed=directed)
+        # flat contract
+        assert flat.B == len(nn) and flat.E == ei.shape[1] and flat.mask.dtype == torch.uint8
+        assert flat.pair_ptr_h.tolist()[-1] == flat.P == flat.pair_len.numel() == flat.pair_count.numel()
+        off = flat.pair_edge_off.cpu().numpy()
+        cnt = flat.pair_count.cpu().numpy()
+        ln = flat.pair_len.cpu().numpy()
+        assert off[0] == 0 and np.array_equal(np.diff(off), cnt) and (cnt[ln < 0] == 0).all()
+        ids = flat.pair_edge_ids[: off[-1]].cpu().numpy()
+        for p in range(flat.P):
+            seg = ids[off[p]: off[p + 1]]
+            g = flat.pair_graph_h[p]
+            assert (np.diff(seg) > 0).all() and (seg >= edge_ptr[g]).all() and (seg < edge_ptr[g + 1]).all()
+        # graph 1 has no edges, graph 2 is empty, graph 4 has no seeds: no pair slots
+        assert [int(flat.pair_ptr_h[g + 1] - flat.pair_ptr_h[g]) for g in range(len(nn))] == [2 * 3, 0, 0, 2 * 2, 0, 3 * 4]
+        res = flat.per_graph()
+        for g in range(len(nn)):
+            ref = ograph.shortest_path_union_mask_by_pair(nn[g], edges[g][0], edges[g][1], seeds[g], answers[g], directed=directed)
+            assert res[g][0].tolist() == list(ref[0]), (g, directed)
+            assert tuple(list(x) for x in res[g][1:]) == tuple(list(x) for x in ref[1:]), (g, directed)
+        # the list-of-arrays mirror is a wrapper over the same entry point
+        gb = L.GraphBatch(nn, [e[0] for e in edges], [e[1] for e in edges])
+        res2 = L.shortest_path_union_mask_by_pair_batch(gb, seeds, answers, directed=directed)
+        for a, b in zip(res, res2):
+            assert a[0].tolist() == b[0].tolist() and tuple(a[1:]) == tuple(b[1:])
+    # nothing to pair at all
+    none = L.label_pairs_flat(t(ei), t(node_ptr), t(edge_ptr), np.zeros(7, np.int64), np.empty(0, np.int64), ap, ai)
+    assert none.P == 0 and int(none.mask.sum()) == 0 and all(r[1:] == ([], [], [], [], []) for r in none.per_graph())
+    with pytest.raises(ValueError, match="ptr must have"):
+        L.label_pairs_flat(t(ei), t(node_ptr), t(edge_ptr), np.zeros(3, np.int64), np.empty(0, np.int64), ap, ai)
+
+
 def test_g_agent_selection_matches_reference_golden(dev):
     from evi_rag_amd import labelling as L
 

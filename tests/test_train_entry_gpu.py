@@ -51,6 +51,17 @@ def test_train_entry_point_then_eval_entry_point(dev, tmp_path, monkeypatch):
     more = train_entry.run(cfg_dir, ["experiment=train_retriever", "dataset=toyqa", f"ckpt_path={ckpt_dir / 'last.ckpt'}",
                                      "trainer.max_epochs=8"], device=str(dev))
     assert [h["epoch"] for h in more["history"]] == [6, 7]
+    # the resumed run inherits the selection state (the checkpoint's `callbacks` entry): a post-resume validation that is not
+    # better than the best so far neither replaces the best checkpoint nor leaves a second epoch_*.ckpt behind
+    post = max(h["val/answer/reachability@20"] for h in more["history"])
+    assert more["best"] == max(out["best"], post)
+    assert len(list(ckpt_dir.glob("epoch_*.ckpt"))) == 1
+    if post <= out["best"]:
+        assert more["best_checkpoint"] == best and (ckpt_dir / best.split("/")[-1]).exists()
+    blob = torch.load(ckpt_dir / "last.ckpt", map_location="cpu", weights_only=True)
+    assert blob["callbacks"]["best"] == more["best"] and blob["callbacks"]["best_path"] == more["best_checkpoint"]
+    assert set(blob["callbacks"]) == {"best", "best_path", "es_best", "bad_checks", "stop_latched"}
+    best = more["best_checkpoint"]
 
     # src/eval.py's side of the hand-over: the evaluation entry point loads the best checkpoint strictly and evaluates
     results = ev.run(cfg_dir, ["experiment=eval_retriever", "dataset=toyqa", f"ckpt.retriever={best}"], device=str(dev))

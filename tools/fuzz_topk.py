@@ -31,7 +31,7 @@ def one_case(rng, dev):
         q[0] = x[N // 2]
     xn = ops.normalize_embeddings(torch.from_numpy(x).to(dev), 1e-6)
     qn = ops.normalize_embeddings(torch.from_numpy(q).to(dev), 1e-6)
-    s, i = ops.cosine_topk(qn, xn, k)
+    s, i = ops.cosine_topk(qn, xn, k, method="scan")
     check_topk_against_scores(s.cpu().numpy(), i.cpu().numpy(), ocos.cosine_scores(q, x, 1e-6), k)
     notes = []
     if N >= 64:  # two-stage: needs unit rows (row 0 is zero -> its proof guard may fail: device fallback repairs it)

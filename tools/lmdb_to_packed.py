@@ -8,8 +8,9 @@ backend keeps resident in HBM (evi_rag_amd.packed_dataset.write_packed).
 
 Needs the `lmdb` package (a dependency of the reference; not present in this repository's build image, where the reading
 loop is exercised against a stand-in with the same `open / begin / cursor` interface: tests/test_host_mirror.py).  The samples
-are unpickled exactly as the reference's `EmbeddingStore.load_sample` does (src/data/components/embedding_store.py:187-193):
-run it on files you built yourself.
+are unpickled like the reference's `EmbeddingStore.load_sample` does (src/data/components/embedding_store.py:187-193), but
+through a RESTRICTED unpickler that only admits the types those dictionaries hold (builtins, torch tensors, numpy arrays): a
+record that names any other callable is refused.
 """
 import argparse
 import os
@@ -18,6 +19,44 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+# What a sample dictionary of the reference's pipeline can contain (scripts/build_retrieval_pipeline.py:2200-2228): builtins,
+# torch tensors (rebuilt through torch._utils / torch.storage helpers) and numpy arrays / scalars.  Everything else is refused,
+# so a crafted record in a shared dataset directory cannot name an arbitrary callable.
+_ALLOWED = {
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "str"), ("builtins", "bytes"), ("builtins", "bytearray"), ("builtins", "int"), ("builtins", "float"),
+    ("builtins", "bool"), ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+    ("collections", "OrderedDict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._tensor", "_rebuild_from_type_v2"), ("torch.storage", "_load_from_bytes"), ("torch", "Size"), ("torch", "device"),
+    ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+}
+_ALLOWED_PREFIXES = (("torch", "Storage"), ("torch", "dtype"))  # torch.FloatStorage ..., torch.float32 ... (matched below)
+
+
+class _SampleUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _ALLOWED:
+            return super().find_class(module, name)
+        if module == "torch" and (name.endswith("Storage") or name in (
+                "float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool")):
+            return super().find_class(module, name)
+        if module == "numpy" and name in ("float32", "float64", "int64", "int32", "int16", "int8", "uint8", "bool_", "float16"):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"lmdb_to_packed: refusing to unpickle {module}.{name} (not a type the reference's samples hold)")
+
+
+def loads_sample(value: bytes):
+    """`pickle.loads` restricted to the types of the reference's sample dictionaries."""
+    import io
+
+    return _SampleUnpickler(io.BytesIO(value)).load()
 
 
 def _read_all(lmdb, path):
@@ -46,11 +85,11 @@ def iter_samples(lmdb_path, limit=0, aux_path=None):
                 name = key.decode("utf-8")
                 if name.startswith("__"):  # metadata records, not samples
                     continue
-                sample = pickle.loads(value)
+                sample = loads_sample(value)
                 if not isinstance(sample, dict) or "edge_index" not in sample:
                     continue
                 if name in aux:
-                    extra = pickle.loads(aux[name])
+                    extra = loads_sample(aux[name])
                     if isinstance(extra, dict):
                         sample.update({k: v for k, v in extra.items() if k not in sample})
                 sample.setdefault("sample_id", name)
