@@ -93,6 +93,8 @@ def parse_args():
                     help="run ONLY the BASELINE config 3 leg (CWQ-shaped CSR / DDE / BFS / seed expansion kernels with their "
                          "CPU-oracle baseline) and print its JSON object")
     ap.add_argument("--graph-batch", type=int, default=64, help="graphs per batch of the --graph-kernels leg")
+    ap.add_argument("--no-labelling", action="store_true",
+                    help="with --graph-kernels: skip the shortest-path labelling leg (counter passes: only CSR / DDE / BFS / expansion run)")
     ap.add_argument("--no-graph-eval", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the text-encoding leg (random-init BERT + pooling kernel)")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -214,7 +216,11 @@ def pmc_traffic(N, D, Q, k, world, kernel_ms_per_step, method="scan"):
                               "rescaled by this run's kernel time; not read live"}
 
 
-def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=4096, relations=4096, cpu_seconds=8.0):
+def exact_env():
+    return os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
+
+
+def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=4096, relations=4096, cpu_seconds=8.0, full=True):
     """Secondary leg (not part of `value`): the per-question subgraph scoring stage of the same
     evaluation — Retriever forward (DDE + edge scorer) and the fused ranking metrics on one
     WebQSP-shaped batch (32 graphs, N_g ~ 1500, E_g ~ 4096, D = H)."""
@@ -275,9 +281,56 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         model(batch)
     torch.cuda.synchronize(dev)
     t_lite = (time.perf_counter() - t0) / iters
+    lite_logits = model(batch).logits.clone()
+    # opt-in matmul_precision="f16x2": two f16 products (activations hi + lo in f16, weights rounded once to f16) instead of
+    # three bf16 products — the same logits-only forward, its distance to the default's logits, and how many (graph, k)
+    # top-k SETS of the evaluation window differ (near-ties flipped by the coarser weights)
+    f16x2 = None
+    if not exact_env():
+        model.matmul_precision = "f16x2"
+        lo2 = model(batch).logits
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model(batch)
+        torch.cuda.synchronize(dev)
+        t_f16 = (time.perf_counter() - t0) / iters
+        model.matmul_precision = "split"
+        ra = M.rank_batch(lite_logits, target, batch, K_WINDOW, want_topk=True)
+        rb2 = M.rank_batch(lo2, target, batch, K_WINDOW, want_topk=True)
+        ia, ib = ra.topk_index.cpu().numpy(), rb2.topk_index.cpu().numpy()
+        cnt = ra.topk_count.cpu().numpy()
+        changed = sum(1 for g in range(graphs) for kk in K_WINDOW
+                      if set(ia[g, :min(kk, int(cnt[g]))].tolist()) != set(ib[g, :min(kk, int(cnt[g]))].tolist()))
+        f16x2 = {"forward_logits_only_ms_per_batch": t_f16 * 1e3, "speedup_over_default": t_lite / t_f16,
+                 "max_abs_dlogit_vs_default": float((lo2 - lite_logits).abs().max().item()),
+                 "topk_sets_changed_vs_default": changed, "of_graph_k_boundaries": graphs * len(K_WINDOW)}
     model.emit_edge_embeddings = True
     gemm_ms = ms[2] / iters
     tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    exact = os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
+    # split-bf16: three bf16 MFMAs per algorithmic product -> executed flops = 3 x algorithmic
+    executed_tf, peak, kname = (tf, 157.3, "k_gemm_nt (f32 MFMA 32x32x2)") if exact else \
+        (3.0 * tf, 2500.0, "k_gemm_nt_bf16x3 (bf16 MFMA 32x32x16, 3 products per f32 product)")
+    roof = {"bound": "mfma", "achieved": executed_tf, "peak": peak, "unit": "TFLOP/s", "frac": executed_tf / peak,
+            "kernel": kname, "algorithmic_tflops": tf, "gemm_ms_per_batch": gemm_ms,
+            "gemm_launches_per_batch": ln[2] / iters, "algorithmic_flops_per_batch": gemm_flops,
+            "edge_feature_ms_per_batch": ms[3] / iters, "traffic": None, "traffic_source": None}
+    pm = pmc_leg_traffic("scorer", f"D{D}", "gemm")
+    if pm is not None and gemm_ms > 0:
+        # HBM bytes the GEMM kernels of ONE forward (edge features on, like the timed pass above) moved (counter passes of tools/scorer_forward_profile.py full on
+        # the same batch shape), as GB/s at this run's GEMM time; the per-edge kernels' bytes beside it
+        legs = {leg: pmc_leg_traffic("scorer", f"D{D}", leg) for leg in ("edge_features", "state_combine")}
+        roof.update(traffic=pm[1]["hbm_bytes_per_batch"] / (gemm_ms * 1e-3) / 1e9, traffic_unit="GB/s (HBM bytes of the GEMM launches)",
+                    hbm_bytes_per_forward={"gemm": pm[1]["hbm_bytes_per_batch"],
+                                           **{leg: v[1]["hbm_bytes_per_batch"] for leg, v in legs.items() if v is not None}},
+                    traffic_source=f"profiles/{pm[0]}: committed rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE passes of the features-on "
+                                   "forward on the same batch shape; not read live")
+    if not full:
+        return {"workload": f"{graphs} graphs, N={N}, E={E}, D=H={D}, DDE 2+2, bidirectional",
+                "forward_ms_per_batch": t_fwd * 1e3, "forward_logits_only_ms_per_batch": t_lite * 1e3,
+                "metrics_ms_per_batch": t_met * 1e3, "queries_per_s": graphs / (t_lite + t_met), "edges_per_s": E / t_lite,
+                "f16x2": f16x2, "roofline": roof}
     # training-shaped step (§8f-4): differentiable forward (per-edge intermediates kept) -> RetrieverLoss -> backward
     # (evi_retriever_backward replays them); eval-mode graph (no dropout), gradients of all 25 parameters
     from evi_rag_amd.loss import RetrieverLoss
@@ -333,10 +386,6 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
                           "clip_grad_norm 1.0 -> AdamW (flat buffers); same batch 8 times; split-bf16 (f32-grade) products")
     # opt-in: trainer.precision = bf16-mixed (configs/trainer/default.yaml:13-14) -> one bf16 product per GEMM, forward and backward
     train_obj["bf16_mixed"] = trainer_leg("bf16-mixed")
-    exact = os.environ.get("EVI_SCORER_GEMM", "")[:1] == "f"
-    # split-bf16: three bf16 MFMAs per algorithmic product -> executed flops = 3 x algorithmic
-    executed_tf, peak, kname = (tf, 157.3, "k_gemm_nt (f32 MFMA 32x32x2)") if exact else \
-        (3.0 * tf, 2500.0, "k_gemm_nt_bf16x3 (bf16 MFMA 32x32x16, 3 products per f32 product)")
     metrics = {k: float(v) for k, v in coll.compute().items()}
     pipeline = bench_eval_pipeline(dev, D, model, nodes=nodes, edges=edges, relations=relations)
     cpu = None
@@ -352,14 +401,12 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         "forward_ms_per_batch": t_fwd * 1e3,
         "forward_logits_only_ms_per_batch": t_lite * 1e3,
         "metrics_ms_per_batch": t_met * 1e3,
+        "f16x2": f16x2,
         "train_step_ms_per_batch": t_train * 1e3,
         "train": train_obj,
         "queries_per_s": graphs / (t_fwd + t_met),
         "edges_per_s": E / t_fwd,
-        "roofline": {"bound": "mfma", "achieved": executed_tf, "peak": peak, "unit": "TFLOP/s", "frac": executed_tf / peak,
-                     "kernel": kname, "algorithmic_tflops": tf, "gemm_ms_per_batch": gemm_ms,
-                     "gemm_launches_per_batch": ln[2] / iters, "algorithmic_flops_per_batch": gemm_flops,
-                     "edge_feature_ms_per_batch": ms[3] / iters},
+        "roofline": roof,
         "reachability@100": metrics.get("answer/reachability@100"),
         "edge_recall@100": metrics.get("edge/recall@100"),
         "eval_pipeline": pipeline,
@@ -660,7 +707,31 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
     return res
 
 
-def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, iters=20, cpu_graphs=8, cpu=True):
+GRAPH_LEG_KERNELS = {  # C-ABI entry point -> the kernels it launches (names as rocprofv3 prints them)
+    "evi_graph_csr": ("k_csr_part_count", "k_csr_part_scan", "k_csr_part_fill", "k_graph_csr"),
+    "evi_dde_node_struct": ("k_dde_round",),
+    "evi_bfs_levels": ("k_bfs_levels",),
+    "evi_select_start_edges": ("k_select_start_edges", "k_zero_mask"),
+}
+
+
+def pmc_leg_traffic(kind, key, leg):
+    """HBM bytes per batch of one leg from the latest committed counter file `profiles/r*_pmc_<kind>.json` (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, tools/collect_pmc_legs.sh), or None.  Not read live: counters cannot be
+    collected inside the bench; the file names its command."""
+    prof_dir = os.path.join(REPO_ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(prof_dir)) if os.path.isdir(prof_dir) else []:
+        if name.endswith(f"_pmc_{kind}.json"):
+            with open(os.path.join(prof_dir, name)) as fh:
+                p = json.load(fh)
+            ent = (p.get(key) or {}).get("legs", {}).get(leg)
+            if ent is not None:
+                best = (name, ent)
+    return best
+
+
+def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, iters=20, cpu_graphs=8, cpu=True, labelling_leg=True):
     """BASELINE config 3 (CWQ-shaped 2-hop expansion): CSR build, DDE structure features, multi-source BFS levels,
     seed-incident edge selection on batches of CWQ-shaped graphs (N_g ~ 3 000, E_g ~ 10 000, DDE 2 + 2 rounds,
     ratio 0.25), the algorithmic bytes of each kernel as GB/s, beside the CPU oracle on a sample."""
@@ -691,8 +762,15 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
            "kernels": {}}
 
     def rec(name, ms, nbytes, note):
-        res["kernels"][name] = {"ms_per_batch": ms, "algorithmic_bytes": nbytes, "GB_per_s": nbytes / (ms * 1e-3) / 1e9,
-                                "graphs_per_s": B / (ms * 1e-3), "note": note}
+        ent = {"ms_per_batch": ms, "algorithmic_bytes": nbytes, "GB_per_s": nbytes / (ms * 1e-3) / 1e9,
+               "graphs_per_s": B / (ms * 1e-3), "note": note, "traffic": None, "traffic_source": None}
+        pm = pmc_leg_traffic("graph", f"batch_{B}", name)
+        if pm is not None and pm[1].get("workload_edges") == E:
+            hb = pm[1]["hbm_bytes_per_batch"]
+            ent.update(traffic=hb / (ms * 1e-3) / 1e9, hbm_bytes_per_batch=hb, traffic_over_algorithmic=hb / nbytes,
+                       traffic_source=f"profiles/{pm[0]}: committed rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE passes of the same "
+                                      "batch, rescaled by this run's kernel time; not read live")
+        res["kernels"][name] = ent
 
     csr = ops.graph_csr(ei, ptr, eptr, num_nodes=N)
     csr_ws = torch.empty(int(lib.evi_graph_csr_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -758,13 +836,16 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
     dom = max(res["kernels"], key=lambda n: res["kernels"][n]["ms_per_batch"])
     dk = res["kernels"][dom]
     res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": dk["GB_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": dk["GB_per_s"] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                       "frac": dk["GB_per_s"] / HBM_PEAK_GBS, "traffic": dk.get("traffic"), "traffic_source": dk.get("traffic_source"),
+                       "traffic_over_algorithmic": dk.get("traffic_over_algorithmic"),
                        "algorithmic_bytes_per_batch": dk["algorithmic_bytes"], "kernel_ms_per_batch": dk["ms_per_batch"],
                        "all_four_kernels": {"algorithmic_bytes_per_batch": sum(k["algorithmic_bytes"] for k in res["kernels"].values()),
                                             "ms_per_batch": total_ms,
                                             "GB_per_s": sum(k["algorithmic_bytes"] for k in res["kernels"].values()) / (total_ms * 1e-3) / 1e9}}
     res["gpu_graphs_per_s"] = B / (seq_ms * 1e-3)  # the replayed pipeline; the eager per-kernel legs above include host launch gaps
     res["gpu_epoch_seconds"] = graphs / res["gpu_graphs_per_s"]
+    if not labelling_leg:  # counter passes: only the four kernels above, so that dispatch counts map to batches
+        return res
     # shortest-path labelling of the same batch: the (seed, answer) pairs' shortest-path DAG
     # edges for every graph — one BFS job per seed and per answer, evi_shortest_path_pairs in two passes — through the FLAT
     # entry point `labelling.label_pairs_flat`: the collated batch's device arrays in (edge_index, ptr, edge_ptr), the seed /
@@ -1196,7 +1277,11 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
     # Hits@k of the planted gold rows on the last timed batch (identical on every rank)
     s_last, i_last = out
     g = gold[(warmup + steps - 1) % n_batches].to(dev).view(Q, 1)
-    rank_of_gold = torch.where((i_last == g).any(dim=1), (i_last == g).float().argmax(dim=1), torch.full((Q,), 10 ** 9, device=dev))
+    # rank = number of returned rows that score STRICTLY higher than the planted row: 1 % of the index rows are exact duplicates,
+    # and a planted row whose twin has the lower id is (correctly, by the (score desc, id asc) order) listed second
+    match = i_last == g
+    gold_score = s_last.gather(1, match.float().argmax(dim=1).view(Q, 1))
+    rank_of_gold = torch.where(match.any(dim=1), (s_last > gold_score).sum(dim=1), torch.full((Q,), 10 ** 9, device=dev))
     hits = {f"hits@{kk}": float((rank_of_gold < kk).float().mean().item()) for kk in K_WINDOW if kk <= k}
     sorted_ok = bool((s_last[:, 1:] <= s_last[:, :-1]).all().item())
 
@@ -1355,7 +1440,7 @@ def main():
 
     if args.graph_kernels:  # config 3 leg only
         if rank == 0:
-            res = bench_graph_kernels(dev, args.graph_batch, cpu=not args.no_cpu_baseline)
+            res = bench_graph_kernels(dev, args.graph_batch, cpu=not args.no_cpu_baseline, labelling_leg=not args.no_labelling)
             os.write(result_fd, (json.dumps(res) + "\n").encode())
         return
     ctx = Ctx(dev, world, rank, _lib.load())
@@ -1417,6 +1502,10 @@ def main():
                 f"batch_{b}": bench_graph_kernels(dev, b, cpu=(cpu_s > 0 and b == 32)) for b in (32, 512)}
         if world == 1 and not args.no_graph_eval:
             result["graph_eval"] = bench_graph_eval(dev, D, cpu_seconds=0.0 if args.no_cpu_baseline else 8.0)
+            if extra and D != 1024:
+                # the reference's DEFAULT scorer width (configs/model/retriever_module.yaml:10-17: emb_dim = hidden_dim = 1024)
+                torch.cuda.empty_cache()
+                result["graph_eval_1024"] = bench_graph_eval(dev, 1024, cpu_seconds=0.0, full=False)
         if world == 1 and not args.no_encode:
             torch.cuda.empty_cache()
             try:

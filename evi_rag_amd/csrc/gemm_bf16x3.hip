@@ -50,6 +50,14 @@ __global__ void k_split_weight(const float* __restrict__ W, int N, int K, int64_
     lo[i] = (__bf16)(x - (float)h);
 }
 
+// W [N, K] f32 -> ONE f16 plane [N, Kp] (round to nearest), written where the bf16 hi plane would go: the f16x2 form
+__global__ void k_round_weight_f16(const float* __restrict__ W, int N, int K, int64_t ldw, int Kp, _Float16* __restrict__ hi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    hi[i] = (_Float16)(k < K ? W[(int64_t)n * ldw + k] : 0.f);
+}
+
 // the same for very long rows (64-bit element count): the W operand of a split-K batch
 __global__ void k_split_weight_long(const float* __restrict__ W, int N, int64_t K, int64_t ldw, int64_t Kp,
                                     __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
@@ -71,6 +79,11 @@ __global__ void k_split_weight_long(const float* __restrict__ W, int N, int64_t 
 // P1 = 1: single product hi * hi (plain bf16 GEMM: relative error 2^-8 instead of 2^-16) — only for the candidate
 // selection of the many-query top-k, whose results are re-scored exactly; the lo planes are neither loaded,
 // staged nor multiplied.
+// P1 = 2 ("f16x2", opt-in, f32 A only, MF = 0): TWO products on v_mfma_f32_32x32x16_f16 — A = hi + lo with hi = f16(a),
+// lo = f16(a - hi) (22 significant bits), W rounded ONCE to f16 (2^-12 relative per weight; `Whi` then holds f16 bits,
+// there is no W lo plane).  Two thirds of the MFMA work of the three-product form; the error is the weights' f16 rounding —
+// four times finer than the TF32 rounding of BOTH operands the reference runs with on CUDA
+// (configs/extras/default.yaml:11) — and f16's range: |a|, |w| must stay below 65 504.
 template <int ACT, int MF, int AH = 0, int P1 = 0>
 __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const float* __restrict__ A, int64_t M, int K, int64_t lda, const __bf16* __restrict__ Whi,
@@ -90,8 +103,11 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     }
     const int64_t w_ld = bt.count > 0 ? bt.w_ld : (int64_t)Kp;
     if (bt.count > 0) Kp = (K + XK - 1) / XK * XK;
+    constexpr bool kALo = P1 != 1;  // A lo plane staged and multiplied (three-product and f16x2 forms)
+    constexpr bool kWLo = P1 == 0;  // W lo plane (three-product form only)
+    static_assert(P1 != 2 || (AH == 0 && MF == 0), "f16x2 takes f32 A and the 32x32x16 MFMA");
     __shared__ uint4 sAhi[2][XM * 4], sWhi[2][XN * 4];                                     // 2 stages x 16 KiB each
-    __shared__ uint4 sAlo[P1 ? 1 : 2][P1 ? 1 : XM * 4], sWlo[P1 ? 1 : 2][P1 ? 1 : XN * 4];  // lo planes (absent when P1)
+    __shared__ uint4 sAlo[kALo ? 2 : 1][kALo ? XM * 4 : 1], sWlo[kWLo ? 2 : 1][kWLo ? XN * 4 : 1];  // lo planes where the form has them
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     // Staging registers.  NS sets: a tile is loaded NS iterations before it is written to LDS.  One set when all three
     // products are multiplied (the register file is full); two with P1, whose k-tile takes a third of the MFMA time —
     // with one set its loop ran at the latency of a global load per k-tile, not at the speed of its MFMAs.
-    constexpr int NS = P1 ? 2 : 1;
+    constexpr int NS = P1 == 1 ? 2 : 1;
     f32x4 ra[NS][4];
     u32x4 ra16[NS][2];  // AH != 0: two chunks of 8 halves per thread
     u32x4 rwh[NS][2], rwl[NS][2];
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const bool ok = wr < N && k < Kp;
         const int64_t off = ok ? (int64_t)wr * w_ld + k : 0;
         rwh[set][i] = *reinterpret_cast<const u32x4*>(Whi + off);
-        if (!P1) rwl[set][i] = *reinterpret_cast<const u32x4*>(Wlo + off);
+        if (kWLo) rwl[set][i] = *reinterpret_cast<const u32x4*>(Wlo + off);
     };
     // k0 = first k of the tile the registers hold: the range check of the load is repeated here, so the
     // select sits next to the conversion and not behind the load (where it would stall on the load's latency)
@@ -146,18 +162,33 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         const int r = s >> 3, c4 = s & 7;
         const bool ok = m0 + r < M && k0 + c4 * 4 < K;
         const f32x4 v = ok ? ra[set][i] : zero4;
-        bf16x4 h, l;
+        uint2 hb, lb;
+        if (P1 == 2) {  // f16 hi / lo
+            typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+            f16x4v h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (__bf16)v[e];
-            l[e] = (__bf16)(v[e] - (float)h[e]);
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (_Float16)v[e];
+                l[e] = (_Float16)(v[e] - (float)h[e]);
+            }
+            hb = __builtin_bit_cast(uint2, h);
+            lb = __builtin_bit_cast(uint2, l);
+        } else {
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (__bf16)v[e];
+                l[e] = (__bf16)(v[e] - (float)h[e]);
+            }
+            hb = *reinterpret_cast<uint2*>(&h);
+            lb = *reinterpret_cast<uint2*>(&l);
         }
         // 8-byte halves of the 16-byte chunk c = c4 >> 1
         uint2* dh = reinterpret_cast<uint2*>(&sAhi[buf][slot3(r, c4 >> 1)]) + (c4 & 1);
-        *dh = *reinterpret_cast<uint2*>(&h);
-        if (!P1) {
-            uint2* dl = reinterpret_cast<uint2*>(&sAlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c4 >> 1)]) + (c4 & 1);
-            *dl = *reinterpret_cast<uint2*>(&l);
+        *dh = hb;
+        if (kALo) {
+            uint2* dl = reinterpret_cast<uint2*>(&sAlo[kALo ? buf : 0][kALo ? slot3(r, c4 >> 1) : 0]) + (c4 & 1);
+            *dl = lb;
         }
     };
     // f16-stored A: 1024 chunks of 8 halves (16 B), 4 per row
@@ -187,14 +218,14 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             l[e] = (__bf16)(f - (float)h[e]);
         }
         *reinterpret_cast<bf16x8*>(&sAhi[buf][slot3(r, c)]) = h;
-        if (!P1) *reinterpret_cast<bf16x8*>(&sAlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = l;
+        if (kALo) *reinterpret_cast<bf16x8*>(&sAlo[kALo ? buf : 0][kALo ? slot3(r, c) : 0]) = l;
     };
     auto store_w = [&](int set, int i, int buf, int k0) {
         const int s = tid + kXThreads * i;
         const int r = s >> 2, c = s & 3;
         const bool ok = n0 + r < N && k0 + c * 8 < Kp;
         *reinterpret_cast<u32x4*>(&sWhi[buf][slot3(r, c)]) = ok ? rwh[set][i] : zero16;
-        if (!P1) *reinterpret_cast<u32x4*>(&sWlo[P1 ? 0 : buf][P1 ? 0 : slot3(r, c)]) = ok ? rwl[set][i] : zero16;
+        if (kWLo) *reinterpret_cast<u32x4*>(&sWlo[kWLo ? buf : 0][kWLo ? slot3(r, c) : 0]) = ok ? rwl[set][i] : zero16;
     };
 
     f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];   // MF = 0
@@ -257,13 +288,13 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
         // never waits on the LDS latency of its own operands.
         // A fragments are read AHEAD groups before their MFMAs: one group (six MFMAs = 192 cycles) covers the LDS
         // latency when three products are multiplied; with one product a group is two MFMAs, so read two ahead.
-        constexpr int AHEAD = P1 ? 2 : 1, RING = AHEAD + 1;
+        constexpr int AHEAD = P1 == 1 ? 2 : 1, RING = AHEAD + 1;
         bf16x8 fah[RING], fal[RING], fbh[MF ? 1 : 2][MF ? 4 : 2], fbl[MF ? 1 : 2][MF ? 4 : 2];
         auto read_a = [&](int g) {
             const int c = MF ? q16 : ((g >> 2) << 1) + fh;  // MF = 0: chunk holding k = 16 (g >> 2) + 8 h .. + 7
             const int row = MF ? wm * 128 + g * 16 + r16 : wm * 128 + (g & 3) * 32 + fr;
             fah[g % RING] = *reinterpret_cast<const bf16x8*>(&sAhi[cur][slot3(row, c)]);
-            if (!P1) fal[g % RING] = *reinterpret_cast<const bf16x8*>(&sAlo[P1 ? 0 : cur][P1 ? 0 : slot3(row, c)]);
+            if (kALo) fal[g % RING] = *reinterpret_cast<const bf16x8*>(&sAlo[kALo ? cur : 0][kALo ? slot3(row, c) : 0]);
         };
         auto read_b = [&](int ks) {
             const int c = MF ? q16 : (ks << 1) + fh;
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
             for (int j = 0; j < (MF ? 4 : 2); ++j) {
                 const int row = MF ? wn * 64 + j * 16 + r16 : wn * 64 + j * 32 + fr;
                 fbh[ks][j] = *reinterpret_cast<const bf16x8*>(&sWhi[cur][slot3(row, c)]);
-                if (!P1) fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sWlo[P1 ? 0 : cur][P1 ? 0 : slot3(row, c)]);
+                if (kWLo) fbl[ks][j] = *reinterpret_cast<const bf16x8*>(&sWlo[kWLo ? cur : 0][kWLo ? slot3(row, c) : 0]);
             }
         };
         read_b(0);
@@ -294,6 +325,13 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16& c = acc[MF ? 0 : i][MF ? 0 : j];
+                    if (P1 == 2) {  // f16x2: (lo + hi) * W on the f16 instruction, the small term first
+                        typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+                        const f16x8v wv = __builtin_bit_cast(f16x8v, fbh[MF ? 0 : ks][MF ? 0 : j]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fal[g % RING]), wv, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fah[g % RING]), wv, c, 0, 0, 0);
+                        continue;
+                    }
                     if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[g % RING], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
                     if (!P1) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g % RING], fbl[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[g % RING], fbh[MF ? 0 : ks][MF ? 0 : j], c, 0, 0, 0);
@@ -462,13 +500,22 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, i
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
                           const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single) {
     if (M == 0 || N == 0) return EVI_OK;
-    if (int rc = split_weight_bf16x3(W, N, K, ldw, wsplit, st)) return rc;
+    if (single == 2) {  // f16x2: the weight as one f16 plane in the hi slot of `wsplit`
+        const int Kp = (K + XK - 1) / XK * XK;
+        const int64_t total = (int64_t)N * Kp;
+        hipLaunchKernelGGL(k_round_weight_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, ldw, Kp,
+                           static_cast<_Float16*>(wsplit));
+        EVI_LAUNCH_CHECK();
+    } else if (int rc = split_weight_bf16x3(W, N, K, ldw, wsplit, st)) {
+        return rc;
+    }
     return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wsplit, N, bias, act, C, ldc, st, single);
 }
 
 // the same with W already split (split_weight_bf16x3 wrote `wplanes`): what a caller that keeps its weights prepared uses.
-// single != 0: one bf16 product (hi * hi only, f32 accumulation and output) — the arithmetic of a bf16-autocast Linear
+// single == 1: one bf16 product (hi * hi only, f32 accumulation and output) — the arithmetic of a bf16-autocast Linear
 // with an f32 result; the scorer's opt-in `bf16-mixed` training precision.
+// single == 2: the f16x2 form (see the kernel): `wplanes` must then hold the weight as ONE f16 plane (k_round_weight_f16).
 int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
                                   const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single) {
     if (M == 0 || N == 0) return EVI_OK;
@@ -485,7 +532,9 @@ int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda,
         return e && e[0] == '1';
     }();
 #define EVI_LAUNCH_X3(ACT)                                                                                              \
-    if (single)                                                                                                         \
+    if (single == 2)                                                                                                    \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 2>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
+    else if (single)                                                                                                    \
         hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
     else if (mfma16)                                                                                                    \
         hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \

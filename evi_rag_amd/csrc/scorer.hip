@@ -143,6 +143,9 @@ struct EdgeFeatArgs {
     float* RCX;  // [e_count, D]  r_ctx
     float* XS;   // [(dir_fwd + dir_bwd) * e_count, D]  struct context per direction
     float* aux;  // [(dir_fwd + dir_bwd) * e_count, 2]  (nav gate, -||translation error||)
+    // k_edge_features<C4, true> (evaluation, D % 32 == 0): P / RCX / XS are written as the bf16 hi / lo planes the pre-split
+    // GEMM reads by LDS-DMA (gemm_ps.hip) — [rows, D] bf16 hi at the buffer's start, [rows, D] bf16 lo right behind it: the
+    // same bytes as the f32 rows, the same hi = bf16(x), lo = bf16(x - hi) the register-staged GEMM forms, so the same bits out
 };
 
 // Lane -> feature map of the per-edge kernels: lane owns the float4 chunks d = 4 * lane + 256 * i, i < C4 = ceil(D / 256)
@@ -152,8 +155,22 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ inline f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ inline void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 __device__ inline float hsum4(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+// one lane's float4 as bf16 hi / lo quads into the two planes of a [rows, D] operand (hi plane first, lo plane behind it)
+__device__ inline void st4_planes(float* base, int64_t rows, int64_t row, int D, int d, f4 v) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    bf4 h, l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h[c] = (__bf16)v[c];
+        l[c] = (__bf16)(v[c] - (float)h[c]);
+    }
+    __bf16* hi = reinterpret_cast<__bf16*>(base);
+    __bf16* lo = hi + rows * D;
+    *reinterpret_cast<bf4*>(hi + row * D + d) = h;
+    *reinterpret_cast<bf4*>(lo + row * D + d) = l;
+}
 
-template <int C4>
+template <int C4, bool PLN = false>
 __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
     extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
@@ -268,13 +285,15 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             const float nav = sigmoidf_(wsum(gacc) + gate_b);
             const int64_t row = (int64_t)out_row * a.e_count + le;
             float* xs = a.XS + row * D;
+            const int64_t xs_rows = (int64_t)(a.dir_fwd + a.dir_bwd) * a.e_count;
             float dsq = 0.f;
 #pragma unroll
             for (int i = 0; i < C4; ++i) {
                 const int d = 4 * lane + 256 * i;
                 if (d < D) {
                     const f4 err = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
-                    st4(xs + d, sv[i]);
+                    if (PLN) st4_planes(a.XS, xs_rows, row, D, d, sv[i]);
+                    else st4(xs + d, sv[i]);
                     dsq += hsum4(err * err);
                 }
             }
@@ -291,8 +310,13 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
         for (int i = 0; i < C4; ++i) {
             const int d = 4 * lane + 256 * i;
             if (d < D) {
-                st4(pp + d, h[i] * rc[i] * t[i]);
-                st4(rx + d, rc[i]);
+                if (PLN) {
+                    st4_planes(a.P, a.e_count, le, D, d, h[i] * rc[i] * t[i]);
+                    st4_planes(a.RCX, a.e_count, le, D, d, rc[i]);
+                } else {
+                    st4(pp + d, h[i] * rc[i] * t[i]);
+                    st4(rx + d, rc[i]);
+                }
             }
         }
     }
@@ -497,6 +521,15 @@ static bool use_f32_gemm() {
     return v && v[0] == 'f';
 }
 
+// EVI_SCORER_GEMM_PS=0 keeps the evaluation forward on the register-staged GEMM (A/B runs; default: the pre-split kernel)
+static bool use_gemm_ps() {
+    static const bool v = [] {
+        const char* e = getenv("EVI_SCORER_GEMM_PS");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 // EviRetrieverBatch.matmul_precision of the call in flight on this thread: 1 = the large GEMMs multiply ONE bf16 product
 // (f32 accumulation and results) instead of three.  Set for the duration of retriever_run by SingleProductScope; read by the
 // two places every large product of the scorer goes through (scorer_gemm, tn_gemm).
@@ -515,7 +548,9 @@ static int scorer_gemm(const float* A, int64_t M, int K, int64_t lda, const floa
     // a handful of rows (question-side projections, the non-text embedding): one wave per output column, exact f32 (gemm_skinny.hip)
     if (gemm_skinny_fits(M, K, lda, ldw)) return launch_gemm_skinny(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
     if (use_f32_gemm()) return launch_gemm_nt(A, M, K, lda, W, N, ldw, bias, act, C, ldc, st);
-    if (wplanes) return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wplanes, N, bias, act, C, ldc, st, t_gemm_single);
+    // matmul_precision 2 (f16x2, forward only): the prepared planes are bf16 hi / lo, so the weight is rounded to its f16 plane
+    // here, per call, into `wsplit` (a [N, K] pass: 0.6 M elements next to a 50 M-element product)
+    if (wplanes && t_gemm_single != 2) return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wplanes, N, bias, act, C, ldc, st, t_gemm_single);
     return launch_gemm_nt_bf16x3(A, M, K, lda, W, N, ldw, bias, act, C, ldc, wsplit, st, t_gemm_single);
 }
 
@@ -781,7 +816,7 @@ static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, flo
         int64_t Ks;
         int S;
         gemm_tn_plan(M, N, K, kTnMaxSlices, &Ks, &S);
-        int rc = launch_gemm_tn_bf16x3(A, M, M, Bm, N, N, K, Ks, (int)S, part, st, t_gemm_single);
+        int rc = launch_gemm_tn_bf16x3(A, M, M, Bm, N, N, K, Ks, (int)S, part, st, t_gemm_single == 1);
         if (rc) return rc;
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, part, (int)S,
                            (int64_t)M * N, C, accumulate ? 1 : 0);
@@ -900,8 +935,10 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     EVI_REQUIRE(b->dropout_p >= 0.f && b->dropout_p < 1.f, "dropout probability has to be between 0 and 1, but got %g", (double)b->dropout_p);
     uint32_t drop_thr = (uint32_t)lrintf(b->dropout_p * 65536.0f);
     if (drop_thr > 65535u) drop_thr = 65535u;
-    EVI_REQUIRE(b->matmul_precision == 0 || b->matmul_precision == 1, "matmul_precision must be 0 (split-bf16, three products) or 1 (one bf16 product), got %d",
+    EVI_REQUIRE(b->matmul_precision >= 0 && b->matmul_precision <= 2,
+                "matmul_precision must be 0 (split-bf16, three products), 1 (one bf16 product) or 2 (f16x2: two f16 products, forward only), got %d",
                 b->matmul_precision);
+    EVI_REQUIRE(!(b->matmul_precision == 2 && bw), "matmul_precision 2 (f16x2) is an evaluation-time option: the backward runs with 0 or 1");
     const SingleProductScope precision_scope(b->matmul_precision);
     const int S = 1 + w->dde_rounds + w->dde_reverse_rounds;
     const int F = 2 * 2 * S;
@@ -1070,22 +1107,47 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         a.aux = pAux;
         int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
         if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS: 32 waves per CU hide the gather latency
+        // Evaluation with prepared weight planes: the edge kernel writes the GEMM operands as bf16 hi / lo planes (same bytes as
+        // the f32 rows) and the three products run on the pre-split kernel, which moves them global -> LDS by LDS-DMA with no
+        // conversion work (gemm_ps.hip: +4-5 % on these shapes, same bits).  Training keeps the f32 rows: the backward replays them.
+        const bool ps = !saved && !bw && prep && !use_f32_gemm() && t_gemm_single == 0 && D % 32 == 0 && use_gemm_ps();
         if (!replay) {
         const int tok = timing_begin(kTimeEdge, st);
         EVI_DPL_DISPATCH(dpl_d, {
-            static thread_local bool attr = false;
-            if (!attr) {
-                EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr = true;
+            if (ps) {
+                static thread_local bool attr_p = false;
+                if (!attr_p) {
+                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr_p = true;
+                }
+                hipLaunchKernelGGL((k_edge_features<DPL, true>), dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
+            } else {
+                static thread_local bool attr = false;
+                if (!attr) {
+                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr = true;
+                }
+                hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
             }
-            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
+        if (ps) {
+            auto ps_gemm = [&](const float* planes_base, int64_t rows, size_t woff, const float* bias, float* C) {
+                const __bf16* ahi = reinterpret_cast<const __bf16*>(planes_base);
+                const char* wp = prep + woff;  // k_split_weight's layout: hi [H, D] bf16, lo behind it (256-byte aligned)
+                return launch_gemm_ps_bf16x3(ahi, ahi + rows * D, rows, D, wp, wp + align_up((size_t)H * D * 2, 256), H, bias, 0, C, H, st);
+            };
+            if ((rc = ps_gemm(pP, ec, PL.p_wa, nullptr, pPA))) return rc;
+            if ((rc = ps_gemm(pRCX, ec, PL.p_wc, nullptr, pRC))) return rc;
+            if ((rc = ps_gemm(pXS, M, PL.p_wb, w->state0_b, pSB))) return rc;
+        } else {
         if ((rc = scorer_gemm(pP, ec, D, D, wa, H, D, nullptr, 0, pPA, H, wsplit, st, planes(PL.p_wa)))) return rc;
         if ((rc = scorer_gemm(pRCX, ec, D, D, wc, H, D, nullptr, 0, pRC, H, wsplit, st, planes(PL.p_wc)))) return rc;
         if ((rc = scorer_gemm(pXS, M, D, D, wb, H, D, w->state0_b, 0, pSB, H, wsplit, st, planes(PL.p_wb)))) return rc;
+        }
         }
         CombineArgs c;
         c.edge_index = b->edge_index;

@@ -23,7 +23,7 @@ from . import _lib, ops
 _NUM_TOPICS_BINARY = 2
 _MAX_DDE_ROUNDS = 4
 _DIRECTION_CODE = {"bidirectional": 0, "forward": 1, "backward": 2}
-_MATMUL_PRECISION_CODE = {"split": 0, "bf16": 1}  # EviRetrieverBatch.matmul_precision
+_MATMUL_PRECISION_CODE = {"split": 0, "bf16": 1, "f16x2": 2}  # EviRetrieverBatch.matmul_precision
 
 
 @dataclass
@@ -141,7 +141,9 @@ class Retriever(nn.Module):
         self.keep_forward_intermediates = True
         # "split" (default): every large product as three bf16 MFMA products of the split f32 operands (f32-grade results);
         # "bf16": one bf16 product with f32 accumulation and results, forward and backward — the arithmetic class of
-        # Lightning's `precision: bf16-mixed` (configs/trainer/default.yaml:13-14), opt-in for training runs
+        # Lightning's `precision: bf16-mixed` (configs/trainer/default.yaml:13-14), opt-in for training runs;
+        # "f16x2" (evaluation only): two f16 products — activations as f16 hi + lo, weights rounded once to f16 (2^-12 relative,
+        # finer than the TF32 the reference's CUDA run uses): two thirds of the matrix work of "split", logits within ~1e-4
         self.matmul_precision = str(matmul_precision)
         if self.matmul_precision not in _MATMUL_PRECISION_CODE:
             raise ValueError(f"matmul_precision must be one of {sorted(_MATMUL_PRECISION_CODE)}, got {matmul_precision!r}")
@@ -516,6 +518,8 @@ class Retriever(nn.Module):
         both = self.direction_mode == "bidirectional"
         params = [p for _, p in self._param_fields()]
         differentiable = self.training if self.differentiable is None else bool(self.differentiable)
+        if differentiable and self.matmul_precision == "f16x2" and torch.is_grad_enabled():
+            raise ValueError("matmul_precision='f16x2' is an evaluation-time option (the backward runs with 'split' or 'bf16')")
         if differentiable and torch.is_grad_enabled() and any(p.requires_grad for p in params):
             # the differentiable form: gradients with respect to the parameters come from
             # evi_retriever_backward; logits_fwd / logits_bwd / edge_embeddings are returned detached

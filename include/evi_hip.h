@@ -590,7 +590,12 @@ typedef struct EviRetrieverBatch {
                                          * product with f32 accumulation and f32 results, forward and backward — at least the
                                          * arithmetic of Lightning's `precision: bf16-mixed` (bf16 autocast rounds the results
                                          * to bf16 as well), which configs/trainer/default.yaml:13-14 recommends for training
-                                         * on GPUs that have it; the few-row products (question side) stay exact f32 */
+                                         * on GPUs that have it; the few-row products (question side) stay exact f32.
+                                         * 2 ("f16x2", evaluation only — the backward refuses it): TWO f16 MFMA products,
+                                         * activations split hi + lo in f16 (22 significant bits), each weight rounded once
+                                         * to f16 (2^-12 relative: four times finer than the TF32 rounding of both operands
+                                         * the reference's CUDA run applies, configs/extras/default.yaml:11); two thirds of
+                                         * the matrix work of 0; operands must stay inside f16's range (|x| < 65 504) */
 } EviRetrieverBatch;
 
 /* RetrieverOutput (src/models/components/retriever.py:80-99); any pointer but logits may be NULL. */

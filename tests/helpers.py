@@ -42,3 +42,17 @@ def check_topk_against_scores(hip_scores, hip_ids, ref_scores_full, k, *, id_bas
             for r in ref_set ^ got_set:
                 assert abs(float(ref_scores_full[q, r]) - float(kth)) <= tie_eps, (
                     f"q={q}: row {r} (score {ref_scores_full[q, r]}) differs from oracle set, k-th={kth}")
+
+
+def report(name: str, **values) -> None:
+    """Measured figures a parity test wants on record (counts of near-tie flips, worst errors): appended as one JSON line to
+    gpurun_out/test_report.jsonl when that directory exists (the GPU box's scratch output, merged back by gpurun); a no-op
+    elsewhere.  Never part of a verdict — the asserts are."""
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "test_report.jsonl"), "a") as fh:
+            fh.write(json.dumps({"test": name, **values}) + "\n")

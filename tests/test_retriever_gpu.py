@@ -221,6 +221,48 @@ def test_retriever_forward_matches_oracle_webqsp_shape(dev, dedupe):
     assert np.array_equal(out.query_ids.cpu().numpy(), ref["query_ids"])
 
 
+@pytest.mark.parametrize("D,H,E_g", [(768, 768, 1200), (1024, 1024, 700), (96, 64, 300)])
+def test_retriever_forward_f16x2_option_within_the_score_tolerance(dev, D, H, E_g):
+    """matmul_precision="f16x2" (opt-in, evaluation only): two f16 MFMA products — activations split hi + lo in f16, every
+    weight rounded once to f16.  The bar is north_star's score tolerance (1e-3 on the logits against the f32 oracle); measured
+    far inside it.  The default ("split") is run beside it on the same batch for the comparison the docs quote; the backward
+    refuses the option."""
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(3, nodes_per_graph=400, edges_per_graph=E_g, emb_dim=D, num_relations=64, seed=D + 1)
+    torch.manual_seed(D)
+    model = Retriever(emb_dim=D, hidden_dim=H).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    w = {k: v.numpy() for k, v in model.state_dict().items()}
+    ref = oscorer.retriever_forward(w, sb, num_rounds=2, num_reverse_rounds=2)
+    model = model.to(dev)
+    batch = synthetic.as_namespace(sb, device=dev)
+    out_split = model(batch)
+    model.matmul_precision = "f16x2"
+    out = model(batch)
+    err = float(np.max(np.abs(out.logits.cpu().numpy() - ref["logits"])))
+    err_split = float(np.max(np.abs(out_split.logits.cpu().numpy() - ref["logits"])))
+    from tests.helpers import report
+
+    report("retriever_forward_f16x2", D=D, H=H, max_abs_dlogit_f16x2=err, max_abs_dlogit_split=err_split)
+    print(f"\nf16x2 D={D} H={H}: max |dlogit| {err:.2e} (split-bf16: {err_split:.2e})")
+    assert err <= 1e-3, err
+    assert err_split <= 3e-4
+    np.testing.assert_allclose(out.edge_embeddings.cpu().numpy(), ref["edge_embeddings"], rtol=0, atol=2e-3)
+    assert not torch.equal(out.logits, out_split.logits)  # it really is another arithmetic
+    model.emit_edge_embeddings = False  # logits-only form: score_head folded into state_net.4
+    lite = model(batch)
+    assert float((lite.logits - out.logits).abs().max()) <= 2e-4
+    model.differentiable = True
+    with pytest.raises(ValueError, match="evaluation-time option"):
+        model(batch)
+    with pytest.raises(ValueError, match="matmul_precision"):
+        Retriever(emb_dim=D, hidden_dim=H, matmul_precision="fp4")
+
+
 @pytest.mark.parametrize("D,H", [(1024, 1024), (384, 256), (1280, 64)])
 def test_retriever_forward_other_dims(dev, D, H):
     """The reference default (emb_dim = hidden_dim = 1024, configs/model/retriever_module.yaml:10-11),
