@@ -38,37 +38,42 @@ constexpr int kBfsWaveDegree = 512;    // up to this by one wave (lanes stride t
 constexpr int kBfsBigCap = 64;
 
 struct BfsQueueShared {
-    int qcount[2];
-    int hub_count;
+    int qtail;      // entries in the (append-only) queue: a node is queued once in the whole search, so ONE array of N_g holds
+    int hub_count;  // every frontier back to back — the current one is [begin, end), the next grows behind it
     int big_count;
+    int pad;
     int4 hubs[kBfsHubCap];  // (out begin, out end, in begin, in end) of the node's CSR rows: read once, when it is classified
     int4 big[kBfsBigCap];
 };
 
-__device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __restrict__ q0, int32_t* __restrict__ q1, int64_t n0,
+// CACHED: the graph's CSR rows were copied into LDS by the caller (l_* arrays: row pointers relative to the graph's first
+// slot, neighbours as LOCAL node ids) — a level then costs LDS reads only; a frontier of a 3 000-node graph is two dependent
+// row gathers deep, ~1.5 us each from the L2, and a search is ~9 such levels.  Otherwise the rows are read from global memory.
+template <bool CACHED>
+__device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __restrict__ q, int64_t n0,
                                        const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
                                        const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr, int mode,
                                        BfsQueueShared* sh) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int cur = 0;
-    for (int level = 0;; ++level, cur ^= 1) {
-        __syncthreads();  // qcount[cur] and the queue are complete
-        const int n = sh->qcount[cur];
+    const int sub = CACHED ? 0 : (int)n0;          // neighbour entry -> local node id
+    const int64_t row0 = CACHED ? 0 : n0;          // local node id -> row pointer index
+    int begin = 0;
+    for (int level = 0;; ++level) {
+        __syncthreads();  // the queue holds the whole frontier
+        const int end = sh->qtail;
+        const int n = end - begin;
         if (n == 0) break;  // uniform
         if (tid == 0) {
-            sh->qcount[cur ^ 1] = 0;
             sh->hub_count = 0;
             sh->big_count = 0;
         }
-        __syncthreads();
-        const int32_t* q = cur ? q1 : q0;
-        int32_t* qn = cur ? q0 : q1;
+        __syncthreads();  // every thread has read `end` before the first append of this level
         auto visit = [&](int w) {
-            if (dist[w] < 0 && atomicCAS(&dist[w], -1, level + 1) == -1) qn[atomicAdd(&sh->qcount[cur ^ 1], 1)] = w;
+            if (dist[w] < 0 && atomicCAS(&dist[w], -1, level + 1) == -1) q[atomicAdd(&sh->qtail, 1)] = w;
         };
         // A row of a frontier node, walked by `width` cooperating threads (this one is number `me`): four entries per
         // trip, the loads of a trip issued before the first LDS compare-and-swap (past-the-end indices are clamped and
-        // their values dropped) — a walk that probes after every load runs at one L2 latency per neighbour.
+        // their values dropped) — a walk that probes after every load runs at one memory latency per neighbour.
         auto walk = [&](const int32_t* __restrict__ nbr, int b, int e, int me, int width) {
             for (int p0 = b + me; p0 < e; p0 += 4 * width) {
                 int w[4];
@@ -76,12 +81,12 @@ __device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __re
                 for (int u = 0; u < 4; ++u) w[u] = nbr[p0 + u * width < e ? p0 + u * width : e - 1];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (p0 + u * width < e) visit(w[u] - (int)n0);
+                    if (p0 + u * width < e) visit(w[u] - sub);
             }
         };
-        for (int i = tid; i < n; i += kBfsThreads) {
+        for (int i = begin + tid; i < end; i += kBfsThreads) {
             const int v = q[i];
-            const int64_t gv = n0 + v;
+            const int64_t gv = row0 + v;
             int ob = 0, oe = 0, ib = 0, ie = 0;
             if (mode != 2) {
                 ob = out_ptr[gv];
@@ -122,6 +127,7 @@ __device__ inline void bfs_block_queue(int32_t* __restrict__ dist, int32_t* __re
             walk(out_nbr, r.x, r.y, tid, kBfsThreads);
             walk(in_nbr, r.z, r.w, tid, kBfsThreads);
         }
+        begin = end;
     }
 }
 
@@ -204,17 +210,35 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     int mode, int32_t* __restrict__ dist_out, int lds_nodes) {
     __shared__ BfsShared sh;
     __shared__ BfsQueueShared shq;
-    extern __shared__ int32_t lds_dist[];  // [lds_nodes]: the levels of graphs that fit stay on chip until the end
+    extern __shared__ int32_t lds_dist[];  // [lds_nodes] ints: levels | queue | (cached CSR rows), as far as the graph fits
     const int j = blockIdx.x, tid = threadIdx.x;
     const int g = job_graph[j];
     const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
     const int ng = (int)(n1 - n0);
     int32_t* out = dist_out + dist_off[j];  // local node id -> level
     int32_t* dist = ng <= lds_nodes ? lds_dist : out;
-    const int qcap = lds_nodes / 3;  // queue mode: dist | queue 0 | queue 1, a third of the dynamic LDS each
-    const bool queued = ng <= qcap;
-    if (tid == 0) shq.qcount[0] = shq.qcount[1] = 0;
+    const bool queued = 2 * (int64_t)ng <= lds_nodes;  // dist | queue
+    // the graph's rows are one contiguous slice of each CSR half: [e0, e1) = [ptr[n0], ptr[n1])
+    const int e0 = out_ptr[n0], ne = out_ptr[n1] - e0;
+    const int sides = mode == 0 ? 2 : 1;
+    const bool cached = queued && ne > 0 && 2 * (int64_t)ng + (int64_t)sides * ((int64_t)ng + 1 + ne) <= lds_nodes;
+    if (tid == 0) shq.qtail = 0;
     for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
+    int32_t* l_out_ptr = lds_dist + 2 * ng;
+    int32_t* l_out_nbr = l_out_ptr + (mode != 2 ? ng + 1 : 0);
+    int32_t* l_in_ptr = l_out_nbr + (mode != 2 ? ne : 0);
+    int32_t* l_in_nbr = l_in_ptr + (mode != 1 ? ng + 1 : 0);
+    if (cached) {  // coalesced copies: row pointers relative to e0, neighbours as local ids
+        if (mode != 2) {
+            for (int v = tid; v <= ng; v += kBfsThreads) l_out_ptr[v] = out_ptr[n0 + v] - e0;
+            for (int p = tid; p < ne; p += kBfsThreads) l_out_nbr[p] = out_nbr[e0 + p] - (int32_t)n0;
+        }
+        if (mode != 1) {
+            const int ie0 = in_ptr[n0];  // = e0: both halves of a graph start at its first edge slot
+            for (int v = tid; v <= ng; v += kBfsThreads) l_in_ptr[v] = in_ptr[n0 + v] - ie0;
+            for (int p = tid; p < ne; p += kBfsThreads) l_in_nbr[p] = in_nbr[ie0 + p] - (int32_t)n0;
+        }
+    }
     __syncthreads();
     for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
         const int64_t s = src_idx[i];
@@ -222,10 +246,14 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
         if (!queued)
             dist[s - n0] = 0;
         else if (atomicCAS(&dist[s - n0], -1, 0) == -1)  // a source listed twice is queued once
-            lds_dist[qcap + atomicAdd(&shq.qcount[0], 1)] = (int32_t)(s - n0);
+            lds_dist[ng + atomicAdd(&shq.qtail, 1)] = (int32_t)(s - n0);
     }
-    if (queued)
-        bfs_block_queue(dist, lds_dist + qcap, lds_dist + 2 * qcap, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &shq);
+    // queue modes: the levels ARE in LDS (2 ng <= lds_nodes) — hand the LDS array itself over, not the LDS-or-global select,
+    // so that the compare-and-swaps on the levels compile to ds_cmpst instead of flat atomics
+    if (cached)
+        bfs_block_queue<true>(lds_dist, lds_dist + ng, n0, l_in_ptr, l_in_nbr, l_out_ptr, l_out_nbr, mode, &shq);
+    else if (queued)
+        bfs_block_queue<false>(lds_dist, lds_dist + ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &shq);
     else
         bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &sh);
     if (dist != out) {
@@ -403,7 +431,15 @@ extern "C" int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, 
     EVI_REQUIRE(mode >= 0 && mode <= 2, "evi_bfs_levels: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
     if (num_jobs == 0) return EVI_OK;
     EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels: null pointer");
-    constexpr int kLdsNodes = 12288;  // 48 KiB of dynamic LDS
+    // 136 KiB of dynamic LDS (+ 21 KiB static): levels + queue + the CSR rows of a CWQ-sized graph (3 000 nodes, 10 000 edges,
+    // both halves: 32 002 ints) stay on chip for the whole search; one workgroup per CU
+    constexpr int kLdsNodes = 34816;
+    static thread_local bool attr = false;
+    if (!attr) {
+        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bfs_levels), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kLdsNodes * (int)sizeof(int32_t)));
+        attr = true;
+    }
     hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), kLdsNodes * sizeof(int32_t),
                        reinterpret_cast<hipStream_t>(stream), job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr,
                        out_ptr, out_nbr, mode, dist_out, kLdsNodes);

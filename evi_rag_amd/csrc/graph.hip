@@ -25,6 +25,8 @@
 // rounding once to f32, which makes the f32 result independent of the summation order.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace evi {
 
 constexpr int kGraphThreads = 1024;
@@ -110,8 +112,8 @@ __device__ inline int wave_inclusive_scan(int v) {
     return v;
 }
 
-template <class Count>
-__device__ inline void block_exclusive_scan_fn(GraphShared& sh, Count cnt, int32_t* ptr, int64_t n0, int64_t n1, int base) {
+template <class Sh, class Count>
+__device__ inline void block_exclusive_scan_fn(Sh& sh, Count cnt, int32_t* ptr, int64_t n0, int64_t n1, int base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kGraphThreads / 64;
     int carry = base;
@@ -136,7 +138,8 @@ __device__ inline void block_exclusive_scan_fn(GraphShared& sh, Count cnt, int32
     __syncthreads();
 }
 
-__device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt, int32_t* ptr, int64_t n0,
+template <class Sh>
+__device__ inline void block_exclusive_scan(Sh& sh, const int32_t* cnt, int32_t* ptr, int64_t n0,
                                             int64_t n1, int base) {
     block_exclusive_scan_fn(sh, [&](int i) { return cnt[i]; }, ptr, n0, n1, base);
 }
@@ -144,7 +147,8 @@ __device__ inline void block_exclusive_scan(GraphShared& sh, const int32_t* cnt,
 // Counting-sort CSR of one graph.  cin / cout are the per-node counters, indexed by LOCAL node id: in
 // LDS when the graph's 2 * N_g counters fit the launch's dynamic LDS (ds_add_rtn instead of L2 atomics),
 // else in the global workspace.
-__device__ inline void csr_build(GraphShared& sh, const int64_t* __restrict__ edge_index, int64_t E, int64_t n0,
+template <class Sh>
+__device__ inline void csr_build(Sh& sh, const int64_t* __restrict__ edge_index, int64_t E, int64_t n0,
                                  int64_t n1, int64_t e0, int64_t e1, int32_t* cin, int32_t* cout,
                                  int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_nbr, int32_t* __restrict__ in_eid,
                                  int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_nbr,
@@ -195,6 +199,103 @@ __global__ __launch_bounds__(kGraphThreads) void k_graph_csr(
     else
         csr_build(sh, edge_index, E, n0, n1, e0, e1, cnt_in + n0, cnt_out + n0, in_ptr, in_nbr, in_eid, out_ptr, out_nbr,
                   out_eid);
+}
+
+// ---- CSR with the output staged in LDS: one workgroup per (graph, side) ---------------------------------------
+// The counting sort above scatters 4-byte entries over a graph's (nbr, eid) arrays.  With the arrays in global memory every
+// scattered store dirties a line that leaves the L2 partly filled: the memory-side write counter shows 6.5x (512 graphs per
+// batch, the working set of the concurrent workgroups exceeds the L2s) to 7.6x (32 graphs cut into 8 parts that run on
+// different XCDs, i.e. different L2s each holding partial lines of the same rows) the bytes of the arrays
+// (profiles/r03_pmc_graph.json: WRITE_SIZE 45 MB per batch of 32 graphs against 6 MB of CSR).  Here one side of one graph's
+// CSR — in-rows (keyed by target) or out-rows (keyed by source) — is built in LDS: the row counters AND the side's (nbr, eid)
+// arrays (up to 14 336 edges = 112 KiB), scattered into with ds atomics, then written to global memory once, coalesced.
+// One launch instead of three; each of the two sides reads the graph's edge list twice (the second pass hits the L2: both
+// sides of a graph are placed on the same XCD).  Graphs larger than the LDS budget take the global-memory build.
+constexpr int kCsrSideNodes = 8192;    // row counters: 32 KiB
+constexpr int kCsrSideEdges = 14336;   // staged (nbr, eid): 2 x 56 KiB
+struct CsrSideShared {
+    int scan[kGraphThreads / 64];
+};
+
+__global__ __launch_bounds__(kGraphThreads) void k_graph_csr_side(
+    const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int B, int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_nbr,
+    int32_t* __restrict__ in_eid, int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_nbr,
+    int32_t* __restrict__ out_eid, int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out) {
+    __shared__ CsrSideShared sh;
+    extern __shared__ int32_t lds[];  // cnt [kCsrSideNodes] | nbr [kCsrSideEdges] | eid [kCsrSideEdges]
+    // workgroup i runs on XCD i % 8: both sides of a graph get the same residue, so the second reader of the graph's edge
+    // list finds it in that XCD's L2
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int side = q & 1;
+    const int g = (q >> 1) * 8 + xcd;
+    if (g >= B) return;
+    const int tid = threadIdx.x;
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    const int64_t ne = e1 - e0;
+    if (ng > kCsrSideNodes || ne > kCsrSideEdges) {  // too large for LDS: side 0 builds both halves in global memory
+        if (side == 0)
+            csr_build(sh, edge_index, E, n0, n1, e0, e1, cnt_in + n0, cnt_out + n0, in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid);
+        return;
+    }
+    int32_t* cnt = lds;
+    int32_t* s_nbr = lds + kCsrSideNodes;
+    int32_t* s_eid = s_nbr + kCsrSideEdges;
+    const int64_t* key = edge_index + (side == 0 ? E : 0);  // in-rows are keyed by the target, out-rows by the source
+    const int64_t* oth = edge_index + (side == 0 ? 0 : E);
+    int32_t* ptr = side == 0 ? in_ptr : out_ptr;
+    int32_t* nbr = side == 0 ? in_nbr : out_nbr;
+    int32_t* eid = side == 0 ? in_eid : out_eid;
+    for (int v = tid; v < ng; v += kGraphThreads) cnt[v] = 0;
+    __syncthreads();
+    // pass 1: row sizes.  Four edges per trip, loads first (an index past the end re-reads the last edge and is dropped)
+    for (int64_t e = e0 + tid; e < e1; e += 4 * kGraphThreads) {
+        int64_t k[4], o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t ee = e + (int64_t)i * kGraphThreads < e1 ? e + (int64_t)i * kGraphThreads : e1 - 1;
+            k[i] = key[ee];
+            o[i] = oth[ee];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (e + (int64_t)i * kGraphThreads >= e1) continue;
+            if (k[i] < n0 || k[i] >= n1 || o[i] < n0 || o[i] >= n1) continue;  // validated upstream; never scatter outside
+            atomicAdd(&cnt[k[i] - n0], 1);
+        }
+    }
+    __syncthreads();
+    block_exclusive_scan_fn(sh, [&](int i) { return cnt[i]; }, ptr, n0, n1, (int)e0);
+    for (int v = tid; v < ng; v += kGraphThreads) cnt[v] = ptr[n0 + v] - (int)e0;  // cursors, relative to the graph's first slot
+    __syncthreads();
+    const int total = ptr[n1] - (int)e0;
+    // pass 2: scatter into LDS
+    for (int64_t e = e0 + tid; e < e1; e += 4 * kGraphThreads) {
+        int64_t k[4], o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t ee = e + (int64_t)i * kGraphThreads < e1 ? e + (int64_t)i * kGraphThreads : e1 - 1;
+            k[i] = key[ee];
+            o[i] = oth[ee];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t ee = e + (int64_t)i * kGraphThreads;
+            if (ee >= e1) continue;
+            if (k[i] < n0 || k[i] >= n1 || o[i] < n0 || o[i] >= n1) continue;
+            const int pos = atomicAdd(&cnt[k[i] - n0], 1);
+            s_nbr[pos] = (int32_t)o[i];
+            s_eid[pos] = (int32_t)ee;
+        }
+    }
+    __syncthreads();
+    // one coalesced pass out
+    for (int i = tid; i < total; i += kGraphThreads) {
+        nbr[e0 + i] = s_nbr[i];
+        eid[e0 + i] = s_eid[i];
+    }
 }
 
 // ---- CSR in P parts per graph (small batches) ------------------------------------------------------------
@@ -451,6 +552,132 @@ __global__ __launch_bounds__(256) void k_dde_round(const float* __restrict__ top
     }
 }
 
+// ---- DDE, one workgroup per graph: the whole feature block of the graph lives in LDS ---------------------------------
+// The node-parallel kernel above gathers 8 bytes of a neighbour's previous column out of its 40-byte ns row: at 512 graphs
+// per batch the ns array (61 MB) is far beyond the L2s, every gather pulls a whole line from memory, and the memory-side
+// counters show 3.7x the algorithmic bytes at 5.6 TB/s — HBM-bound on over-fetch (profiles/r03_pmc_graph.json).  Here a
+// graph's [N_g, C * S] block is built IN LDS — column 0 from the topic one-hot, every round reads column jin and writes
+// column jout of the same block (distinct columns: no ping-pong), rounds separated by workgroup barriers — and written to
+// global memory once, coalesced.  Memory traffic: the neighbour lists (once per round, the second round of a chain from the
+// L2), the row pointers, the topic rows in and the ns rows out.  Worth it when there are enough graphs to fill the chip
+// (one workgroup per graph); a graph whose block does not fit the LDS runs the same code on its global ns rows.
+constexpr int kDdeGraphLdsFloats = 36864;  // 144 KiB
+
+template <int C, class F>
+__device__ inline void dde_graph_rounds(F* __restrict__ st, int W, int S, int ng, int64_t n0, const int32_t* __restrict__ in_ptr,
+                                        const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr,
+                                        const int32_t* __restrict__ out_nbr, int rounds, int rev_rounds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ngpad = (ng + 63) / 64 * 64;
+    for (int step = 0; step < rounds + rev_rounds; ++step) {
+        const bool rev = step >= rounds;
+        const int j = rev ? step - rounds + 1 : step + 1;
+        const int jin = rev ? (j == 1 ? 0 : rounds + j - 1) : j - 1;
+        const int jout = rev ? rounds + j : j;
+        const int32_t* __restrict__ ptr = rev ? out_ptr : in_ptr;
+        const int32_t* __restrict__ nbr = rev ? out_nbr : in_nbr;
+        for (int v = tid; v < ngpad; v += kGraphThreads) {  // whole waves: the hub rows below are summed by all 64 lanes
+            const bool live = v < ng;
+            int b = 0, e = 0;
+            if (live) {
+                b = ptr[n0 + v];
+                e = ptr[n0 + v + 1];
+            }
+            const int deg = e - b;
+            const bool hub = deg > kHubDegree;
+            if (live && !hub) {
+                double acc[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = 0.0;
+                for (int p = b; p < e; p += 4) {  // four neighbours per trip, loads first (see k_dde_round)
+                    int u[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i] = nbr[p + i < e ? p + i : e - 1] - (int)n0;
+                    float x[4][C];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) x[i][c] = st[u[i] * W + c * S + jin];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (p + i < e) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c] += (double)x[i][c];
+                        }
+                }
+                const float cnt = deg > 0 ? (float)deg : 1.0f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) st[v * W + c * S + jout] = (float)acc[c] / cnt;
+            }
+            unsigned long long hubs = __ballot(hub);
+            while (hubs) {
+                const int l = __ffsll((long long)hubs) - 1;
+                hubs &= hubs - 1;
+                const int hb = __shfl(b, l, 64), he = __shfl(e, l, 64);
+                const int hv = v - lane + l;
+                double acc[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = 0.0;
+                for (int p = hb + lane; p < he; p += 256) {
+                    int u[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i] = nbr[p + 64 * i < he ? p + 64 * i : he - 1] - (int)n0;
+                    float x[4][C];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) x[i][c] = st[u[i] * W + c * S + jin];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (p + 64 * i < he) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c] += (double)x[i][c];
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+                if (lane == 0) {
+                    const float cnt = (float)(he - hb);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) st[hv * W + c * S + jout] = (float)acc[c] / cnt;
+                }
+            }
+        }
+        __syncthreads();  // column jout is complete before a later round reads it
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kGraphThreads) void k_dde_graph(const float* __restrict__ topic, int topic_stride, float* __restrict__ ns,
+                                                             int S, const int64_t* __restrict__ node_ptr,
+                                                             const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
+                                                             const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
+                                                             int rounds, int rev_rounds) {
+    extern __shared__ float lds_ns[];  // [N_g][C * S]
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    const int W = C * S;
+    if ((int64_t)ng * W <= kDdeGraphLdsFloats) {
+        for (int v = tid; v < ng; v += kGraphThreads)
+#pragma unroll
+            for (int c = 0; c < C; ++c) lds_ns[v * W + c * S] = topic[(n0 + v) * topic_stride + c];
+        __syncthreads();
+        dde_graph_rounds<C>(lds_ns, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
+        float* __restrict__ dst = ns + n0 * W;
+        for (int i = tid; i < ng * W; i += kGraphThreads) dst[i] = lds_ns[i];  // one coalesced pass out
+    } else {  // the block does not fit: the same rounds on the graph's global ns rows
+        float* st = ns + n0 * W;
+        for (int v = tid; v < ng; v += kGraphThreads)
+#pragma unroll
+            for (int c = 0; c < C; ++c) st[v * W + c * S] = topic[(n0 + v) * topic_stride + c];
+        __syncthreads();
+        dde_graph_rounds<C>(st, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
+    }
+}
+
 }  // namespace evi
 
 using namespace evi;
@@ -531,6 +758,28 @@ extern "C" int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int P = csr_parts(B);
     const size_t lds = 2 * kCsrLdsNodes * sizeof(int32_t);
+    // default: the LDS-staged build, one workgroup per (graph, side) in ONE launch; EVI_CSR_BUILD=parts selects the older
+    // global-scatter kernels (A/B runs, and the path graphs beyond the LDS budget take inside the new kernel anyway)
+    static const bool staged = [] {
+        const char* e = getenv("EVI_CSR_BUILD");
+        return !(e && e[0] == 'p');
+    }();
+    if (staged && !getenv("EVI_CSR_PARTS")) {
+        static thread_local bool attr = false;
+        const size_t side_lds = (size_t)(kCsrSideNodes + 2 * kCsrSideEdges) * sizeof(int32_t);
+        if (!attr) {
+            EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_graph_csr_side),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)side_lds));
+            attr = true;
+        }
+        int32_t* cnt_in = static_cast<int32_t*>(workspace);
+        int32_t* cnt_out = cnt_in + (N > 0 ? N : 1);
+        const unsigned grid = (unsigned)((B + 7) / 8 * 16);
+        hipLaunchKernelGGL(k_graph_csr_side, dim3(grid), dim3(kGraphThreads), side_lds, st, edge_index, E, node_ptr, edge_ptr, B,
+                           in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid, cnt_in, cnt_out);
+        EVI_LAUNCH_CHECK();
+        return EVI_OK;
+    }
     if (P == 1) {
         int32_t* cnt_in = static_cast<int32_t*>(workspace);
         int32_t* cnt_out = cnt_in + (N > 0 ? N : 1);
@@ -546,6 +795,43 @@ extern "C" int evi_graph_csr(const int64_t* edge_index, int64_t E, const int64_t
         hipLaunchKernelGGL(k_csr_part_fill, dim3(B * P), dim3(kGraphThreads), lds, st, edge_index, E, node_ptr, edge_ptr, Nn, P,
                            (const int32_t*)part, in_nbr, in_eid, out_nbr, out_eid, kCsrLdsNodes);
     }
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+// graphs per batch from which DDE runs one workgroup per graph (k_dde_graph) instead of node-parallel over the batch
+// (k_dde_round); EVI_DDE_MODE=graph | nodes forces either
+static int dde_graph_min_batch() {  // read per call (a getenv is nothing next to a launch): tests switch it in-process
+    const char* e = getenv("EVI_DDE_MODE");
+    if (e && e[0] == 'g') return 1;
+    if (e && e[0] == 'n') return 0x7FFFFFFF;
+    return 96;
+}
+
+extern "C" int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
+                                   const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr,
+                                   const int32_t* out_nbr, int rounds, int rev_rounds, float* node_struct, void* stream);
+
+extern "C" int evi_dde_node_struct_graphs(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
+                                          const int64_t* node_ptr, int B, const int32_t* in_ptr, const int32_t* in_nbr,
+                                          const int32_t* out_ptr, const int32_t* out_nbr, int rounds, int rev_rounds,
+                                          float* node_struct, void* stream) {
+    if (node_ptr == nullptr || B < dde_graph_min_batch() || num_topics != 2 || N == 0 || rounds < 0 || rounds > 4 || rev_rounds < 0 ||
+        rev_rounds > 4)
+        return evi_dde_node_struct(topic_one_hot, topic_stride, num_topics, N, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds,
+                                   node_struct, stream);  // (also the one place the argument checks live)
+    EVI_REQUIRE(topic_stride >= num_topics, "evi_dde_node_struct: topic_one_hot feature dim %d < num_topics=%d", topic_stride, num_topics);
+    EVI_REQUIRE(topic_one_hot && in_ptr && out_ptr && node_struct, "evi_dde_node_struct: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static thread_local bool attr = false;
+    if (!attr) {
+        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dde_graph<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kDdeGraphLdsFloats * (int)sizeof(float)));
+        attr = true;
+    }
+    const int S = 1 + rounds + rev_rounds;
+    hipLaunchKernelGGL(k_dde_graph<2>, dim3((unsigned)B), dim3(kGraphThreads), kDdeGraphLdsFloats * sizeof(float), st, topic_one_hot,
+                       topic_stride, node_struct, S, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

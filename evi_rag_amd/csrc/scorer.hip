@@ -157,12 +157,17 @@ __device__ inline void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 __device__ inline float hsum4(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 // one lane's float4 as bf16 hi / lo quads into the two planes of a [rows, D] operand (hi plane first, lo plane behind it)
 __device__ inline void st4_planes(float* base, int64_t rows, int64_t row, int D, int d, f4 v) {
+    // no contraction here: `v` is a product in the caller, and fusing it into `v - hi` (fp-contract=fast is HIP's default) would
+    // take lo from the UNROUNDED product — more exact, but not the bits the register-staged GEMM forms from the stored f32 row
+#pragma clang fp contract(off)
     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
     bf4 h, l;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        h[c] = (__bf16)v[c];
-        l[c] = (__bf16)(v[c] - (float)h[c]);
+        float x = v[c];
+        asm volatile("" : "+v"(x));  // the ROUNDED f32 value, opaque to the optimiser: belt and braces with the pragma
+        h[c] = (__bf16)x;
+        l[c] = (__bf16)(x - (float)h[c]);
     }
     __bf16* hi = reinterpret_cast<__bf16*>(base);
     __bf16* lo = hi + rows * D;
@@ -996,8 +1001,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                             I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
                             evi_graph_csr_workspace_bytes(N), stream)))
         return rc;
-    if ((rc = evi_dde_node_struct(b->topic_one_hot, b->topic_stride, 2, N, I32(L.in_ptr), I32(L.in_nbr),
-                                  I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
+    if ((rc = evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
+                                         I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
         return rc;
 
     // 3-5. factored state_net.0 (see the header), per edge chunk

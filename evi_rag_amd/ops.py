@@ -635,9 +635,9 @@ def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: Gr
     S = 1 + int(num_rounds) + int(num_reverse_rounds)
     ns = torch.empty((N, num_topics * S), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    _lib.check(lib.evi_dde_node_struct(_ptr(t), t.size(1), int(num_topics), N, csr.in_ptr.data_ptr(),
-                                       csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
-                                       int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))
+    _lib.check(lib.evi_dde_node_struct_graphs(_ptr(t), t.size(1), int(num_topics), N, _ptr(ptr), B, csr.in_ptr.data_ptr(),
+                                              csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
+                                              int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))
     return ns
 
 

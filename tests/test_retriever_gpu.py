@@ -434,7 +434,7 @@ def test_out_of_range_relation_id_on_the_hint_path_is_reported_not_read_out_of_b
     model.check_deferred()  # the flag was reset
 
 
-@pytest.mark.parametrize("parts", [1, 2, 4, 8])
+@pytest.mark.parametrize("parts", [0, 1, 2, 4, 8])
 def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
     """The CSR is built from P edge-list parts per graph at small batches (B x P workgroups, LDS counters) and in one piece
     at large ones: every P must give the same rows (as multisets; the order inside a row is unspecified), the same DDE
@@ -442,9 +442,12 @@ def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
     than the parts' LDS counters hold (built in one piece inside the scan kernel)."""
     from evi_rag_amd import _lib, ops
 
-    monkeypatch.setenv("EVI_CSR_PARTS", str(parts))
+    if parts:
+        monkeypatch.setenv("EVI_CSR_PARTS", str(parts))
+    else:  # the default build: one workgroup per (graph, side), rows staged in LDS and written out coalesced; the 20 000-edge
+        monkeypatch.delenv("EVI_CSR_PARTS", raising=False)  # and the 9 000-node graphs exceed its LDS budget (global build inside it)
     rng = np.random.default_rng(5)
-    sizes = [(40, 90), (3000, 10000), (1, 0), (7000, 9000), (64, 4000), (500, 1)]
+    sizes = [(40, 90), (3000, 10000), (1, 0), (7000, 9000), (64, 4000), (500, 1), (300, 20000), (9000, 12000), (8192, 14336)]
     ei, ptr, eptr = [], [0], [0]
     for n, e in sizes:
         s = rng.integers(0, n, e)
@@ -472,8 +475,15 @@ def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
     seeds = np.asarray([ptr[g] + (0 if n < 3 else 2) for g, (n, _) in enumerate(sizes)])
     topic[seeds] = [1.0, 0.0]
     for rounds in [(2, 2), (0, 3), (4, 1), (0, 0)]:
-        ns = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds).cpu().numpy()
-        np.testing.assert_allclose(ns, ograph.node_structure_features(topic, ei, *rounds), rtol=0, atol=2e-6)
+        # both forms of the kernel: node-parallel over the batch, and one workgroup per graph with the graph's feature block in
+        # LDS (the 9 000-node graph's block does not fit and runs on its global rows) — equal bit for bit (f64 row sums)
+        monkeypatch.setenv("EVI_DDE_MODE", "nodes")
+        ns = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds)
+        monkeypatch.setenv("EVI_DDE_MODE", "graph")
+        ns_g = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds)
+        monkeypatch.delenv("EVI_DDE_MODE")
+        assert torch.equal(ns, ns_g), rounds
+        np.testing.assert_allclose(ns.cpu().numpy(), ograph.node_structure_features(topic, ei, *rounds), rtol=0, atol=2e-6)
     # multi-source BFS per graph vs the oracle (queue mode for the small graphs, scan mode for the 7000-node one)
     lib = _lib.load()
     jg = torch.arange(B, dtype=torch.int32, device=dev)
