@@ -461,6 +461,41 @@ def _random_bert(dev, D):
     return model, layers
 
 
+class _Fp8Linear(torch.nn.Module):
+    """nn.Linear on PyTorch-ROCm's fp8 GEMM (torch._scaled_mm -> hipBLASLt): OCP e4m3 operands with ONE scale per tensor — the
+    weight quantised once, the activation per call from its own amax (a device scalar: nothing is read back) — bf16 result,
+    bias added after.  BASELINE configs[4] "fp8 encode": the encoder forward stays PyTorch's (north_star), so this is a probe of
+    what the framework offers on gfx950, not a kernel of ours."""
+
+    def __init__(self, lin: torch.nn.Linear):
+        super().__init__()
+        w = lin.weight.detach().float()
+        self.scale_w = (w.abs().amax() / 448.0).clamp(min=1e-12)
+        self.w8 = (w / self.scale_w).to(torch.float8_e4m3fn)  # [out, in] row-major: its transpose is the column-major B operand
+        self.bias = None if lin.bias is None else lin.bias.detach()
+
+    def forward(self, x):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        sx = (x2.abs().amax().float() / 448.0).clamp(min=1e-12)
+        x8 = (x2.float() / sx).to(torch.float8_e4m3fn)
+        y = torch._scaled_mm(x8, self.w8.t(), scale_a=sx, scale_b=self.scale_w, out_dtype=torch.bfloat16)
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype)
+        return y.reshape(*shp[:-1], y.shape[-1])
+
+
+def _swap_linears_fp8(module):
+    n = 0
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.Linear) and child.in_features % 16 == 0 and child.out_features % 16 == 0:
+            setattr(module, name, _Fp8Linear(child))
+            n += 1
+        else:
+            n += _swap_linears_fp8(child)
+    return n
+
+
 class _LengthTokenizer:
     """Stand-in tokenizer (no vocabulary offline): text "i" has lengths[i] random token ids; a batch is padded to its longest
     text like the reference's `padding=True` (scripts/text_encode_utils.py:52-57)."""
@@ -543,6 +578,49 @@ def bench_encode(dev, D, *, texts=4096, batch_size=64, iters=3, autocast=None, f
                             "overlap_at_k_encoder_only (bf16 encode, f32 table)": ov(i_mid, i_ref),
                             "max_abs_embedding_diff": float((low - ref).abs().max().item()),
                             "note": "random-init encoder: embeddings nearly collinear, overlap is a lower bound"}
+        # configs[4] "fp8 encode": every nn.Linear of the encoder layers on torch._scaled_mm (e4m3 x e4m3, per-tensor scales,
+        # bf16 out), the rest under bf16 autocast as above.  Eager launches (the per-call activation amax + quantisation are
+        # extra kernels).  If this PyTorch build has no usable fp8 GEMM on gfx950 the error is recorded and J2 stays bf16.
+        try:
+            import copy as _copy
+
+            m8 = _copy.deepcopy(model)
+            swapped = _swap_linears_fp8(m8.encoder)
+            enc8 = TextEncoder.from_components(_LengthTokenizer(lengths), m8, str(dev), fp16=False)
+            enc8.autocast, enc8.use_graphs = torch.bfloat16, False
+            out8 = enc8.encode_to_device(names[: 4 * batch_size], batch_size)
+            torch.cuda.synchronize(dev)
+            best8 = float("inf")
+            for _ in range(iters):
+                t0 = time.perf_counter()
+                out8 = enc8.encode_to_device(names, batch_size)
+                torch.cuda.synchronize(dev)
+                best8 = min(best8, time.perf_counter() - t0)
+            low8 = ops.normalize_embeddings(out8)
+            _, i_8 = ops.cosine_topk(low8[:32].contiguous(), low8, k)
+            enc8.use_graphs = True
+            try:
+                enc8.encode_to_device(names, batch_size)
+                torch.cuda.synchronize(dev)
+                best8g = float("inf")
+                for _ in range(iters):
+                    t0 = time.perf_counter()
+                    enc8.encode_to_device(names, batch_size)
+                    torch.cuda.synchronize(dev)
+                    best8g = min(best8g, time.perf_counter() - t0)
+                graphed = {"texts_per_s": texts / best8g, "graphs_captured": len(enc8.__dict__.get("_graphs", {})), "use_graphs_after": bool(enc8.use_graphs)}
+            except Exception as exc:  # noqa: BLE001
+                graphed = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            res["fp8_linear"] = {"what": "encoder nn.Linear layers on torch._scaled_mm (OCP e4m3 operands, per-tensor scales, bf16 result), "
+                                         "attention / LayerNorm / GELU under bf16 autocast",
+                                 "linears_swapped": swapped, "texts_per_s": texts / best8, "ms_per_batch": best8 / (texts / batch_size) * 1e3,
+                                 "speedup_over_bf16_autocast_eager": best / best8, "graph_replay": graphed,
+                                 "overlap_at_k_encoder_only (fp8 linears, f32 table)": ov(i_8, i_ref),
+                                 "max_abs_embedding_diff_vs_f32": float((low8 - ref).abs().max().item())}
+            del m8, enc8
+        except Exception as exc:  # noqa: BLE001 - the probe's outcome IS the error when fp8 GEMMs are not available
+            res["fp8_linear"] = {"error": f"{type(exc).__name__}: {exc}"[:600]}
+        torch.cuda.empty_cache()
     return res
 
 
@@ -1268,6 +1346,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
                          "what": "evi_cosine_topk_gemm: one GEMM-shaped pass selects candidates (split-bf16), the scan's arithmetic "
                                  "re-scores them; proof flag read back once per call",
                          "executed_TFLOPs_lower_bound": 2.0 * many_query * (row_end - row_begin) * D / t_gemm / 1e12},
+                "selection_products": ops.cosine_topk_gemm.last_products,
                 "identical_ids": bool(torch.equal(r_scan[1], r_gemm[1])), "identical_scores": bool(torch.equal(r_scan[0], r_gemm[0])),
                 "planted_row_in_top10": found}
         del mq, r_scan, r_gemm

@@ -112,8 +112,6 @@ _SIGNATURES = {
     "evi_gather_rows": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P, _P]),
     "evi_edge_batch": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P]),
     "evi_qa_edge_mask": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P]),
-    "evi_split_rows_bf16": (c_int, [_P, c_int64, c_int, c_int64, c_int, _P, _P, _P]),
-    "evi_gemm_nt_bf16x3_presplit": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int, _P, c_int, _P, c_int64, _P]),
     "evi_graph_csr_workspace_bytes": (c_size_t, [c_int64]),
     "evi_graph_csr": (c_int, [_P, c_int64, _P, _P, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "evi_dde_node_struct": (c_int, [_P, c_int, c_int, c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P]),

@@ -18,6 +18,8 @@
 // (N_g * 4 B per level).  Integer work, L2-latency-bound.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace evi {
 
 constexpr int kBfsThreads = 1024;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
     const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ in_ptr,
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
-    int mode, int32_t* __restrict__ dist_out, int lds_nodes) {
+    int mode, int32_t* __restrict__ dist_out, int lds_nodes, int cache_rows) {
     __shared__ BfsShared sh;
     __shared__ BfsQueueShared shq;
     extern __shared__ int32_t lds_dist[];  // [lds_nodes] ints: levels | queue | (cached CSR rows), as far as the graph fits
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     // the graph's rows are one contiguous slice of each CSR half: [e0, e1) = [ptr[n0], ptr[n1])
     const int e0 = out_ptr[n0], ne = out_ptr[n1] - e0;
     const int sides = mode == 0 ? 2 : 1;
-    const bool cached = queued && ne > 0 && 2 * (int64_t)ng + (int64_t)sides * ((int64_t)ng + 1 + ne) <= lds_nodes;
+    const bool cached = cache_rows && queued && ne > 0 && 2 * (int64_t)ng + (int64_t)sides * ((int64_t)ng + 1 + ne) <= lds_nodes;
     if (tid == 0) shq.qtail = 0;
     for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
     int32_t* l_out_ptr = lds_dist + 2 * ng;
@@ -229,14 +231,27 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     int32_t* l_in_ptr = l_out_nbr + (mode != 2 ? ne : 0);
     int32_t* l_in_nbr = l_in_ptr + (mode != 1 ? ng + 1 : 0);
     if (cached) {  // coalesced copies: row pointers relative to e0, neighbours as local ids
+        // eight entries per thread per trip, every load of a trip issued before the first LDS store (an index past the end
+        // re-reads the last entry): the copy of a CWQ graph's two halves is ~26 000 ints = 26 per thread — one entry per trip
+        // would be 26 dependent memory latencies in front of the search
+        auto copy = [&](const int32_t* __restrict__ src, int32_t* dst, int n, int sub) {
+            for (int i0 = tid; i0 < n; i0 += 8 * kBfsThreads) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * kBfsThreads < n ? i0 + u * kBfsThreads : n - 1];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * kBfsThreads < n) dst[i0 + u * kBfsThreads] = v[u] - sub;
+            }
+        };
         if (mode != 2) {
-            for (int v = tid; v <= ng; v += kBfsThreads) l_out_ptr[v] = out_ptr[n0 + v] - e0;
-            for (int p = tid; p < ne; p += kBfsThreads) l_out_nbr[p] = out_nbr[e0 + p] - (int32_t)n0;
+            copy(out_ptr + n0, l_out_ptr, ng + 1, e0);
+            copy(out_nbr + e0, l_out_nbr, ne, (int)n0);
         }
         if (mode != 1) {
             const int ie0 = in_ptr[n0];  // = e0: both halves of a graph start at its first edge slot
-            for (int v = tid; v <= ng; v += kBfsThreads) l_in_ptr[v] = in_ptr[n0 + v] - ie0;
-            for (int p = tid; p < ne; p += kBfsThreads) l_in_nbr[p] = in_nbr[ie0 + p] - (int32_t)n0;
+            copy(in_ptr + n0, l_in_ptr, ng + 1, ie0);
+            copy(in_nbr + ie0, l_in_nbr, ne, (int)n0);
         }
     }
     __syncthreads();
@@ -431,18 +446,25 @@ extern "C" int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, 
     EVI_REQUIRE(mode >= 0 && mode <= 2, "evi_bfs_levels: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
     if (num_jobs == 0) return EVI_OK;
     EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels: null pointer");
-    // 136 KiB of dynamic LDS (+ 21 KiB static): levels + queue + the CSR rows of a CWQ-sized graph (3 000 nodes, 10 000 edges,
-    // both halves: 32 002 ints) stay on chip for the whole search; one workgroup per CU
-    constexpr int kLdsNodes = 34816;
+    // Two launch shapes.  LATENCY (a search per CU or fewer: num_jobs <= 256, the reference's batch of 32 graphs with its ~150
+    // seed / answer jobs): 136 KiB of dynamic LDS (+ 21 KiB static) hold the levels, the queue AND the CSR rows of a CWQ-sized
+    // graph (3 000 nodes, 10 000 edges, both halves: 32 002 ints) for the whole search, one workgroup per CU.  THROUGHPUT (more
+    // jobs than CUs): 48 KiB, three workgroups per CU hide each other's row gathers, rows read from the L2 — caching them would
+    // cost two thirds of the resident searches (measured at 512 jobs: 70 us uncached x 3 per CU against 87 us cached x 1).
+    // EVI_BFS_CACHE=0 / 1 forces either.
+    constexpr int kLdsBig = 34816, kLdsSmall = 12288;
+    bool big = num_jobs <= 256;
+    if (const char* e = getenv("EVI_BFS_CACHE")) big = e[0] == '1';
+    const int lds_nodes = big ? kLdsBig : kLdsSmall;
     static thread_local bool attr = false;
     if (!attr) {
         EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bfs_levels), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          kLdsNodes * (int)sizeof(int32_t)));
+                                          kLdsBig * (int)sizeof(int32_t)));
         attr = true;
     }
-    hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), kLdsNodes * sizeof(int32_t),
+    hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), lds_nodes * sizeof(int32_t),
                        reinterpret_cast<hipStream_t>(stream), job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr,
-                       out_ptr, out_nbr, mode, dist_out, kLdsNodes);
+                       out_ptr, out_nbr, mode, dist_out, lds_nodes, big ? 1 : 0);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

@@ -92,10 +92,6 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, i
 // C = A W^T with W already split (plain store epilogue)
 int launch_gemm_bf16_presplit(const void* A, int a_f16, int single, int64_t M, int K, int64_t lda, const void* wsplit, int N,
                               float* C, int64_t ldc, hipStream_t st);
-// Split-bf16 GEMM on pre-split bf16 hi / lo planes of BOTH operands ([rows, Kp], Kp % 32 == 0), LDS-DMA staging (gemm_ps.hip)
-int launch_gemm_ps_bf16x3(const void* Ahi, const void* Alo, int64_t M, int Kp, const void* Whi, const void* Wlo, int N,
-                          const float* bias, int act, float* C, int64_t ldc, hipStream_t st);
-int split_rows_bf16x3(const float* x, int64_t rows, int K, int64_t ld, int Kp, void* hi, void* lo, hipStream_t st);
 // Split-bf16 variant (gemm_bf16x3.hip); wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes.
 size_t gemm_bf16x3_workspace_bytes(int N, int K);
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,

@@ -143,9 +143,6 @@ struct EdgeFeatArgs {
     float* RCX;  // [e_count, D]  r_ctx
     float* XS;   // [(dir_fwd + dir_bwd) * e_count, D]  struct context per direction
     float* aux;  // [(dir_fwd + dir_bwd) * e_count, 2]  (nav gate, -||translation error||)
-    // k_edge_features<C4, true> (evaluation, D % 32 == 0): P / RCX / XS are written as the bf16 hi / lo planes the pre-split
-    // GEMM reads by LDS-DMA (gemm_ps.hip) — [rows, D] bf16 hi at the buffer's start, [rows, D] bf16 lo right behind it: the
-    // same bytes as the f32 rows, the same hi = bf16(x), lo = bf16(x - hi) the register-staged GEMM forms, so the same bits out
 };
 
 // Lane -> feature map of the per-edge kernels: lane owns the float4 chunks d = 4 * lane + 256 * i, i < C4 = ceil(D / 256)
@@ -155,27 +152,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ inline f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ inline void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 __device__ inline float hsum4(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-// one lane's float4 as bf16 hi / lo quads into the two planes of a [rows, D] operand (hi plane first, lo plane behind it)
-__device__ inline void st4_planes(float* base, int64_t rows, int64_t row, int D, int d, f4 v) {
-    // no contraction here: `v` is a product in the caller, and fusing it into `v - hi` (fp-contract=fast is HIP's default) would
-    // take lo from the UNROUNDED product — more exact, but not the bits the register-staged GEMM forms from the stored f32 row
-#pragma clang fp contract(off)
-    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-    bf4 h, l;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float x = v[c];
-        asm volatile("" : "+v"(x));  // the ROUNDED f32 value, opaque to the optimiser: belt and braces with the pragma
-        h[c] = (__bf16)x;
-        l[c] = (__bf16)(x - (float)h[c]);
-    }
-    __bf16* hi = reinterpret_cast<__bf16*>(base);
-    __bf16* lo = hi + rows * D;
-    *reinterpret_cast<bf4*>(hi + row * D + d) = h;
-    *reinterpret_cast<bf4*>(lo + row * D + d) = l;
-}
-
-template <int C4, bool PLN = false>
+template <int C4>
 __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
     extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
@@ -290,15 +267,13 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             const float nav = sigmoidf_(wsum(gacc) + gate_b);
             const int64_t row = (int64_t)out_row * a.e_count + le;
             float* xs = a.XS + row * D;
-            const int64_t xs_rows = (int64_t)(a.dir_fwd + a.dir_bwd) * a.e_count;
             float dsq = 0.f;
 #pragma unroll
             for (int i = 0; i < C4; ++i) {
                 const int d = 4 * lane + 256 * i;
                 if (d < D) {
                     const f4 err = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
-                    if (PLN) st4_planes(a.XS, xs_rows, row, D, d, sv[i]);
-                    else st4(xs + d, sv[i]);
+                    st4(xs + d, sv[i]);
                     dsq += hsum4(err * err);
                 }
             }
@@ -315,13 +290,8 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
         for (int i = 0; i < C4; ++i) {
             const int d = 4 * lane + 256 * i;
             if (d < D) {
-                if (PLN) {
-                    st4_planes(a.P, a.e_count, le, D, d, h[i] * rc[i] * t[i]);
-                    st4_planes(a.RCX, a.e_count, le, D, d, rc[i]);
-                } else {
-                    st4(pp + d, h[i] * rc[i] * t[i]);
-                    st4(rx + d, rc[i]);
-                }
+                st4(pp + d, h[i] * rc[i] * t[i]);
+                st4(rx + d, rc[i]);
             }
         }
     }
@@ -524,15 +494,6 @@ namespace evi {
 static bool use_f32_gemm() {
     const char* v = getenv("EVI_SCORER_GEMM");
     return v && v[0] == 'f';
-}
-
-// EVI_SCORER_GEMM_PS=0 keeps the evaluation forward on the register-staged GEMM (A/B runs; default: the pre-split kernel)
-static bool use_gemm_ps() {
-    static const bool v = [] {
-        const char* e = getenv("EVI_SCORER_GEMM_PS");
-        return !(e && e[0] == '0');
-    }();
-    return v;
 }
 
 // EviRetrieverBatch.matmul_precision of the call in flight on this thread: 1 = the large GEMMs multiply ONE bf16 product
@@ -868,6 +829,20 @@ static int colsum_into(const float* X, int64_t rows, int cols, float* out, int a
     return EVI_OK;
 }
 
+// dst[q][0..W) += column sums of X [rows, Q * W], columns grouped into Q vectors of W (two ordered stages, two launches)
+static int colsum_into_multi(const float* X, int64_t rows, int Q, int W, float* const* dst, const BwdLayout& L, char* ws, hipStream_t st) {
+    if (rows <= 0) return EVI_OK;
+    float* part = reinterpret_cast<float*>(ws + L.colpart);
+    const int cols = Q * W;
+    const int nb = (int)((rows + kColsumRows - 1) / kColsumRows);
+    ReduceDst d{};
+    for (int q = 0; q < Q; ++q) d.p[q] = dst[q];
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part);
+    hipLaunchKernelGGL(k_reduce_partials_multi, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, nb, Q, W, d);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
 // out[s][:] = sum of the rows of X in segment s (k_segment_rowsum); long segments are cut into slices summed in order afterwards
 static int segment_rowsum_into(const float* X, int D, const int64_t* ptr, const int64_t* perm, int64_t S, int64_t rows_total,
                                float* out, const BwdLayout& L, char* ws, hipStream_t st) {
@@ -1031,8 +1006,20 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     char* bws = nullptr;
     auto G = [&](const float* p) { return const_cast<float*>(p); };  // gradient buffers live in a weights-shaped struct
     auto BF = [&](size_t off) { return reinterpret_cast<float*>(bws + off); };
+    ZeroTable ztab{};  // buffers to clear: collected, then cleared by ONE launch (flush_zero) before anything accumulates into them
     auto zero = [&](float* p, int64_t n) {
-        if (n > 0) hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st, p, n);
+        if (n <= 0) return;
+        if (ztab.count == kZeroMax) {
+            hipLaunchKernelGGL(k_zero_multi, dim3(64, (unsigned)ztab.count), dim3(256), 0, st, ztab);
+            ztab.count = 0;
+        }
+        ztab.p[ztab.count] = p;
+        ztab.n[ztab.count] = n;
+        ++ztab.count;
+    };
+    auto flush_zero = [&]() {
+        if (ztab.count > 0) hipLaunchKernelGGL(k_zero_multi, dim3(64, (unsigned)ztab.count), dim3(256), 0, st, ztab);
+        ztab.count = 0;
     };
     auto transpose = [&](const float* src, int R_, int C_, float* dst) {  // dst [C_, R_] = src[R_, C_]^T
         hipLaunchKernelGGL(k_transpose_pad, dim3((unsigned)((R_ + 31) / 32), (unsigned)((C_ + 31) / 32)), dim3(256), 0, st, src,
@@ -1051,6 +1038,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         zero(G(g->state4_w), (int64_t)H * H); zero(G(g->state4_b), H); zero(G(g->score_w), H); zero(G(g->score_b), 1);
         zero(BF(BL.gWa), (int64_t)H * D); zero(BF(BL.gWb), (int64_t)H * D); zero(BF(BL.gWc), (int64_t)H * D); zero(BF(BL.gwd), H);
         zero(BF(BL.ysum), H); zero(BF(BL.ssum), 1);
+        flush_zero();
         transpose(wa, H, D, BF(BL.WaT));
         transpose(wb, H, D, BF(BL.WbT));
         transpose(wc, H, D, BF(BL.WcT));
@@ -1112,47 +1100,25 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         a.aux = pAux;
         int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
         if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS: 32 waves per CU hide the gather latency
-        // Evaluation with prepared weight planes: the edge kernel writes the GEMM operands as bf16 hi / lo planes (same bytes as
-        // the f32 rows) and the three products run on the pre-split kernel, which moves them global -> LDS by LDS-DMA with no
-        // conversion work (gemm_ps.hip: +4-5 % on these shapes, same bits).  Training keeps the f32 rows: the backward replays them.
-        const bool ps = !saved && !bw && prep && !use_f32_gemm() && t_gemm_single == 0 && D % 32 == 0 && use_gemm_ps();
         if (!replay) {
         const int tok = timing_begin(kTimeEdge, st);
         EVI_DPL_DISPATCH(dpl_d, {
-            if (ps) {
-                static thread_local bool attr_p = false;
-                if (!attr_p) {
-                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL, true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr_p = true;
-                }
-                hipLaunchKernelGGL((k_edge_features<DPL, true>), dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
-            } else {
-                static thread_local bool attr = false;
-                if (!attr) {
-                    EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr = true;
-                }
-                hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
+            static thread_local bool attr = false;
+            if (!attr) {
+                EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_features<DPL>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr = true;
             }
+            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
-        if (ps) {
-            auto ps_gemm = [&](const float* planes_base, int64_t rows, size_t woff, const float* bias, float* C) {
-                const __bf16* ahi = reinterpret_cast<const __bf16*>(planes_base);
-                const char* wp = prep + woff;  // k_split_weight's layout: hi [H, D] bf16, lo behind it (256-byte aligned)
-                return launch_gemm_ps_bf16x3(ahi, ahi + rows * D, rows, D, wp, wp + align_up((size_t)H * D * 2, 256), H, bias, 0, C, H, st);
-            };
-            if ((rc = ps_gemm(pP, ec, PL.p_wa, nullptr, pPA))) return rc;
-            if ((rc = ps_gemm(pRCX, ec, PL.p_wc, nullptr, pRC))) return rc;
-            if ((rc = ps_gemm(pXS, M, PL.p_wb, w->state0_b, pSB))) return rc;
-        } else {
+        // (r03: writing P / RCX / XS as bf16 hi / lo planes and multiplying them on a pre-split LDS-DMA GEMM was wired in here,
+        // bit-identical, and measured with rocprofv3 on this batch: 288.8 us per launch against 285.0 us for this kernel, the edge
+        // kernel 344 against 330 us — no gain inside the pipeline, so that kernel and its entry points were removed)
         if ((rc = scorer_gemm(pP, ec, D, D, wa, H, D, nullptr, 0, pPA, H, wsplit, st, planes(PL.p_wa)))) return rc;
         if ((rc = scorer_gemm(pRCX, ec, D, D, wc, H, D, nullptr, 0, pRC, H, wsplit, st, planes(PL.p_wc)))) return rc;
         if ((rc = scorer_gemm(pXS, M, D, D, wb, H, D, w->state0_b, 0, pSB, H, wsplit, st, planes(PL.p_wb)))) return rc;
-        }
         }
         CombineArgs c;
         c.edge_index = b->edge_index;
@@ -1202,12 +1168,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         EVI_LAUNCH_CHECK();
         {   // column partials: [gridC][5][H] then [gridC] — reduce each of the five vectors and S (accumulating over chunks)
             float* dst5[5] = {G(g->state_ln_w), G(g->state_ln_b), BF(BL.ysum), BF(BL.gwd), G(g->state0_b)};
-            // the partial rows interleave the five vectors: reduce them as one [gridC][5H] table into a scratch row first
-            float* tmp = BF(BL.colpart) + ((BL.gridC + kColsumRows - 1) / kColsumRows + 1) * 5 * H;  // behind colsum_into's scratch
-            if ((rc = colsum_into(BF(BL.partC), BL.gridC, 5 * H, tmp, 0, BL, bws, st))) return rc;
-            for (int q = 0; q < 5; ++q)
-                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, dst5[q], tmp + (int64_t)q * H, (int64_t)H);
-            EVI_LAUNCH_CHECK();
+            // the partial rows interleave the five vectors: one [gridC][5H] table, reduced straight into the five gradients
+            if ((rc = colsum_into_multi(BF(BL.partC), BL.gridC, 5, H, dst5, BL, bws, st))) return rc;
             if ((rc = colsum_into(BF(BL.partC) + (int64_t)BL.gridC * 5 * H, BL.gridC, 1, BF(BL.ssum), 1, BL, bws, st))) return rc;
         }
         // d(state_net.0 inputs): dP = dPA Wa, dRCX = dRC Wc, dXS = dz Wb   (NT GEMMs against the transposed blocks)
@@ -1248,12 +1210,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
             EVI_LAUNCH_CHECK();
             // the per-wave partial table [gridE * waves][4 D] -> one row (two ordered stages), then into the four gradients
             const int64_t prow = (int64_t)BL.gridE * BL.wavesE;
-            float* tmp = BF(BL.colpart) + ((prow + kColsumRows - 1) / kColsumRows + 1) * 4 * D;  // behind colsum_into's own scratch
-            hipLaunchKernelGGL(k_zero_f32, dim3(8), dim3(256), 0, st, tmp, (int64_t)4 * D);
-            if ((rc = colsum_into(BF(BL.partE), prow, 4 * D, tmp, 0, BL, bws, st))) return rc;
             float* dst4[4] = {G(g->struct_ln_w), G(g->struct_ln_b), G(g->struct_gate_w), G(g->struct_b)};
-            for (int q = 0; q < 4; ++q)
-                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, dst4[q], tmp + (int64_t)q * D, (int64_t)D);
+            if ((rc = colsum_into_multi(BF(BL.partE), prow, 4, D, dst4, BL, bws, st))) return rc;
             if ((rc = colsum_into(BF(BL.partE) + prow * 4 * D, prow, 1, G(g->struct_gate_b), 1, BL, bws, st))) return rc;
         }
         // struct_proj.0: weight [D, F] += dU^T SX (its bias gradient, the column sums of dU, came with the kernel's partials)

@@ -69,6 +69,36 @@ __global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__
     }
 }
 
+// Up to kZeroMax buffers zeroed by ONE launch (the backward clears ~36 gradient buffers per call: 36 launches of ~4 us each
+// were pure launch overhead).  blockIdx.y = buffer, blockIdx.x strides over it.
+constexpr int kZeroMax = 40;
+struct ZeroTable {
+    float* p[kZeroMax];
+    int64_t n[kZeroMax];
+    int count;
+};
+__global__ void k_zero_multi(ZeroTable t) {
+    const int b = blockIdx.y;
+    if (b >= t.count) return;
+    float* __restrict__ p = t.p[b];
+    const int64_t n = t.n[b];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// dst[q][i] += sum_s part[s * (Q * W) + q * W + i], s ascending: the second stage of a column sum whose columns are Q vectors of
+// W entries bound for Q different gradient buffers (one launch instead of a reduce + Q adds)
+struct ReduceDst {
+    float* p[8];
+};
+__global__ void k_reduce_partials_multi(const float* __restrict__ part, int S, int Q, int W, ReduceDst dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Q * W) return;
+    const int q = (int)(i / W), c = (int)(i % W);
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += part[(int64_t)s * Q * W + i];
+    dst.p[q][c] += acc;  // (the partial sum first, then ONE add into the gradient: what reduce-into-tmp + k_add_inplace did)
+}
+
 // out[i] (+)= sum_s part[s * len + i], s ascending
 __global__ void k_reduce_partials(const float* __restrict__ part, int S, int64_t len, float* __restrict__ out, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -351,7 +351,11 @@ def cosine_topk_gemm(queries: torch.Tensor, index: torch.Tensor, k: int, *, row_
         out_index = torch.empty((Q, k), dtype=torch.int64, device=dev)
     status = torch.empty(1, dtype=torch.int32, device=dev)
     fn = lib.evi_cosine_topk_gemm_f16 if x.dtype == torch.float16 else lib.evi_cosine_topk_gemm
-    plan = [products] if products is not None else ([1, 3] if k <= 1024 else [3])
+    # The single-product (plain bf16) selection keeps max(1024, k) reserve rows per query and needs the k-th and the last kept
+    # score 2 x 4.2e-3 |q| apart: the rows inside that band grow with N (about 390 of the 1024 at 2^23 rows of an exchangeable
+    # index, i.e. more than the reserve beyond ~2 x 10^7 rows) — there the attempt only costs a wasted pass (measured at 10^8
+    # rows: 319 ms with the failed attempt in front, against the three-product pass alone), so it is skipped
+    plan = [products] if products is not None else ([1, 3] if (k <= 1024 and N <= (1 << 24)) else [3])
     st = -1
     for prod in plan:
         if x.dtype == torch.float16:
@@ -778,16 +782,6 @@ def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         ws = _workspace(dev, "gemm_bf16x3", int(lib.evi_gemm_nt_bf16x3_workspace_bytes(N, K)))
         _lib.check(lib.evi_gemm_nt_bf16x3(_ptr(x2), M, K, K, _ptr(w), N, K, b, _ACT[act], _ptr(out), N, ws.data_ptr(),
                                           ws.numel(), _stream(dev)))
-    elif mode == "bf16x3_ps":  # both operands pre-split into bf16 hi / lo planes, LDS-DMA staging (gemm_ps.hip)
-        Kp = (K + 31) // 32 * 32
-        planes = torch.empty((2, M + N, Kp), dtype=torch.bfloat16, device=dev)
-        s = _stream(dev)
-        if M:
-            _lib.check(lib.evi_split_rows_bf16(_ptr(x2), M, K, K, Kp, planes[0, :M].data_ptr(), planes[1, :M].data_ptr(), s))
-        _lib.check(lib.evi_split_rows_bf16(_ptr(w), N, K, K, Kp, planes[0, M:].data_ptr(), planes[1, M:].data_ptr(), s))
-        _lib.check(lib.evi_gemm_nt_bf16x3_presplit(planes[0, :M].data_ptr() if M else None, planes[1, :M].data_ptr() if M else None,
-                                                   M, Kp, planes[0, M:].data_ptr(), planes[1, M:].data_ptr(), N, b, _ACT[act],
-                                                   _ptr(out), N, s))
     else:
-        raise ValueError(f"mode must be 'f32', 'bf16x3' or 'bf16x3_ps', got {mode!r}")
+        raise ValueError(f"mode must be 'f32' or 'bf16x3', got {mode!r}")
     return out.reshape(*x.shape[:-1], N)

@@ -479,14 +479,6 @@ size_t evi_scatter_rows_workspace_bytes(int64_t max_embedding_id);
 int evi_scatter_rows(const float* src, const int64_t* ids, int64_t n, int D, float* table,
                      int64_t max_embedding_id, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The split-bf16 GEMM on operands that are ALREADY split: A and W as bf16 hi / lo planes [rows, Kp] (Kp a multiple of
- * 32, zero padded: evi_split_rows_bf16 makes them from f32 rows).  Same arithmetic and results as evi_gemm_nt_bf16x3;
- * the planes go global -> LDS by LDS-DMA with no conversion work in the kernel.  The scorer uses it for the GEMMs whose
- * A operand its own kernels produce (they write the planes directly). */
-int evi_split_rows_bf16(const float* x, int64_t rows, int K, int64_t ld, int Kp, void* hi, void* lo, void* stream);
-int evi_gemm_nt_bf16x3_presplit(const void* Ahi, const void* Alo, int64_t M, int Kp, const void* Whi, const void* Wlo,
-                                int N, const float* bias, int act, float* C, int64_t ldc, void* stream);
-
 /* ---- G6/G7: DDE structure features ----------------------------------------------------------- */
 
 /* node_struct[v, c*S + j], S = 1 + rounds + rev_rounds (topic-major, as

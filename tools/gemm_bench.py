@@ -9,7 +9,7 @@ import torch
 from evi_rag_amd import ops
 
 
-MODES = ("bf16x3", "bf16x3_ps", "f32")
+MODES = ("bf16x3", "f32")
 
 
 def main():

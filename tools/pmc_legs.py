@@ -28,7 +28,7 @@ GRAPH_LEGS = {
     "evi_select_start_edges": ("k_select_start_edges", "k_zero_mask"),
 }
 SCORER_LEGS = {
-    "gemm": ("k_gemm_nt", "k_gemm_ps", "k_gemm_skinny", "k_split_weight", "k_split_planes"),
+    "gemm": ("k_gemm_nt", "k_gemm_skinny", "k_split_weight", "k_round_weight"),
     "edge_features": ("k_edge_features",),
     "state_combine": ("k_state_combine",),
     "dde_csr": ("k_dde_round", "k_csr_part", "k_graph_csr"),
