@@ -805,8 +805,8 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
 
 GRAPH_LEG_KERNELS = {  # C-ABI entry point -> the kernels it launches (names as rocprofv3 prints them)
     "evi_graph_csr": ("k_csr_part_count", "k_csr_part_scan", "k_csr_part_fill", "k_graph_csr"),
-    "evi_dde_node_struct": ("k_dde_round",),
-    "evi_bfs_levels": ("k_bfs_levels",),
+    "evi_dde_node_struct": ("k_dde_round", "k_dde_graph"),
+    "evi_bfs_levels": ("k_bfs_levels",),  # also matches k_bfs_levels_edges
     "evi_select_start_edges": ("k_select_start_edges", "k_zero_mask"),
 }
 
@@ -877,25 +877,26 @@ def bench_graph_kernels(dev, batch, *, graphs=3531, nodes=3000, edges=10000, ite
     ns = torch.empty((N, 2 * S), dtype=torch.float32, device=dev)
 
     def dde():
-        _lib.check(lib.evi_dde_node_struct_graphs(topic.data_ptr(), topic.size(1), 2, N, ptr.data_ptr(), B, csr.in_ptr.data_ptr(),
-                                                  csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), rounds, rounds,
-                                                  ns.data_ptr(), ops._stream(dev)))
+        _lib.check(lib.evi_dde_node_struct_edges(topic.data_ptr(), topic.size(1), 2, N, ptr.data_ptr(), eptr.data_ptr(), ei.data_ptr(), E, B,
+                                                 csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
+                                                 csr.out_nbr.data_ptr(), rounds, rounds, ns.data_ptr(), ops._stream(dev)))
 
     rec("evi_dde_node_struct", timed(dde),
-        2 * rounds * (E * 12 + N * 16) + N * 10 * 4, "per round E*(4 nbr + 8 gathered) + N*(8 ptr + 8 out); 2 + 2 rounds")
+        2 * rounds * (E * 12 + N * 16) + N * 10 * 4, "per round E*(4 nbr + 8 gathered) + N*(8 ptr + 8 out); 2 + 2 rounds (the row-walking "
+        "form's bytes, kept as the yardstick; the edge-parallel LDS kernel reads the edge list once: E*16 + N*48)")
     jg = torch.arange(B, dtype=torch.int32, device=dev)
     sp, doff = t(sb.q_ptr), t(sb.ptr[:-1])
     dist_lv = torch.empty(N, dtype=torch.int32, device=dev)
 
     def bfs():
-        _lib.check(lib.evi_bfs_levels(jg.data_ptr(), sp.data_ptr(), seeds.data_ptr(), doff.data_ptr(), B, ptr.data_ptr(),
-                                      csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
-                                      csr.out_nbr.data_ptr(), 0, dist_lv.data_ptr(), ops._stream(dev)))
+        _lib.check(lib.evi_bfs_levels_edges(jg.data_ptr(), sp.data_ptr(), seeds.data_ptr(), doff.data_ptr(), B, ptr.data_ptr(),
+                                            eptr.data_ptr(), ei.data_ptr(), E, csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
+                                            csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), 0, dist_lv.data_ptr(), ops._stream(dev)))
 
     ms = timed(bfs)
     levels = int(dist_lv.max().item()) + 1
-    rec("evi_bfs_levels", ms, N * 4 + 2 * E * 8 + N * 16,
-        f"undirected, {levels} levels, frontier queues in LDS: every CSR row once (ptr pair + nbr), the levels written once")
+    rec("evi_bfs_levels", ms, N * 4 + E * 16,
+        f"undirected, {levels} levels, edge-parallel in LDS (evi_bfs_levels_edges): the edge list once (16 B/edge), the levels written once")
     res["two_hop_frontier_nodes_per_graph"] = int(((dist_lv >= 0) & (dist_lv <= 2)).sum().item()) / B
     mask = torch.empty(E, dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -277,6 +277,111 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     }
 }
 
+// ---- edge-parallel BFS in LDS -------------------------------------------------------------------------------------
+// Measured in round 3 (profiles/r03_*): with the graph's CSR rows cached in LDS the search above still took ~4.4 us per level
+// (9 levels, 40 us per CWQ-shaped graph) — not memory but the frontier machinery: queue appends, compare-and-swaps on the
+// levels, three tiers of hub expansion, four barriers per level.  These graphs are SMALL (10^3-10^4 edges): the whole edge
+// list fits LDS as packed (u, v) pairs of 16-bit local ids, and a level is then one pass of the 1024 threads over ALL edges —
+// ten edges per thread for a CWQ graph: `level[u] == L and level[v] < 0  ->  level[v] = L + 1` (both orientations when
+// undirected), plain stores (every writer of a node writes the same value), ONE barrier per level, no CSR, no queue, no hubs.
+// Levels are 16-bit in LDS (N_g <= 32 767 bounds them), so a CWQ graph needs 6 + 40 KB: three searches per CU.
+// Graphs beyond the LDS budget take the CSR-based search above, inside the same kernel.
+__global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
+    const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
+    const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
+    const int64_t* __restrict__ edge_index, int64_t E, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr, int mode, int32_t* __restrict__ dist_out,
+    int lds_nodes) {
+    __shared__ BfsShared sh;
+    __shared__ BfsQueueShared shq;
+    __shared__ int s_changed[3];
+    extern __shared__ int32_t lds_dist[];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int g = job_graph[j];
+    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
+    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
+    const int ng = (int)(n1 - n0);
+    const int64_t ne64 = e1 - e0;
+    int32_t* out = dist_out + dist_off[j];  // local node id -> level
+    const int dist_ints = (ng + 1) / 2;     // 16-bit levels, two per int
+    if (ng <= 32767 && (int64_t)dist_ints + ne64 <= lds_nodes) {
+        const int ne = (int)ne64;
+        int16_t* d16 = reinterpret_cast<int16_t*>(lds_dist);
+        uint32_t* pairs = reinterpret_cast<uint32_t*>(lds_dist + dist_ints);
+        for (int v = tid; v < ng; v += kBfsThreads) d16[v] = -1;
+        if (tid < 3) s_changed[tid] = 0;
+        // the edge list, eight edges per thread per trip, loads first; an edge with an endpoint outside the graph (validated
+        // upstream) becomes the self loop (0, 0), which no level can cross
+        for (int i0 = tid; i0 < ne; i0 += 8 * kBfsThreads) {
+            int64_t a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t ee = e0 + (i0 + u * kBfsThreads < ne ? i0 + u * kBfsThreads : ne - 1);
+                a[u] = edge_index[ee];
+                b[u] = edge_index[E + ee];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u * kBfsThreads >= ne) continue;
+                const bool ok = a[u] >= n0 && a[u] < n1 && b[u] >= n0 && b[u] < n1;
+                pairs[i0 + u * kBfsThreads] = ok ? ((uint32_t)(a[u] - n0) | ((uint32_t)(b[u] - n0) << 16)) : 0u;
+            }
+        }
+        __syncthreads();
+        for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
+            const int64_t s0 = src_idx[i];
+            if (s0 >= n0 && s0 < n1) d16[s0 - n0] = 0;  // out-of-range sources are ignored (:619)
+        }
+        __syncthreads();
+        for (int level = 0;; ++level) {
+            // three rotating flags: level L raises flag[L % 3]; flag[(L + 1) % 3] is cleared meanwhile — nobody reads it before
+            // the end of level L + 1, and the flag read at the end of level L - 1 is a different one
+            if (tid == 0) s_changed[(level + 1) % 3] = 0;
+            bool any = false;
+            for (int i = tid; i < ne; i += kBfsThreads) {
+                const uint32_t p = pairs[i];
+                const int u = (int)(p & 0xFFFFu), v = (int)(p >> 16);
+                const int du = d16[u], dv = d16[v];
+                if (mode != 2 && du == level && dv < 0) {
+                    d16[v] = (int16_t)(level + 1);
+                    any = true;
+                }
+                if (mode != 1 && dv == level && du < 0) {
+                    d16[u] = (int16_t)(level + 1);
+                    any = true;
+                }
+            }
+            if (any) s_changed[level % 3] = 1;
+            __syncthreads();
+            if (!s_changed[level % 3]) break;  // uniform: the frontier did not grow
+        }
+        for (int v = tid; v < ng; v += kBfsThreads) out[v] = d16[v];
+        return;
+    }
+    // ---- beyond the LDS budget: the CSR-based search (rows from the L2), as k_bfs_levels
+    int32_t* dist = ng <= lds_nodes ? lds_dist : out;
+    const bool queued = 2 * (int64_t)ng <= lds_nodes;
+    if (tid == 0) shq.qtail = 0;
+    for (int v = tid; v < ng; v += kBfsThreads) dist[v] = -1;
+    __syncthreads();
+    for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
+        const int64_t s0 = src_idx[i];
+        if (s0 < n0 || s0 >= n1) continue;
+        if (!queued)
+            dist[s0 - n0] = 0;
+        else if (atomicCAS(&dist[s0 - n0], -1, 0) == -1)
+            lds_dist[ng + atomicAdd(&shq.qtail, 1)] = (int32_t)(s0 - n0);
+    }
+    if (queued)
+        bfs_block_queue<false>(lds_dist, lds_dist + ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &shq);
+    else
+        bfs_block(dist, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, mode, &sh);
+    if (dist != out) {
+        __syncthreads();
+        for (int v = tid; v < ng; v += kBfsThreads) out[v] = dist[v];
+    }
+}
+
 // One workgroup per job (graph, source set, target set): the reference's deterministic single shortest
 // path (_shortest_path_single, :453-530).  Its FIFO BFS over (neighbour id, edge id)-sorted adjacency
 // visits each level in the lexicographic order of the tree paths, so the path it returns is the
@@ -465,6 +570,26 @@ extern "C" int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, 
     hipLaunchKernelGGL(k_bfs_levels, dim3(num_jobs), dim3(kBfsThreads), lds_nodes * sizeof(int32_t),
                        reinterpret_cast<hipStream_t>(stream), job_graph, src_ptr, src_idx, dist_off, node_ptr, in_ptr, in_nbr,
                        out_ptr, out_nbr, mode, dist_out, lds_nodes, big ? 1 : 0);
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
+extern "C" int evi_bfs_levels_edges(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
+                                    const int64_t* dist_off, int num_jobs, const int64_t* node_ptr, const int64_t* edge_ptr,
+                                    const int64_t* edge_index, int64_t E, const int32_t* in_ptr, const int32_t* in_nbr,
+                                    const int32_t* out_ptr, const int32_t* out_nbr, int mode, int32_t* dist_out, void* stream) {
+    EVI_REQUIRE(num_jobs >= 0, "evi_bfs_levels_edges: num_jobs must be >= 0");
+    EVI_REQUIRE(mode >= 0 && mode <= 2, "evi_bfs_levels_edges: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
+    if (num_jobs == 0) return EVI_OK;
+    EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && edge_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels_edges: null pointer");
+    EVI_REQUIRE(E == 0 || edge_index, "evi_bfs_levels_edges: null edge_index");
+    if (const char* e = getenv("EVI_BFS_EDGES"))  // A/B runs: 0 = the CSR-based search for every graph
+        if (e[0] == '0')
+            return evi_bfs_levels(job_graph, src_ptr, src_idx, dist_off, num_jobs, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, mode, dist_out, stream);
+    constexpr int kLds = 12288;  // 48 KiB of dynamic LDS: a CWQ graph (6 KB of levels + 40 KB of edges) fits, three searches per CU
+    hipLaunchKernelGGL(k_bfs_levels_edges, dim3(num_jobs), dim3(kBfsThreads), kLds * sizeof(int32_t), reinterpret_cast<hipStream_t>(stream),
+                       job_graph, src_ptr, src_idx, dist_off, node_ptr, edge_ptr, edge_index, E, in_ptr, in_nbr, out_ptr, out_nbr, mode,
+                       dist_out, kLds);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }

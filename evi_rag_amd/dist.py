@@ -101,6 +101,13 @@ class ShardedIndex:
             if row_scale is not None or shadow is None or shadow.shape != local_rows.shape or shadow.dtype != torch.float16:
                 raise ValueError("method 'two_stage' needs an L2-normalised f32 shard (no row_scale) and its float16 shadow")
             self.two_stage_status = torch.zeros(1, dtype=torch.int32, device=local_rows.device)
+            if local_rows.is_cuda:
+                # the proof's error bound assumes rows of norm <= 1 (as cosine_topk_gemm's does): verified once per shard (one pass
+                # + one read-back, cached on the tensor), whoever built the shadow
+                from . import ops
+
+                if not ops.rows_are_unit_norm(local_rows):
+                    raise ValueError("method 'two_stage' needs L2-normalised rows (norm <= 1): run ops.normalize_embeddings on the shard first")
         # per-row scale of the local shard: the fused normalisation of a raw index, or the
         # dequantisation scale of an fp8 index (ops.quantize_rows_fp8)
         self.row_scale = row_scale

@@ -79,9 +79,10 @@ def _bfs(gb: GraphBatch, job_graph: np.ndarray, sources: List[np.ndarray], mode:
     jg, sp, si, do = t(job_graph, torch.int32), t(src_ptr, torch.int64), t(src_idx, torch.int64), t(dist_off[:-1], torch.int64)
     lib = _lib.load()
     c = gb.csr
-    _lib.check(lib.evi_bfs_levels(ops._ptr(jg), ops._ptr(sp), ops._ptr(si), do.data_ptr() if J else None, J,
-                                  ops._ptr(gb.node_ptr), c.in_ptr.data_ptr(), c.in_nbr.data_ptr(), c.out_ptr.data_ptr(),
-                                  c.out_nbr.data_ptr(), int(mode), dist.data_ptr(), ops._stream(dev)))
+    _lib.check(lib.evi_bfs_levels_edges(ops._ptr(jg), ops._ptr(sp), ops._ptr(si), do.data_ptr() if J else None, J,
+                                        ops._ptr(gb.node_ptr), ops._ptr(gb.edge_ptr), ops._ptr(gb.edge_index), gb.E,
+                                        c.in_ptr.data_ptr(), c.in_nbr.data_ptr(), c.out_ptr.data_ptr(),
+                                        c.out_nbr.data_ptr(), int(mode), dist.data_ptr(), ops._stream(dev)))
     return dist, dist_off
 
 
@@ -263,9 +264,9 @@ def label_pairs_flat(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr:
 
     def bfs(j0, j1, mode):
         if j1 > j0:  # sub-ranges address the same tables: the offsets inside src_ptr / dist_off are absolute
-            _lib.check(lib.evi_bfs_levels(d_jg[j0:].data_ptr(), d_sp[j0:].data_ptr(), d_si.data_ptr(), d_do[j0:].data_ptr(), j1 - j0,
-                                          ops._ptr(nptr), csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
-                                          csr.out_nbr.data_ptr(), int(mode), dist.data_ptr(), st))
+            _lib.check(lib.evi_bfs_levels_edges(d_jg[j0:].data_ptr(), d_sp[j0:].data_ptr(), d_si.data_ptr(), d_do[j0:].data_ptr(), j1 - j0,
+                                                ops._ptr(nptr), ops._ptr(eptr), ops._ptr(ei), E, csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
+                                                csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), int(mode), dist.data_ptr(), st))
 
     if directed:
         bfs(0, S, 1)   # forward from the seeds

@@ -409,7 +409,7 @@ def drop_shadow_f16(index: torch.Tensor) -> None:
 
 def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: torch.Tensor, k: int, *, row_id_base: int = 0,
                           fallback="device", out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                          status: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
+                          status: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, check_norms: bool = True):
     """cosine_topk over an L2-normalised f32 index at half the HBM bytes (see evi_cosine_topk_two_stage): the f16
     `shadow` (index_shadow_f16(index)) is scanned to select k + max(256, k/2) candidates per query, which are re-scored
     from the f32 rows with the scan's arithmetic; ids and scores equal cosine_topk(queries, index, k) bit for bit.
@@ -438,6 +438,11 @@ def cosine_topk_two_stage(queries: torch.Tensor, index: torch.Tensor, shadow: to
     N = x.shape[0]
     if x.shape[1] != D:
         raise ValueError(f"query dim {D} != index dim {x.shape[1]}")
+    # the exactness proof bounds the f16 rounding of a row by 2^-11 of its norm and assumes norm <= 1, like cosine_topk_gemm's:
+    # the same guard (one pass over the index + one read-back the FIRST time this tensor is seen, cached on the tensor)
+    if check_norms and N and not rows_are_unit_norm(x):
+        raise ValueError("cosine_topk_two_stage needs an index of rows with norm <= 1 (normalize_embeddings): its exactness proof "
+                         "assumes them; use cosine_topk for a raw index")
     if status is not None and (status.dtype != torch.int32 or status.numel() != 1):
         raise ValueError("status must be an int32 tensor with one element")
     if Q == 0 or N == 0:
@@ -629,7 +634,11 @@ def graph_csr(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr: torch.
 
 
 def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: GraphCSR, num_rounds: int,
-                    num_reverse_rounds: int, num_topics: int = 2) -> torch.Tensor:
+                    num_reverse_rounds: int, num_topics: int = 2, *, edge_index: Optional[torch.Tensor] = None,
+                    edge_ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """DDE structure features ns [N, num_topics * (1 + rounds + reverse rounds)] (src/models/components/graph.py:41-74,
+    retriever.py:519-553).  With the batch's edge_index / edge_ptr given, graphs whose edge list fits LDS are propagated
+    edge-parallel in one launch (evi_dde_node_struct_edges); the CSR serves the others.  Same bits either way."""
     dev = _require_gpu(topic_one_hot, node_ptr)
     t = _f32c(topic_one_hot, "topic_one_hot")
     if t.dim() == 1:
@@ -639,6 +648,13 @@ def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: Gr
     S = 1 + int(num_rounds) + int(num_reverse_rounds)
     ns = torch.empty((N, num_topics * S), dtype=torch.float32, device=dev)
     lib = _lib.load()
+    if edge_index is not None and edge_ptr is not None:
+        ei = _i64c(edge_index, "edge_index")
+        eptr = _i64c(edge_ptr.view(-1), "edge_ptr")
+        _lib.check(lib.evi_dde_node_struct_edges(_ptr(t), t.size(1), int(num_topics), N, _ptr(ptr), _ptr(eptr), _ptr(ei), ei.size(1), B,
+                                                 csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
+                                                 csr.out_nbr.data_ptr(), int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))
+        return ns
     _lib.check(lib.evi_dde_node_struct_graphs(_ptr(t), t.size(1), int(num_topics), N, _ptr(ptr), B, csr.in_ptr.data_ptr(),
                                               csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
                                               int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))

@@ -461,8 +461,12 @@ def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
         ns = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds)
         monkeypatch.setenv("EVI_DDE_MODE", "graph")
         ns_g = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds)
+        # ... and edge-parallel per graph: the edge list in LDS, f64 LDS atomic adds (exact sums: order-free), no rows at all
+        monkeypatch.setenv("EVI_DDE_MODE", "edges")
+        ns_e = ops.dde_node_struct(t(topic), t(np.asarray(ptr, np.int64)), csr, *rounds, edge_index=t(ei), edge_ptr=t(np.asarray(eptr, np.int64)))
         monkeypatch.delenv("EVI_DDE_MODE")
         assert torch.equal(ns, ns_g), rounds
+        assert torch.equal(ns, ns_e), rounds
         # the oracle (like PyG's scatter-mean) sums a row in f32 in edge order, the kernels in f64 rounded once: the 6 667-entry
         # hub rows of the 20 000-edge graph carry a few f32 ulps of summation error on the ORACLE's side
         np.testing.assert_allclose(ns.cpu().numpy(), ograph.node_structure_features(topic, ei, *rounds), rtol=0, atol=6e-6)
@@ -474,10 +478,17 @@ def test_csr_parts_dde_and_bfs_agree_for_every_split(dev, parts, monkeypatch):
     doff = np.asarray(ptr[:-1], np.int64)
     dist = torch.empty(N, dtype=torch.int32, device=dev)
     sp_d, src_d, doff_d, ptr_d = t(sp), t(src), t(doff), t(np.asarray(ptr, np.int64))  # kept alive across the launches
+    ei_d, eptr_d = t(ei), t(np.asarray(eptr, np.int64))
+    dist_e = torch.empty(N, dtype=torch.int32, device=dev)
     for mode in (0, 1, 2):
         _lib.check(lib.evi_bfs_levels(jg.data_ptr(), sp_d.data_ptr(), src_d.data_ptr(), doff_d.data_ptr(), B,
                                       ptr_d.data_ptr(), csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
                                       csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), mode, dist.data_ptr(), ops._stream(dev)))
+        # the edge-parallel LDS search (graphs whose edge list fits 48 KiB; the 20 000-edge graph takes the CSR path inside it)
+        _lib.check(lib.evi_bfs_levels_edges(jg.data_ptr(), sp_d.data_ptr(), src_d.data_ptr(), doff_d.data_ptr(), B, ptr_d.data_ptr(),
+                                            eptr_d.data_ptr(), ei_d.data_ptr(), E, csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(),
+                                            csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(), mode, dist_e.data_ptr(), ops._stream(dev)))
+        assert torch.equal(dist, dist_e), mode
         got = dist.cpu().numpy()
         for g, (n, e) in enumerate(sizes):
             s_l, d_l = (ei[0, eptr[g]: eptr[g + 1]] - ptr[g]).tolist(), (ei[1, eptr[g]: eptr[g + 1]] - ptr[g]).tolist()

@@ -23,7 +23,7 @@ import re
 
 GRAPH_LEGS = {
     "evi_graph_csr": ("k_csr_part_count", "k_csr_part_scan", "k_csr_part_fill", "k_graph_csr"),
-    "evi_dde_node_struct": ("k_dde_round",),
+    "evi_dde_node_struct": ("k_dde_round", "k_dde_graph"),
     "evi_bfs_levels": ("k_bfs_levels",),
     "evi_select_start_edges": ("k_select_start_edges", "k_zero_mask"),
 }
@@ -31,7 +31,7 @@ SCORER_LEGS = {
     "gemm": ("k_gemm_nt", "k_gemm_skinny", "k_split_weight", "k_round_weight"),
     "edge_features": ("k_edge_features",),
     "state_combine": ("k_state_combine",),
-    "dde_csr": ("k_dde_round", "k_csr_part", "k_graph_csr"),
+    "dde_csr": ("k_dde_round", "k_dde_graph", "k_csr_part", "k_graph_csr"),
     "other": (),
 }
 
