@@ -117,7 +117,6 @@ _SIGNATURES = {
     "evi_graph_csr": (c_int, [_P, c_int64, _P, _P, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "evi_dde_node_struct": (c_int, [_P, c_int, c_int, c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "evi_dde_node_struct_graphs": (c_int, [_P, c_int, c_int, c_int64, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
-    "evi_dde_node_struct_edges": (c_int, [_P, c_int, c_int, c_int64, _P, _P, _P, c_int64, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "evi_gemm_nt_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, c_int64, _P, c_int, _P, c_int64, _P]),
     "evi_gemm_nt_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int]),
     "evi_gemm_nt_bf16x3": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int, c_int64, _P, c_int, _P, c_int64, _P, c_size_t, _P]),

@@ -277,15 +277,17 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
     }
 }
 
-// ---- edge-parallel BFS in LDS -------------------------------------------------------------------------------------
-// Measured in round 3 (profiles/r03_*): with the graph's CSR rows cached in LDS the search above still took ~4.4 us per level
-// (9 levels, 40 us per CWQ-shaped graph) — not memory but the frontier machinery: queue appends, compare-and-swaps on the
-// levels, three tiers of hub expansion, four barriers per level.  These graphs are SMALL (10^3-10^4 edges): the whole edge
-// list fits LDS as packed (u, v) pairs of 16-bit local ids, and a level is then one pass of the 1024 threads over ALL edges —
-// ten edges per thread for a CWQ graph: `level[u] == L and level[v] < 0  ->  level[v] = L + 1` (both orientations when
-// undirected), plain stores (every writer of a node writes the same value), ONE barrier per level, no CSR, no queue, no hubs.
-// Levels are 16-bit in LDS (N_g <= 32 767 bounds them), so a CWQ graph needs 6 + 40 KB: three searches per CU.
-// Graphs beyond the LDS budget take the CSR-based search above, inside the same kernel.
+// ---- edge-parallel BFS: levels in LDS, the edge list in REGISTERS ---------------------------------------------------
+// Measured in round 3: with the graph's CSR rows cached in LDS the frontier search above still took ~4.4 us per level (9 levels,
+// 40 us per CWQ-shaped graph) — not memory but the frontier machinery: queue appends, compare-and-swaps, three tiers of hub
+// expansion, four barriers per level, every LDS access waiting for the one before.  These graphs are SMALL (10^3-10^4 edges):
+// each of the 1 024 threads keeps <= 12 edges as packed 16-bit (u, v) pairs in registers for the whole search, the levels
+// (16-bit, N_g <= 32 767) sit in LDS, and a level is: read level[u], level[v] of all the thread's edges (24 independent LDS
+// reads, issued back to back), then `level[u] == L and level[v] < 0 -> level[v] = L + 1` (both orientations when undirected) as
+// plain stores — every writer of a node writes the same value — and ONE barrier.  No CSR, no queue, no hubs, 6 KB of LDS.
+// Graphs with more than 12 288 edges or 32 767 nodes take the CSR-based search above, inside the same kernel.
+constexpr int kBfsEdgeRegs = 12;
+
 __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
     const int32_t* __restrict__ job_graph, const int64_t* __restrict__ src_ptr, const int64_t* __restrict__ src_idx,
     const int64_t* __restrict__ dist_off, const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
@@ -303,28 +305,27 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
     const int ng = (int)(n1 - n0);
     const int64_t ne64 = e1 - e0;
     int32_t* out = dist_out + dist_off[j];  // local node id -> level
-    const int dist_ints = (ng + 1) / 2;     // 16-bit levels, two per int
-    if (ng <= 32767 && (int64_t)dist_ints + ne64 <= lds_nodes) {
+    if (ng <= 32767 && ne64 <= (int64_t)kBfsEdgeRegs * kBfsThreads && (ng + 1) / 2 <= lds_nodes) {
         const int ne = (int)ne64;
         int16_t* d16 = reinterpret_cast<int16_t*>(lds_dist);
-        uint32_t* pairs = reinterpret_cast<uint32_t*>(lds_dist + dist_ints);
         for (int v = tid; v < ng; v += kBfsThreads) d16[v] = -1;
         if (tid < 3) s_changed[tid] = 0;
-        // the edge list, eight edges per thread per trip, loads first; an edge with an endpoint outside the graph (validated
-        // upstream) becomes the self loop (0, 0), which no level can cross
-        for (int i0 = tid; i0 < ne; i0 += 8 * kBfsThreads) {
-            int64_t a[8], b[8];
+        // this thread's edges, all loads issued before the first use; an edge past the end, or with an endpoint outside the graph
+        // (validated upstream), becomes the self loop (0, 0), which no level can cross
+        uint32_t pr[kBfsEdgeRegs];
+        {
+            int64_t a[kBfsEdgeRegs], b[kBfsEdgeRegs];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t ee = e0 + (i0 + u * kBfsThreads < ne ? i0 + u * kBfsThreads : ne - 1);
-                a[u] = edge_index[ee];
-                b[u] = edge_index[E + ee];
+            for (int r = 0; r < kBfsEdgeRegs; ++r) {
+                const int idx = tid + r * kBfsThreads;
+                const int64_t ee = e0 + (idx < ne ? idx : (ne > 0 ? ne - 1 : 0));
+                a[r] = ne > 0 ? edge_index[ee] : 0;
+                b[r] = ne > 0 ? edge_index[E + ee] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (i0 + u * kBfsThreads >= ne) continue;
-                const bool ok = a[u] >= n0 && a[u] < n1 && b[u] >= n0 && b[u] < n1;
-                pairs[i0 + u * kBfsThreads] = ok ? ((uint32_t)(a[u] - n0) | ((uint32_t)(b[u] - n0) << 16)) : 0u;
+            for (int r = 0; r < kBfsEdgeRegs; ++r) {
+                const bool ok = tid + r * kBfsThreads < ne && a[r] >= n0 && a[r] < n1 && b[r] >= n0 && b[r] < n1;
+                pr[r] = ok ? ((uint32_t)(a[r] - n0) | ((uint32_t)(b[r] - n0) << 16)) : 0u;
             }
         }
         __syncthreads();
@@ -337,17 +338,21 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
             // three rotating flags: level L raises flag[L % 3]; flag[(L + 1) % 3] is cleared meanwhile — nobody reads it before
             // the end of level L + 1, and the flag read at the end of level L - 1 is a different one
             if (tid == 0) s_changed[(level + 1) % 3] = 0;
+            int du[kBfsEdgeRegs], dv[kBfsEdgeRegs];
+#pragma unroll
+            for (int r = 0; r < kBfsEdgeRegs; ++r) {
+                du[r] = d16[pr[r] & 0xFFFFu];
+                dv[r] = d16[pr[r] >> 16];
+            }
             bool any = false;
-            for (int i = tid; i < ne; i += kBfsThreads) {
-                const uint32_t p = pairs[i];
-                const int u = (int)(p & 0xFFFFu), v = (int)(p >> 16);
-                const int du = d16[u], dv = d16[v];
-                if (mode != 2 && du == level && dv < 0) {
-                    d16[v] = (int16_t)(level + 1);
+#pragma unroll
+            for (int r = 0; r < kBfsEdgeRegs; ++r) {
+                if (mode != 2 && du[r] == level && dv[r] < 0) {
+                    d16[pr[r] >> 16] = (int16_t)(level + 1);
                     any = true;
                 }
-                if (mode != 1 && dv == level && du < 0) {
-                    d16[u] = (int16_t)(level + 1);
+                if (mode != 1 && dv[r] == level && du[r] < 0) {
+                    d16[pr[r] & 0xFFFFu] = (int16_t)(level + 1);
                     any = true;
                 }
             }
@@ -586,7 +591,8 @@ extern "C" int evi_bfs_levels_edges(const int32_t* job_graph, const int64_t* src
     if (const char* e = getenv("EVI_BFS_EDGES"))  // A/B runs: 0 = the CSR-based search for every graph
         if (e[0] == '0')
             return evi_bfs_levels(job_graph, src_ptr, src_idx, dist_off, num_jobs, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, mode, dist_out, stream);
-    constexpr int kLds = 12288;  // 48 KiB of dynamic LDS: a CWQ graph (6 KB of levels + 40 KB of edges) fits, three searches per CU
+    constexpr int kLds = 12288;  // 48 KiB of dynamic LDS for the graphs that take the CSR-based path; the edge-parallel search
+                                 // needs 2 bytes per node of it (its edges live in registers)
     hipLaunchKernelGGL(k_bfs_levels_edges, dim3(num_jobs), dim3(kBfsThreads), kLds * sizeof(int32_t), reinterpret_cast<hipStream_t>(stream),
                        job_graph, src_ptr, src_idx, dist_off, node_ptr, edge_ptr, edge_index, E, in_ptr, in_nbr, out_ptr, out_nbr, mode,
                        dist_out, kLds);

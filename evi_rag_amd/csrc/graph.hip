@@ -25,7 +25,6 @@
 // rounding once to f32, which makes the f32 result independent of the summation order.
 #include "common.hpp"
 
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <stdlib.h>
 
@@ -563,6 +562,9 @@ __global__ __launch_bounds__(256) void k_dde_round(const float* __restrict__ top
 // global memory once, coalesced.  Memory traffic: the neighbour lists (once per round, the second round of a chain from the
 // L2), the row pointers, the topic rows in and the ns rows out.  Worth it when there are enough graphs to fill the chip
 // (one workgroup per graph); a graph whose block does not fit the LDS runs the same code on its global ns rows.
+// (An edge-parallel variant — the edge list in LDS, acc[dst] += x[src] with f64 LDS atomic adds, exact and order-free — was built
+// and measured in round 3: 100 us per CWQ-shaped graph against 84 us for this kernel and 30 us per BATCH of 32 for the
+// node-parallel one: 80 000 ds_add_f64 per graph run at ~2.5 cycles each.  Removed.)
 constexpr int kDdeGraphLdsFloats = 36864;  // 144 KiB
 
 template <int C, class F>
@@ -677,113 +679,6 @@ __global__ __launch_bounds__(kGraphThreads) void k_dde_graph(const float* __rest
             for (int c = 0; c < C; ++c) st[v * W + c * S] = topic[(n0 + v) * topic_stride + c];
         __syncthreads();
         dde_graph_rounds<C>(st, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
-    }
-}
-
-// ---- DDE, edge-parallel per graph ----------------------------------------------------------------------------------------
-// k_dde_graph above still walks CSR rows: a power-law graph's hub rows are summed by one wave each, one after the other, every
-// hub a fresh trip to the neighbour list in global memory — 84 us per CWQ-shaped graph (profiles/r03_*), latency, not bytes.
-// A mean-propagation round does not need rows at all:   acc[dst] += x[src]  over ALL edges,  then  x'[v] = acc[v] / deg[v].
-// With the graph's edge list in LDS as packed 16-bit (u, v) pairs (as in the edge-parallel BFS) a round is one pass of the
-// 1024 threads over the edges with f64 LDS atomic adds — sums of f32 values in f64 are exact for any order, so the result
-// does not depend on which lane adds first and equals the row-walking kernels' bit for bit — and one pass over the nodes.
-// No CSR, no hubs, two barriers per round.  LDS: x 8 N_g + acc 16 N_g + degrees 8 N_g + pairs 4 E_g bytes (a CWQ graph: 136 KB).
-constexpr int kDdeEdgesLdsInts = 36864;  // 144 KiB
-
-template <int C>
-__global__ __launch_bounds__(kGraphThreads) void k_dde_graph_edges(const float* __restrict__ topic, int topic_stride, float* __restrict__ ns,
-                                                                   int S, const int64_t* __restrict__ node_ptr,
-                                                                   const int64_t* __restrict__ edge_ptr,
-                                                                   const int64_t* __restrict__ edge_index, int64_t E,
-                                                                   const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
-                                                                   const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
-                                                                   int rounds, int rev_rounds) {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds_i[];
-    const int g = blockIdx.x, tid = threadIdx.x;
-    const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
-    const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
-    const int ng = (int)(n1 - n0);
-    const int64_t ne64 = e1 - e0;
-    const int W = C * S;
-    float* __restrict__ nsg = ns + n0 * W;
-    // ints: x [ng * C] | deg_in [ng] | deg_out [ng] | pairs [ne] | (8-byte aligned) acc [ng * C] doubles
-    const int64_t ints_before_acc = ((int64_t)ng * (C + 2) + ne64 + 1) / 2 * 2;
-    if (ng > 32767 || ints_before_acc + 2 * (int64_t)ng * C > kDdeEdgesLdsInts) {
-        // does not fit: the row-walking rounds on the graph's global ns rows (CSR from the caller)
-        for (int v = tid; v < ng; v += kGraphThreads)
-#pragma unroll
-            for (int c = 0; c < C; ++c) nsg[v * W + c * S] = topic[(n0 + v) * topic_stride + c];
-        __syncthreads();
-        dde_graph_rounds<C>(nsg, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
-        return;
-    }
-    const int ne = (int)ne64;
-    float* x = reinterpret_cast<float*>(lds_i);
-    int32_t* deg_in = lds_i + ng * C;
-    int32_t* deg_out = deg_in + ng;
-    uint32_t* pairs = reinterpret_cast<uint32_t*>(deg_out + ng);
-    double* acc = reinterpret_cast<double*>(lds_i + ints_before_acc);
-    for (int v = tid; v < ng; v += kGraphThreads) {
-        deg_in[v] = deg_out[v] = 0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            acc[v * C + c] = 0.0;
-            nsg[v * W + c * S] = topic[(n0 + v) * topic_stride + c];  // column 0 of every channel: the one-hot itself
-        }
-    }
-    __syncthreads();
-    constexpr uint32_t kSkip = 0xFFFFFFFFu;  // an edge with an endpoint outside the graph (validated upstream) is left out
-    for (int i0 = tid; i0 < ne; i0 += 8 * kGraphThreads) {
-        int64_t a[8], b[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t ee = e0 + (i0 + u * kGraphThreads < ne ? i0 + u * kGraphThreads : ne - 1);
-            a[u] = edge_index[ee];
-            b[u] = edge_index[E + ee];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (i0 + u * kGraphThreads >= ne) continue;
-            const bool ok = a[u] >= n0 && a[u] < n1 && b[u] >= n0 && b[u] < n1;
-            pairs[i0 + u * kGraphThreads] = ok ? ((uint32_t)(a[u] - n0) | ((uint32_t)(b[u] - n0) << 16)) : kSkip;
-            if (ok) {
-                atomicAdd(&deg_out[a[u] - n0], 1);
-                atomicAdd(&deg_in[b[u] - n0], 1);
-            }
-        }
-    }
-    for (int step = 0; step < rounds + rev_rounds; ++step) {
-        const bool rev = step >= rounds;
-        const int j = rev ? step - rounds + 1 : step + 1;
-        const int jout = rev ? rounds + j : j;
-        if (j == 1) {  // a chain starts from the one-hot (the reverse chain restarts from it: edge_index.flip(0), graph.py:66-72)
-            __syncthreads();
-            for (int v = tid; v < ng; v += kGraphThreads)
-#pragma unroll
-                for (int c = 0; c < C; ++c) x[v * C + c] = topic[(n0 + v) * topic_stride + c];
-        }
-        __syncthreads();  // x (and the degrees, the first time) complete; acc is zero
-        for (int i = tid; i < ne; i += kGraphThreads) {
-            const uint32_t p = pairs[i];
-            if (p == kSkip) continue;
-            const int u = (int)(p & 0xFFFFu), v = (int)(p >> 16);
-            const int from = rev ? v : u, to = rev ? u : v;  // messages flow source -> target; the reverse rounds run on flipped edges
-#pragma unroll
-            for (int c = 0; c < C; ++c) unsafeAtomicAdd(&acc[to * C + c], (double)x[from * C + c]);
-        }
-        __syncthreads();
-        const int32_t* deg = rev ? deg_out : deg_in;
-        for (int v = tid; v < ng; v += kGraphThreads) {
-            const int d = deg[v];
-            const float cnt = d > 0 ? (float)d : 1.0f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float val = (float)acc[v * C + c] / cnt;
-                acc[v * C + c] = 0.0;
-                x[v * C + c] = val;
-                nsg[v * W + c * S + jout] = val;
-            }
-        }
     }
 }
 
@@ -920,43 +815,6 @@ static int dde_graph_min_batch() {  // read per call (a getenv is nothing next t
 extern "C" int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
                                    const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr,
                                    const int32_t* out_nbr, int rounds, int rev_rounds, float* node_struct, void* stream);
-
-extern "C" int evi_dde_node_struct_graphs(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
-                                          const int64_t* node_ptr, int B, const int32_t* in_ptr, const int32_t* in_nbr,
-                                          const int32_t* out_ptr, const int32_t* out_nbr, int rounds, int rev_rounds,
-                                          float* node_struct, void* stream);
-
-// graphs per batch from which the edge-parallel per-graph kernel is used (EVI_DDE_MODE=edges forces it, =graph / =nodes the others)
-static int dde_edges_min_batch() {
-    const char* e = getenv("EVI_DDE_MODE");
-    if (e && e[0] == 'e') return 1;
-    if (e && (e[0] == 'g' || e[0] == 'n')) return 0x7FFFFFFF;
-    return 16;
-}
-
-extern "C" int evi_dde_node_struct_edges(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
-                                         const int64_t* node_ptr, const int64_t* edge_ptr, const int64_t* edge_index, int64_t E, int B,
-                                         const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr, const int32_t* out_nbr,
-                                         int rounds, int rev_rounds, float* node_struct, void* stream) {
-    if (node_ptr == nullptr || edge_ptr == nullptr || (E > 0 && edge_index == nullptr) || B < dde_edges_min_batch() || num_topics != 2 ||
-        N == 0 || rounds < 0 || rounds > 4 || rev_rounds < 0 || rev_rounds > 4)
-        return evi_dde_node_struct_graphs(topic_one_hot, topic_stride, num_topics, N, node_ptr, B, in_ptr, in_nbr, out_ptr, out_nbr, rounds,
-                                          rev_rounds, node_struct, stream);
-    EVI_REQUIRE(topic_stride >= num_topics, "evi_dde_node_struct: topic_one_hot feature dim %d < num_topics=%d", topic_stride, num_topics);
-    EVI_REQUIRE(topic_one_hot && in_ptr && out_ptr && node_struct, "evi_dde_node_struct: null pointer");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static thread_local bool attr = false;
-    if (!attr) {
-        EVI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dde_graph_edges<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          kDdeEdgesLdsInts * (int)sizeof(int32_t)));
-        attr = true;
-    }
-    const int S = 1 + rounds + rev_rounds;
-    hipLaunchKernelGGL(k_dde_graph_edges<2>, dim3((unsigned)B), dim3(kGraphThreads), kDdeEdgesLdsInts * sizeof(int32_t), st, topic_one_hot,
-                       topic_stride, node_struct, S, node_ptr, edge_ptr, edge_index, E, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
-    EVI_LAUNCH_CHECK();
-    return EVI_OK;
-}
 
 extern "C" int evi_dde_node_struct_graphs(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
                                           const int64_t* node_ptr, int B, const int32_t* in_ptr, const int32_t* in_nbr,

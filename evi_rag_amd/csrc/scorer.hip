@@ -976,9 +976,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                             I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
                             evi_graph_csr_workspace_bytes(N), stream)))
         return rc;
-    if ((rc = evi_dde_node_struct_edges(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, b->edge_ptr, b->edge_index, E, B,
-                                        I32(L.in_ptr), I32(L.in_nbr), I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds,
-                                        w->dde_reverse_rounds, ns, stream)))
+    if ((rc = evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
+                                         I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
         return rc;
 
     // 3-5. factored state_net.0 (see the header), per edge chunk

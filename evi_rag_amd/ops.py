@@ -634,11 +634,10 @@ def graph_csr(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr: torch.
 
 
 def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: GraphCSR, num_rounds: int,
-                    num_reverse_rounds: int, num_topics: int = 2, *, edge_index: Optional[torch.Tensor] = None,
-                    edge_ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    num_reverse_rounds: int, num_topics: int = 2) -> torch.Tensor:
     """DDE structure features ns [N, num_topics * (1 + rounds + reverse rounds)] (src/models/components/graph.py:41-74,
-    retriever.py:519-553).  With the batch's edge_index / edge_ptr given, graphs whose edge list fits LDS are propagated
-    edge-parallel in one launch (evi_dde_node_struct_edges); the CSR serves the others.  Same bits either way."""
+    retriever.py:519-553): node-parallel launches per round pair for small batches, one workgroup per graph with the graph's
+    feature block in LDS from ~100 graphs per batch on (evi_dde_node_struct_graphs).  Same bits either way."""
     dev = _require_gpu(topic_one_hot, node_ptr)
     t = _f32c(topic_one_hot, "topic_one_hot")
     if t.dim() == 1:
@@ -648,13 +647,6 @@ def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: Gr
     S = 1 + int(num_rounds) + int(num_reverse_rounds)
     ns = torch.empty((N, num_topics * S), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    if edge_index is not None and edge_ptr is not None:
-        ei = _i64c(edge_index, "edge_index")
-        eptr = _i64c(edge_ptr.view(-1), "edge_ptr")
-        _lib.check(lib.evi_dde_node_struct_edges(_ptr(t), t.size(1), int(num_topics), N, _ptr(ptr), _ptr(eptr), _ptr(ei), ei.size(1), B,
-                                                 csr.in_ptr.data_ptr(), csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(),
-                                                 csr.out_nbr.data_ptr(), int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))
-        return ns
     _lib.check(lib.evi_dde_node_struct_graphs(_ptr(t), t.size(1), int(num_topics), N, _ptr(ptr), B, csr.in_ptr.data_ptr(),
                                               csr.in_nbr.data_ptr(), csr.out_ptr.data_ptr(), csr.out_nbr.data_ptr(),
                                               int(num_rounds), int(num_reverse_rounds), _ptr(ns), _stream(dev)))

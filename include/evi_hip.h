@@ -347,11 +347,11 @@ int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, const int64
                    const int32_t* in_nbr, const int32_t* out_ptr, const int32_t* out_nbr, int mode,
                    int32_t* dist_out, void* stream);
 
-/* The same levels with the batch's edge list given as well (edge_index [2, E] i64 batch-global, edge_ptr [B+1]): a graph whose
- * edges fit LDS as packed 16-bit (u, v) pairs (N_g <= 32 767, ceil(N_g / 2) + E_g <= 12 288 ints: every WebQSP / CWQ graph) is
- * searched EDGE-parallel — one pass of the workgroup over all its edges per level, one barrier per level, no queue, no row
- * gathers: ~4x faster than the frontier search on 10^4-edge graphs, whose levels cost barriers and compare-and-swaps, not
- * memory.  Larger graphs take evi_bfs_levels' path inside the same launch (that is what the CSR arguments are for). */
+/* The same levels with the batch's edge list given as well (edge_index [2, E] i64 batch-global, edge_ptr [B+1]): a graph of at
+ * most 12 288 edges and 32 767 nodes (every WebQSP / CWQ graph) is searched EDGE-parallel — every thread of the workgroup keeps
+ * <= 12 edges in registers as packed 16-bit (u, v) pairs, the levels sit in LDS, and a level is one round of independent LDS
+ * reads, a few plain stores and one barrier: no queue, no row gathers, no CSR.  Larger graphs take evi_bfs_levels' path inside
+ * the same launch (that is what the CSR arguments are for). */
 int evi_bfs_levels_edges(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
                          const int64_t* dist_off, int num_jobs, const int64_t* node_ptr, const int64_t* edge_ptr,
                          const int64_t* edge_index, int64_t E, const int32_t* in_ptr, const int32_t* in_nbr,
@@ -511,16 +511,6 @@ int evi_dde_node_struct_graphs(const float* topic_one_hot, int topic_stride, int
                                const int32_t* out_ptr, const int32_t* out_nbr, int rounds, int rev_rounds,
                                float* node_struct, void* stream);
 
-/* The same features with the batch's edge list given as well.  From 16 graphs per batch on, a graph whose edges fit LDS as packed
- * 16-bit (u, v) pairs (N_g <= 32 767, 32 N_g + 4 E_g bytes <= 144 KiB: every WebQSP / CWQ graph) is propagated EDGE-parallel in
- * LDS: per round one pass over all edges with f64 atomic adds (sums of f32 values in f64 are exact, so order-free and equal to
- * the row-walking forms bit for bit), one pass over the nodes — no rows, no hubs; ONE launch for all rounds of the batch.
- * Larger graphs take the row-walking rounds on their global rows inside the same launch (the CSR arguments); smaller batches
- * evi_dde_node_struct's node-parallel launches. */
-int evi_dde_node_struct_edges(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,
-                              const int64_t* node_ptr, const int64_t* edge_ptr, const int64_t* edge_index, int64_t E, int B,
-                              const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr, const int32_t* out_nbr,
-                              int rounds, int rev_rounds, float* node_struct, void* stream);
 
 /* ---- S1-S6: the edge scorer ------------------------------------------------------------------- */
 
