@@ -781,26 +781,10 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
     enc.use_graphs = False
     wall_pe, issue_pe, same_pe = run_pipelined()
     enc.use_graphs = True
-    # The three stages do not overlap by themselves: a scan workgroup (1 024 threads x 128 registers) owns a CU's whole register
-    # file, a scorer GEMM workgroup 128 KiB of its LDS, so the encoder's small kernels queue behind them although they need a
-    # fraction of the chip.  CU-masked streams (hipExtStreamCreateWithCUMask) give the encoder `enc_cus` CUs of its own and keep
-    # the scan / scorer streams off them: the 2.3 ms encoder stage then runs beside the other two instead of between them.
-    partition = None
-    try:
-        from evi_rag_amd import streams as evs
-
-        enc_cus = int(os.environ.get("EVI_E2E_ENCODER_CUS", "16"))
-        ps_enc, ps_rest_a, ps_rest_b = evs.partitioned_streams(dev, [enc_cus, None, None])
-        saved_streams = (s_enc, s_topk, s_sc)
-        s_enc, s_topk, s_sc = ps_enc, ps_rest_a, ps_rest_b
-        wall_pp, issue_pp, same_pp = run_pipelined()
-        s_enc, s_topk, s_sc = saved_streams
-        partition = {"what": f"the same pipeline on CU-masked streams: {enc_cus} CUs for the encoder stream, the other "
-                             f"{evs.cu_count(dev) - enc_cus} for the top-k and the scorer + metrics streams",
-                     "queries_per_s": questions * iters / wall_pp, "ms_per_batch": wall_pp / iters * 1e3,
-                     "host_issue_ms_per_batch": issue_pp / iters * 1e3, "last_topk_identical_to_f32_scan": same_pp}
-    except Exception as exc:  # noqa: BLE001 - informational leg
-        partition = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+    # (The three stages do not overlap by themselves: a scan workgroup — 1 024 threads x 128 registers — owns a CU's whole register
+    # file, a scorer GEMM workgroup 128 KiB of its LDS, so the encoder's small kernels queue behind whole workgroups.  CU-masked
+    # streams (hipExtStreamCreateWithCUMask: 16 CUs for the encoder stream, 240 for the other two) were tried in round 3 to let it
+    # run beside them: 25.2 ms per batch against 8.5 ms — masked queues cost far more than the overlap gives.  Not kept.)
     res = {"workload": f"{questions} questions per batch: encode (random-init BERT {layers}L/{D}H, f32) -> top-{k} over {rows} x {D} f32 "
                        f"-> scorer on {questions} WebQSP-shaped graphs (E={sb.num_edges}, D=H={D}, logits only) -> fused metrics",
            "what": "encode | exact top-k | scorer + metrics on three HIP streams, two buffer slots, library defaults (graph-replayed "
@@ -808,7 +792,6 @@ def bench_end_to_end(dev, D, *, rows, k, seed, questions=32, iters=12, warmup=3,
                    "neighbouring batches",
            "queries_per_s": questions * iters / wall_p, "ms_per_batch": wall_p / iters * 1e3,
            "host_issue_ms_per_batch": issue_p / iters * 1e3,
-           "cu_partition": partition,
            "eager_encoder": {"what": "the same pipeline with TextEncoder.use_graphs = False", "queries_per_s": questions * iters / wall_pe,
                              "ms_per_batch": wall_pe / iters * 1e3, "host_issue_ms_per_batch": issue_pe / iters * 1e3,
                              "last_topk_identical_to_f32_scan": same_pe},
