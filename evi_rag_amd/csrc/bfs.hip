@@ -328,10 +328,6 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
                 pr[r] = ok ? ((uint32_t)(a[r] - n0) | ((uint32_t)(b[r] - n0) << 16)) : 0u;
             }
         }
-        unsigned live = 0;  // bit r: edge r of this thread can still discover a node (self loops and padding never can)
-#pragma unroll
-        for (int r = 0; r < kBfsEdgeRegs; ++r)
-            if ((pr[r] & 0xFFFFu) != (pr[r] >> 16)) live |= 1u << r;
         __syncthreads();
         for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
             const int64_t s0 = src_idx[i];
@@ -342,22 +338,17 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
             // three rotating flags: level L raises flag[L % 3]; flag[(L + 1) % 3] is cleared meanwhile — nobody reads it before
             // the end of level L + 1, and the flag read at the end of level L - 1 is a different one
             if (tid == 0) s_changed[(level + 1) % 3] = 0;
-            // An edge whose endpoints both carry a level can never discover anything again: it is dropped from the thread's
-            // live set, so the later levels of a search read less and less of the LDS (measured: the level loop IS LDS traffic —
-            // 24 random 16-bit reads per thread and level, ~3 us per level for 10 000 edges on one CU)
+            // (dropping edges whose endpoints are both settled from the thread's live set was tried: 34.6 against 34.7 us — the
+            // ~3 us per level are not the LDS reads; the CSR-based frontier search costs 4 us per level on the same graphs)
             int du[kBfsEdgeRegs], dv[kBfsEdgeRegs];
 #pragma unroll
             for (int r = 0; r < kBfsEdgeRegs; ++r) {
-                du[r] = dv[r] = 0;
-                if (live & (1u << r)) {
-                    du[r] = d16[pr[r] & 0xFFFFu];
-                    dv[r] = d16[pr[r] >> 16];
-                }
+                du[r] = d16[pr[r] & 0xFFFFu];
+                dv[r] = d16[pr[r] >> 16];
             }
             bool any = false;
 #pragma unroll
             for (int r = 0; r < kBfsEdgeRegs; ++r) {
-                if (!(live & (1u << r))) continue;
                 if (mode != 2 && du[r] == level && dv[r] < 0) {
                     d16[pr[r] >> 16] = (int16_t)(level + 1);
                     any = true;
@@ -366,7 +357,6 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
                     d16[pr[r] & 0xFFFFu] = (int16_t)(level + 1);
                     any = true;
                 }
-                if (du[r] >= 0 && dv[r] >= 0) live &= ~(1u << r);
             }
             if (any) s_changed[level % 3] = 1;
             __syncthreads();

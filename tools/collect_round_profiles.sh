@@ -3,7 +3,7 @@
 # Usage: bash tools/collect_round_profiles.sh rNN   -> writes gpurun_out/rNN_profiles/ (summaries only; traces are deleted, the
 # merge back from the box is capped at 64 MiB).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${TAG}_profiles
 S=/tmp/evi_prof_$$
@@ -52,9 +52,9 @@ echo "per-kernel traffic done"
 
 # 3. SQ counters: scorer forward (+backward), graph kernels, the headline scan
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $S/sq_scorer -o sq -- python3 $R/tools/scorer_forward_profile.py full > /dev/null 2> $O/sq_scorer.err || exit 4
-python3 $R/tools/pmc_kernels.py $S/sq_scorer/sq_counter_collection.csv --match k_gemm k_edge k_state k_split k_combine --out $O/${TAG}_pmc_sq_scorer.json --note "tools/scorer_forward_profile.py full (config-3 batch, D=H=768)" > /dev/null
+python3 $R/tools/pmc_kernels.py $S/sq_scorer/sq_counter_collection.csv --match k_gemm k_edge k_state k_split k_round k_combine --out $O/${TAG}_pmc_sq_scorer.json --note "tools/scorer_forward_profile.py full (config-3 batch, D=H=768)" > /dev/null
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $S/sq_scan -o sq -- python3 $R/bench.py $SMALL --no-two-stage > /dev/null 2> $O/sq_scan.err || exit 5
-python3 $R/tools/pmc_kernels.py $S/sq_scan/sq_counter_collection.csv --match k_cosine k_candidates k_query --out $O/${TAG}_pmc_sq_scan.json --note "bench.py headline scan (config 2, f32)" > /dev/null
+python3 $R/tools/pmc_kernels.py $S/sq_scan/sq_counter_collection.csv --match k_cosine k_candidates k_query --split-by-grid --out $O/${TAG}_pmc_sq_scan.json --note "bench.py headline scan (config 2, f32); one entry per launch size: the 65 536-row segment does not saturate the 32-bit SQ accumulators" > /dev/null
 echo "sq done"
 
 # 4. kernel stats of the scorer forward/backward and the graph kernels on their own

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--match", nargs="*", default=[])
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--split-by-grid", action="store_true",
+                    help="one entry per (kernel, grid size): the scan launches three segment sizes per step, and the 32-bit SQ "
+                         "accumulators saturate on the two long ones — the short (65 536-row) launch gives the unsaturated figure")
     a = ap.parse_args()
     per = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values (one per dispatch)
     with open(a.csv, newline="") as fh:
@@ -28,6 +31,9 @@ def main():
             if a.match and not any(m in name for m in a.match):
                 continue
             short = re.sub(r"\(.*", "", name)  # drop the argument list, keep the template arguments
+            if a.split_by_grid:
+                grid = row.get("Grid_Size") or row.get("Grid_Size_X") or "?"
+                short = f"{short} [grid {grid}]"
             per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     out = {"source": a.csv, "note": a.note, "kernels": {}}
     for k, counters in sorted(per.items()):
