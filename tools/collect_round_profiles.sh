@@ -54,7 +54,7 @@ echo "per-kernel traffic done"
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $S/sq_scorer -o sq -- python3 $R/tools/scorer_forward_profile.py full > /dev/null 2> $O/sq_scorer.err || exit 4
 python3 $R/tools/pmc_kernels.py $S/sq_scorer/sq_counter_collection.csv --match k_gemm k_edge k_state k_split k_round k_combine --out $O/${TAG}_pmc_sq_scorer.json --note "tools/scorer_forward_profile.py full (config-3 batch, D=H=768)" > /dev/null
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $S/sq_scan -o sq -- python3 $R/bench.py $SMALL --no-two-stage > /dev/null 2> $O/sq_scan.err || exit 5
-python3 $R/tools/pmc_kernels.py $S/sq_scan/sq_counter_collection.csv --match k_cosine k_candidates k_query --split-by-grid --out $O/${TAG}_pmc_sq_scan.json --note "bench.py headline scan (config 2, f32); one entry per launch size: the 65 536-row segment does not saturate the 32-bit SQ accumulators" > /dev/null
+python3 $R/tools/pmc_kernels.py $S/sq_scan/sq_counter_collection.csv --match k_cosine k_candidates k_query --out $O/${TAG}_pmc_sq_scan.json --note "bench.py headline scan (config 2, f32); unsaturated_dispatches = the figures from the launches (the 65 536-row first segment) whose 32-bit SQ accumulators did not pin" > /dev/null
 echo "sq done"
 
 # 4. kernel stats of the scorer forward/backward and the graph kernels on their own

@@ -25,6 +25,7 @@ def main():
                          "accumulators saturate on the two long ones — the short (65 536-row) launch gives the unsaturated figure")
     a = ap.parse_args()
     per = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values (one per dispatch)
+    by_dispatch = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> dispatch id -> counter -> value
     with open(a.csv, newline="") as fh:
         for row in csv.DictReader(fh):
             name = row["Kernel_Name"]
@@ -35,6 +36,7 @@ def main():
                 grid = row.get("Grid_Size") or row.get("Grid_Size_X") or "?"
                 short = f"{short} [grid {grid}]"
             per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            by_dispatch[short][row.get("Dispatch_Id", len(per[short][row["Counter_Name"]]))][row["Counter_Name"]] = float(row["Counter_Value"])
     out = {"source": a.csv, "note": a.note, "kernels": {}}
     for k, counters in sorted(per.items()):
         mean = {c: sum(v) / len(v) for c, v in counters.items()}
@@ -50,6 +52,20 @@ def main():
             w = mean["SQ_WAVE_CYCLES"]
             entry["wave_cycle_split"] = {"active": mean.get("SQ_ACTIVE_INST_ANY", 0) / w, "issue_stall": mean.get("SQ_WAIT_INST_ANY", 0) / w,
                                          "parked": mean.get("SQ_WAIT_ANY", 0) / w}
+        if sat:
+            # the same derived figures from the dispatches in which NO counter pinned (the scan's short first segment): the 32-bit
+            # accumulators saturate on the long launches only
+            ok = [c for c in by_dispatch[k].values() if all(v < 2147483648.0 for v in c.values())]
+            if ok:
+                m2 = {c: sum(d[c] for d in ok if c in d) / len(ok) for c in ok[0]}
+                sub = {"dispatches": len(ok), "per_dispatch_mean": m2}
+                if m2.get("SQ_BUSY_CU_CYCLES", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in m2:
+                    sub["mfma_busy_fraction_per_simd"] = m2["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * m2["SQ_BUSY_CU_CYCLES"])
+                if m2.get("SQ_WAVE_CYCLES", 0) > 0:
+                    w2 = m2["SQ_WAVE_CYCLES"]
+                    sub["wave_cycle_split"] = {"active": m2.get("SQ_ACTIVE_INST_ANY", 0) / w2, "issue_stall": m2.get("SQ_WAIT_INST_ANY", 0) / w2,
+                                               "parked": m2.get("SQ_WAIT_ANY", 0) / w2}
+                entry["unsaturated_dispatches"] = sub
         out["kernels"][k] = entry
     with open(a.out, "w") as fh:
         json.dump(out, fh, indent=1)
