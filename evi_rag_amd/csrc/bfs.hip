@@ -307,8 +307,9 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
     int32_t* out = dist_out + dist_off[j];  // local node id -> level
     if (ng <= 32767 && ne64 <= (int64_t)kBfsEdgeRegs * kBfsThreads && (ng + 1) / 2 <= lds_nodes) {
         const int ne = (int)ne64;
-        int16_t* d16 = reinterpret_cast<int16_t*>(lds_dist);
-        for (int v = tid; v < ng; v += kBfsThreads) d16[v] = -1;
+        constexpr unsigned kInf = 0x7FFFu;  // "no level yet" (levels stay below it: N_g <= 32 767)
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(lds_dist);
+        for (int v = tid; v < ng; v += kBfsThreads) d16[v] = (uint16_t)kInf;
         if (tid < 3) s_changed[tid] = 0;
         // this thread's edges, all loads issued before the first use; an edge past the end, or with an endpoint outside the graph
         // (validated upstream), becomes the self loop (0, 0), which no level can cross
@@ -328,41 +329,57 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
                 pr[r] = ok ? ((uint32_t)(a[r] - n0) | ((uint32_t)(b[r] - n0) << 16)) : 0u;
             }
         }
+        unsigned live = 0;  // bit r: edge r can still discover a node (self loops and padding never can)
+#pragma unroll
+        for (int r = 0; r < kBfsEdgeRegs; ++r)
+            if ((pr[r] & 0xFFFFu) != (pr[r] >> 16)) live |= 1u << r;
         __syncthreads();
         for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
             const int64_t s0 = src_idx[i];
             if (s0 >= n0 && s0 < n1) d16[s0 - n0] = 0;  // out-of-range sources are ignored (:619)
         }
         __syncthreads();
+        // The level loop is bound by instruction issue, not by LDS or memory (measured: ~3 us per level for 10 000 edges on one
+        // CU whatever is read; a wave64 vector instruction takes 4 cycles and four waves share a SIMD).  So: (a) an edge whose
+        // endpoints both carry a level is dead, and a register slot r that is dead in ALL 64 lanes is skipped by a scalar branch
+        // — from the third or fourth level on most slots are; (b) the undirected test is  min == L and max == INF  on the pair
+        // of levels: one comparison chain and one store instead of two.
         for (int level = 0;; ++level) {
             // three rotating flags: level L raises flag[L % 3]; flag[(L + 1) % 3] is cleared meanwhile — nobody reads it before
             // the end of level L + 1, and the flag read at the end of level L - 1 is a different one
             if (tid == 0) s_changed[(level + 1) % 3] = 0;
-            // (dropping edges whose endpoints are both settled from the thread's live set was tried: 34.6 against 34.7 us — the
-            // ~3 us per level are not the LDS reads; the CSR-based frontier search costs 4 us per level on the same graphs)
-            int du[kBfsEdgeRegs], dv[kBfsEdgeRegs];
-#pragma unroll
-            for (int r = 0; r < kBfsEdgeRegs; ++r) {
-                du[r] = d16[pr[r] & 0xFFFFu];
-                dv[r] = d16[pr[r] >> 16];
-            }
             bool any = false;
 #pragma unroll
             for (int r = 0; r < kBfsEdgeRegs; ++r) {
-                if (mode != 2 && du[r] == level && dv[r] < 0) {
-                    d16[pr[r] >> 16] = (int16_t)(level + 1);
-                    any = true;
+                const bool alive = (live >> r) & 1u;
+                if (__ballot(alive) == 0ull) continue;  // wave-uniform: nobody's slot r can discover anything any more
+                const unsigned ua = pr[r] & 0xFFFFu, va = pr[r] >> 16;
+                unsigned du = kInf, dv = kInf;
+                if (alive) {
+                    du = d16[ua];
+                    dv = d16[va];
                 }
-                if (mode != 1 && dv[r] == level && du[r] < 0) {
-                    d16[pr[r] & 0xFFFFu] = (int16_t)(level + 1);
-                    any = true;
+                if (!alive) continue;
+                const unsigned lo = du < dv ? du : dv, hi = du < dv ? dv : du;
+                if (hi != kInf) {  // both settled: dead from now on
+                    live &= ~(1u << r);
+                    continue;
                 }
+                if (lo != (unsigned)level) continue;
+                // exactly one endpoint is on the frontier, the other has no level yet: does the orientation allow the step?
+                const bool from_u = du == (unsigned)level;
+                if ((mode == 1 && !from_u) || (mode == 2 && from_u)) continue;
+                d16[from_u ? va : ua] = (uint16_t)(level + 1);
+                any = true;
             }
             if (any) s_changed[level % 3] = 1;
             __syncthreads();
             if (!s_changed[level % 3]) break;  // uniform: the frontier did not grow
         }
-        for (int v = tid; v < ng; v += kBfsThreads) out[v] = d16[v];
+        for (int v = tid; v < ng; v += kBfsThreads) {
+            const unsigned d = d16[v];
+            out[v] = d == kInf ? -1 : (int32_t)d;
+        }
         return;
     }
     // ---- beyond the LDS budget: the CSR-based search (rows from the L2), as k_bfs_levels

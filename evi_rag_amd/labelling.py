@@ -46,16 +46,25 @@ class GraphBatch:
         if s_all.shape[0] != d_all.shape[0]:
             raise ValueError("edge_src and edge_dst differ in length")
         g_of = np.repeat(np.arange(B, dtype=np.int64), cnt0)
-        n_of = np.asarray(num_nodes, np.int64).reshape(-1)[g_of] if B else np.empty(0, np.int64)
-        ok = (s_all >= 0) & (d_all >= 0) & (s_all < n_of) & (d_all < n_of)  # _valid_edge_indices (:638-647)
-        keep = np.nonzero(ok)[0]
-        g_keep = g_of[keep]
-        counts = np.bincount(g_keep, minlength=B).astype(np.int64) if B else np.empty(0, np.int64)
-        self.edge_ptr_h = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        pos = keep - off0[g_keep]  # position of every kept edge in its own graph's original list
-        self.valid_ids = np.split(pos, self.edge_ptr_h[1:-1]) if B else []
-        base = self.node_ptr_h[g_keep]
-        ei = np.stack([s_all[keep] + base, d_all[keep] + base]) if B else np.empty((2, 0), np.int64)
+        n_of = nn[g_of] if B else np.empty(0, np.int64)
+        # _valid_edge_indices (:638-647): 0 <= s, d < n — as unsigned compares (a negative id is a huge unsigned one): two passes
+        ok = (s_all.view(np.uint64) < n_of.view(np.uint64)) & (d_all.view(np.uint64) < n_of.view(np.uint64))
+        base = self.node_ptr_h[g_of] if B else np.empty(0, np.int64)
+        if bool(ok.all()):
+            # the common case (graphs out of build_graph): nothing to filter, no index arrays — positions map to themselves
+            self.valid_ids = None
+            self.edge_ptr_h = off0
+            ei = np.empty((2, s_all.shape[0]), np.int64)
+            np.add(s_all, base, out=ei[0])
+            np.add(d_all, base, out=ei[1])
+        else:
+            keep = np.nonzero(ok)[0]
+            g_keep = g_of[keep]
+            counts = np.bincount(g_keep, minlength=B).astype(np.int64) if B else np.empty(0, np.int64)
+            self.edge_ptr_h = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            pos = keep - off0[g_keep]  # position of every kept edge in its own graph's original list
+            self.valid_ids = np.split(pos, self.edge_ptr_h[1:-1]) if B else []
+            ei = np.stack([s_all[keep] + base[keep], d_all[keep] + base[keep]]) if B else np.empty((2, 0), np.int64)
         self.edge_index = torch.from_numpy(np.ascontiguousarray(ei)).to(dev)
         self.node_ptr = torch.from_numpy(self.node_ptr_h).to(dev)
         self.edge_ptr = torch.from_numpy(self.edge_ptr_h).to(dev)
@@ -377,7 +386,7 @@ def shortest_path_single_batch(gb: GraphBatch, sources: Sequence[Sequence[int]],
         if L < 0:
             results.append(([], []))
             continue
-        edges = gb.valid_ids[g][edges_h[g, :L]].tolist()  # back to positions in the caller's edge list
+        edges = (edges_h[g, :L] if gb.valid_ids is None else gb.valid_ids[g][edges_h[g, :L]]).tolist()  # back to positions in the caller's edge list
         results.append((edges, nodes_h[g, : L + 1].tolist()))
     return results
 
