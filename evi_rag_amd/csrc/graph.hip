@@ -556,12 +556,11 @@ __global__ __launch_bounds__(256) void k_dde_round(const float* __restrict__ top
 // ---- DDE, one workgroup per graph: the whole feature block of the graph lives in LDS ---------------------------------
 // The node-parallel kernel above gathers 8 bytes of a neighbour's previous column out of its 40-byte ns row: at 512 graphs
 // per batch the ns array (61 MB) is far beyond the L2s, every gather pulls a whole line from memory, and the memory-side
-// counters show 3.7x the algorithmic bytes at 5.6 TB/s — HBM-bound on over-fetch (profiles/r03_pmc_graph.json).  Here a
-// graph's [N_g, C * S] block is built IN LDS — column 0 from the topic one-hot, every round reads column jin and writes
-// column jout of the same block (distinct columns: no ping-pong), rounds separated by workgroup barriers — and written to
-// global memory once, coalesced.  Memory traffic: the neighbour lists (once per round, the second round of a chain from the
-// L2), the row pointers, the topic rows in and the ns rows out.  Worth it when there are enough graphs to fill the chip
-// (one workgroup per graph); a graph whose block does not fit the LDS runs the same code on its global ns rows.
+// counters show 3.7x the algorithmic bytes at 5.6 TB/s — HBM-bound on over-fetch (profiles/r03_pmc_graph_before_lds_kernels.json).
+// Here one workgroup owns a graph: the propagated state, the row pointers and the neighbour lists (16-bit local ids) of the side
+// being walked live in LDS, rounds are separated by workgroup barriers, every round's column goes straight to the graph's ns
+// rows.  Memory traffic: each side's rows once, the topic rows in, the ns columns out.  A graph that does not fit the LDS runs
+// the row-walking rounds on its global ns rows (dde_graph_rounds).
 // (An edge-parallel variant — the edge list in LDS, acc[dst] += x[src] with f64 LDS atomic adds, exact and order-free — was built
 // and measured in round 3: 100 us per CWQ-shaped graph against 84 us for this kernel and 30 us per BATCH of 32 for the
 // node-parallel one: 80 000 ds_add_f64 per graph run at ~2.5 cycles each.  Removed.)
@@ -653,32 +652,159 @@ __device__ inline void dde_graph_rounds(F* __restrict__ st, int W, int S, int ng
     }
 }
 
+// One mean-propagation round on LDS-resident rows: xn[v] = mean over row(v) of xc[u]; also ns[v][c * S + jout] (global).
+// ptr: [ng + 1] row offsets relative to the graph's first slot; nbr: local ids as 16-bit.
+template <int C>
+__device__ inline void dde_lds_round(const float* __restrict__ xc, float* __restrict__ xn, const int32_t* __restrict__ ptr,
+                                     const uint16_t* __restrict__ nbr, int ng, float* __restrict__ nsg, int W, int S, int jout) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ngpad = (ng + 63) / 64 * 64;
+    for (int v = tid; v < ngpad; v += kGraphThreads) {  // whole waves: hub rows are summed by all 64 lanes
+        const bool live = v < ng;
+        int b = 0, e = 0;
+        if (live) {
+            b = ptr[v];
+            e = ptr[v + 1];
+        }
+        const int deg = e - b;
+        const bool hub = deg > kHubDegree;
+        if (live && !hub) {
+            double acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = 0.0;
+            for (int p = b; p < e; p += 4) {  // four neighbours per trip, reads first
+                int u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = nbr[p + i < e ? p + i : e - 1];
+                float x[4][C];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) x[i][c] = xc[u[i] * C + c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p + i < e) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] += (double)x[i][c];
+                    }
+            }
+            const float cnt = deg > 0 ? (float)deg : 1.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float val = (float)acc[c] / cnt;
+                xn[v * C + c] = val;
+                nsg[v * W + c * S + jout] = val;
+            }
+        }
+        unsigned long long hubs = __ballot(hub);
+        while (hubs) {
+            const int l = __ffsll((long long)hubs) - 1;
+            hubs &= hubs - 1;
+            const int hb = __shfl(b, l, 64), he = __shfl(e, l, 64);
+            const int hv = v - lane + l;
+            double acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = 0.0;
+            for (int p = hb + lane; p < he; p += 256) {
+                int u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = nbr[p + 64 * i < he ? p + 64 * i : he - 1];
+                float x[4][C];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) x[i][c] = xc[u[i] * C + c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p + 64 * i < he) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] += (double)x[i][c];
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+            if (lane == 0) {
+                const float cnt = (float)(he - hb);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float val = (float)acc[c] / cnt;
+                    xn[hv * C + c] = val;
+                    nsg[hv * W + c * S + jout] = val;
+                }
+            }
+        }
+    }
+}
+
+// LDS (ints): x0 [ng C] | x1 [ng C] | ptr [ng + 1] | nbr16 [ceil(ne / 2)] — the rows of ONE side at a time (the forward chain
+// walks in-rows, the reverse chain out-rows; the side is reloaded between the chains): a CWQ graph needs 12 + 12 + 12 + 20 KB.
+// Everything a round touches is then on chip: the state, the row pointers AND the neighbour lists — the first version of this
+// kernel kept the whole [N_g, 10] output block in LDS instead and read the neighbour lists from global memory: every hub row
+// (summed by one wave, one hub after the other) paid a fresh memory latency, 84 us per CWQ-shaped graph.
 template <int C>
 __global__ __launch_bounds__(kGraphThreads) void k_dde_graph(const float* __restrict__ topic, int topic_stride, float* __restrict__ ns,
                                                              int S, const int64_t* __restrict__ node_ptr,
                                                              const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
                                                              const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
                                                              int rounds, int rev_rounds) {
-    extern __shared__ float lds_ns[];  // [N_g][C * S]
+    extern __shared__ __attribute__((aligned(16))) float lds_ns[];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
     const int ng = (int)(n1 - n0);
     const int W = C * S;
-    if ((int64_t)ng * W <= kDdeGraphLdsFloats) {
+    float* __restrict__ nsg = ns + n0 * W;
+    const int e0 = in_ptr[n0];
+    const int ne = in_ptr[n1] - e0;  // valid entries of either half
+    for (int v = tid; v < ng; v += kGraphThreads)
+#pragma unroll
+        for (int c = 0; c < C; ++c) nsg[v * W + c * S] = topic[(n0 + v) * topic_stride + c];  // column 0: the one-hot itself
+    if (ng > 65535 || 2 * (int64_t)ng * C + (ng + 1) + (ne + 1) / 2 > kDdeGraphLdsFloats) {
+        // does not fit: the same rounds on the graph's global ns rows, rows from global memory
+        __syncthreads();
+        dde_graph_rounds<C>(nsg, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
+        return;
+    }
+    float* x0 = lds_ns;
+    float* x1 = x0 + ng * C;
+    int32_t* l_ptr = reinterpret_cast<int32_t*>(x1 + ng * C);
+    uint16_t* l_nbr = reinterpret_cast<uint16_t*>(l_ptr + ng + 1);
+    for (int chain = 0; chain < 2; ++chain) {
+        const int nr = chain ? rev_rounds : rounds;
+        if (nr == 0) continue;
+        const int32_t* __restrict__ gptr = chain ? out_ptr : in_ptr;
+        const int32_t* __restrict__ gnbr = chain ? out_nbr : in_nbr;
+        __syncthreads();  // the previous chain is done with the LDS
         for (int v = tid; v < ng; v += kGraphThreads)
 #pragma unroll
-            for (int c = 0; c < C; ++c) lds_ns[v * W + c * S] = topic[(n0 + v) * topic_stride + c];
-        __syncthreads();
-        dde_graph_rounds<C>(lds_ns, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
-        float* __restrict__ dst = ns + n0 * W;
-        for (int i = tid; i < ng * W; i += kGraphThreads) dst[i] = lds_ns[i];  // one coalesced pass out
-    } else {  // the block does not fit: the same rounds on the graph's global ns rows
-        float* st = ns + n0 * W;
-        for (int v = tid; v < ng; v += kGraphThreads)
+            for (int c = 0; c < C; ++c) x0[v * C + c] = topic[(n0 + v) * topic_stride + c];  // a chain starts from the one-hot
+        for (int i0 = tid; i0 <= ng; i0 += 8 * kGraphThreads) {  // eight per trip, loads first
+            int t[8];
 #pragma unroll
-            for (int c = 0; c < C; ++c) st[v * W + c * S] = topic[(n0 + v) * topic_stride + c];
+            for (int u = 0; u < 8; ++u) t[u] = gptr[n0 + (i0 + u * kGraphThreads <= ng ? i0 + u * kGraphThreads : ng)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * kGraphThreads <= ng) l_ptr[i0 + u * kGraphThreads] = t[u] - e0;
+        }
+        for (int i0 = tid; i0 < ne; i0 += 8 * kGraphThreads) {
+            int t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = gnbr[e0 + (i0 + u * kGraphThreads < ne ? i0 + u * kGraphThreads : ne - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * kGraphThreads < ne) l_nbr[i0 + u * kGraphThreads] = (uint16_t)(t[u] - (int)n0);
+        }
         __syncthreads();
-        dde_graph_rounds<C>(st, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
+        float* xc = x0;
+        float* xn = x1;
+        for (int j = 1; j <= nr; ++j) {
+            dde_lds_round<C>(xc, xn, l_ptr, l_nbr, ng, nsg, W, S, chain ? rounds + j : j);
+            __syncthreads();
+            float* t = xc;
+            xc = xn;
+            xn = t;
+        }
     }
 }
 
