@@ -297,12 +297,8 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
     __shared__ BfsShared sh;
     __shared__ BfsQueueShared shq;
     __shared__ int s_changed[3];
-    __shared__ long long s_ts[24];
     extern __shared__ int32_t lds_dist[];
-    const bool dbg = (mode & 0x100) != 0;
-    mode &= 0xFF;
     const int j = blockIdx.x, tid = threadIdx.x;
-    if (dbg && tid == 0) s_ts[0] = wall_clock64();
     const int g = job_graph[j];
     const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
     const int64_t e0 = edge_ptr[g], e1 = edge_ptr[g + 1];
@@ -343,17 +339,16 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
             if (s0 >= n0 && s0 < n1) d16[s0 - n0] = 0;  // out-of-range sources are ignored (:619)
         }
         __syncthreads();
-        // The level loop is bound by instruction issue, not by LDS or memory (measured: ~3 us per level for 10 000 edges on one
-        // CU whatever is read; a wave64 vector instruction takes 4 cycles and four waves share a SIMD).  So: (a) an edge whose
-        // endpoints both carry a level is dead, and a register slot r that is dead in ALL 64 lanes is skipped by a scalar branch
-        // — from the third or fourth level on most slots are; (b) the undirected test is  min == L and max == INF  on the pair
-        // of levels: one comparison chain and one store instead of two.
-        if (dbg && tid == 0) s_ts[1] = wall_clock64();
+        // Where the time goes (wall_clock64 stamps of thread 0 on a CWQ-shaped graph, round 3): 4.0 us to load the edges and
+        // initialise, then 1.7-2.7 us per level — ~350 instructions per wave and level with four waves per SIMD, i.e. instruction
+        // issue on ONE CU, not LDS or memory; plus ~9 us of launch and drain around the kernel.  Two things trim the work per
+        // level without changing that picture (34.3 against 34.7 us per batch of 32): an edge whose endpoints both carry a level is
+        // dead, and a register slot that is dead in all 64 lanes is skipped by a scalar branch; the undirected test is
+        // min == L and max == INF on the pair of levels — one comparison chain and one store instead of two.
         for (int level = 0;; ++level) {
             // three rotating flags: level L raises flag[L % 3]; flag[(L + 1) % 3] is cleared meanwhile — nobody reads it before
             // the end of level L + 1, and the flag read at the end of level L - 1 is a different one
             if (tid == 0) s_changed[(level + 1) % 3] = 0;
-            if (dbg && tid == 0 && level < 20) s_ts[2 + level] = wall_clock64();
             bool any = false;
 #pragma unroll
             for (int r = 0; r < kBfsEdgeRegs; ++r) {
@@ -385,13 +380,6 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
         for (int v = tid; v < ng; v += kBfsThreads) {
             const unsigned d = d16[v];
             out[v] = d == kInf ? -1 : (int32_t)d;
-        }
-        if (dbg) {  // timing probe (tools): wall-clock ticks of thread 0 at start / after the load / at every level / at the end
-            __syncthreads();
-            if (tid == 0) {
-                s_ts[23] = wall_clock64();
-                for (int i = 0; i < 24 && i < ng; ++i) out[i] = (int32_t)(s_ts[i] - s_ts[0]);
-            }
         }
         return;
     }
@@ -616,7 +604,7 @@ extern "C" int evi_bfs_levels_edges(const int32_t* job_graph, const int64_t* src
                                     const int64_t* edge_index, int64_t E, const int32_t* in_ptr, const int32_t* in_nbr,
                                     const int32_t* out_ptr, const int32_t* out_nbr, int mode, int32_t* dist_out, void* stream) {
     EVI_REQUIRE(num_jobs >= 0, "evi_bfs_levels_edges: num_jobs must be >= 0");
-    EVI_REQUIRE((mode & 0xFF) >= 0 && (mode & 0xFF) <= 2, "evi_bfs_levels_edges: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
+    EVI_REQUIRE(mode >= 0 && mode <= 2, "evi_bfs_levels_edges: mode must be 0 (undirected), 1 (forward) or 2 (backward)");
     if (num_jobs == 0) return EVI_OK;
     EVI_REQUIRE(job_graph && src_ptr && dist_off && node_ptr && edge_ptr && in_ptr && out_ptr && dist_out, "evi_bfs_levels_edges: null pointer");
     EVI_REQUIRE(E == 0 || edge_index, "evi_bfs_levels_edges: null edge_index");
