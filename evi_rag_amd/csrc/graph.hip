@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kGraphThreads) void k_dde_graph(const float* __rest
                                                              int S, const int64_t* __restrict__ node_ptr,
                                                              const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_nbr,
                                                              const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_nbr,
-                                                             int rounds, int rev_rounds) {
+                                                             int rounds, int rev_rounds, int lds_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds_ns[];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int64_t n0 = node_ptr[g], n1 = node_ptr[g + 1];
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kGraphThreads) void k_dde_graph(const float* __rest
     for (int v = tid; v < ng; v += kGraphThreads)
 #pragma unroll
         for (int c = 0; c < C; ++c) nsg[v * W + c * S] = topic[(n0 + v) * topic_stride + c];  // column 0: the one-hot itself
-    if (ng > 65535 || 2 * (int64_t)ng * C + (ng + 1) + (ne + 1) / 2 > kDdeGraphLdsFloats) {
+    if (ng > 65535 || 2 * (int64_t)ng * C + (ng + 1) + (ne + 1) / 2 > lds_floats) {
         // does not fit: the same rounds on the graph's global ns rows, rows from global memory
         __syncthreads();
         dde_graph_rounds<C>(nsg, W, S, ng, n0, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
@@ -960,8 +960,11 @@ extern "C" int evi_dde_node_struct_graphs(const float* topic_one_hot, int topic_
         attr = true;
     }
     const int S = 1 + rounds + rev_rounds;
-    hipLaunchKernelGGL(k_dde_graph<2>, dim3((unsigned)B), dim3(kGraphThreads), kDdeGraphLdsFloats * sizeof(float), st, topic_one_hot,
-                       topic_stride, node_struct, S, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds);
+    // LDS per workgroup: 80 KiB (two graphs per CU: a CWQ-shaped graph needs 78.1 KiB) when the batch's graphs are that small on
+    // average, else 144 KiB (one per CU); a graph that does not fit the chosen size takes the global-memory rounds
+    const int lds_floats = N / B <= 3200 ? 20480 : kDdeGraphLdsFloats;
+    hipLaunchKernelGGL(k_dde_graph<2>, dim3((unsigned)B), dim3(kGraphThreads), (size_t)lds_floats * sizeof(float), st, topic_one_hot,
+                       topic_stride, node_struct, S, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds, lds_floats);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
 }
