@@ -960,9 +960,9 @@ extern "C" int evi_dde_node_struct_graphs(const float* topic_one_hot, int topic_
         attr = true;
     }
     const int S = 1 + rounds + rev_rounds;
-    // LDS per workgroup: 80 KiB (two graphs per CU: a CWQ-shaped graph needs 78.1 KiB) when the batch's graphs are that small on
-    // average, else 144 KiB (one per CU); a graph that does not fit the chosen size takes the global-memory rounds
-    const int lds_floats = N / B <= 3200 ? 20480 : kDdeGraphLdsFloats;
+    // 144 KiB per workgroup, one graph per CU.  (80 KiB — two CWQ-shaped graphs per CU — was measured: 234 against 136 us per
+    // batch of 512, because every graph a little above the average size then falls to the global-memory rounds.)
+    const int lds_floats = kDdeGraphLdsFloats;
     hipLaunchKernelGGL(k_dde_graph<2>, dim3((unsigned)B), dim3(kGraphThreads), (size_t)lds_floats * sizeof(float), st, topic_one_hot,
                        topic_stride, node_struct, S, node_ptr, in_ptr, in_nbr, out_ptr, out_nbr, rounds, rev_rounds, lds_floats);
     EVI_LAUNCH_CHECK();
