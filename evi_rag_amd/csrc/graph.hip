@@ -935,7 +935,9 @@ static int dde_graph_min_batch() {  // read per call (a getenv is nothing next t
     const char* e = getenv("EVI_DDE_MODE");
     if (e && e[0] == 'g') return 1;
     if (e && e[0] == 'n') return 0x7FFFFFFF;
-    return 96;
+    // measured crossover on CWQ-shaped graphs (2 + 2 rounds): node-parallel 63 / 82 / 114 / 146 / 266 us at 96 / 128 / 192 / 256 / 512
+    // graphs per batch, one workgroup per graph 76 / 67 / 75 / 74 / 137 us
+    return 112;
 }
 
 extern "C" int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_topics, int64_t N,

@@ -637,7 +637,7 @@ def dde_node_struct(topic_one_hot: torch.Tensor, node_ptr: torch.Tensor, csr: Gr
                     num_reverse_rounds: int, num_topics: int = 2) -> torch.Tensor:
     """DDE structure features ns [N, num_topics * (1 + rounds + reverse rounds)] (src/models/components/graph.py:41-74,
     retriever.py:519-553): node-parallel launches per round pair for small batches, one workgroup per graph with the graph's
-    feature block in LDS from ~100 graphs per batch on (evi_dde_node_struct_graphs).  Same bits either way."""
+    feature block in LDS from 112 graphs per batch on (evi_dde_node_struct_graphs).  Same bits either way."""
     dev = _require_gpu(topic_one_hot, node_ptr)
     t = _f32c(topic_one_hot, "topic_one_hot")
     if t.dim() == 1:

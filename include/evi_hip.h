@@ -501,7 +501,7 @@ int evi_dde_node_struct(const float* topic_one_hot, int topic_stride, int num_to
                         const int32_t* in_ptr, const int32_t* in_nbr, const int32_t* out_ptr,
                         const int32_t* out_nbr, int rounds, int rev_rounds, float* node_struct, void* stream);
 
-/* The same features with the graph boundaries given (node_ptr [B+1], batch-global): from ~100 graphs per batch on, one
+/* The same features with the graph boundaries given (node_ptr [B+1], batch-global): from 112 graphs per batch on, one
  * workgroup per graph builds the graph's [N_g, C*S] block in LDS (all rounds, workgroup barriers in between) and writes it out
  * once, coalesced — the node-parallel form gathers 8 bytes out of 40-byte rows that no longer fit the L2s at that size
  * (3.7x the algorithmic bytes by the memory-side counters).  Smaller batches take evi_dde_node_struct's path.  Same results
