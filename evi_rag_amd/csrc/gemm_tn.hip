@@ -24,7 +24,10 @@ __device__ inline int slot_tn(int r, int c) { return r * 4 + (c ^ ((r >> 2) & 3)
 }  // namespace
 
 // P1 = 1: one product (hi * hi) — the `bf16-mixed` training precision; no lo planes, half the LDS.
-template <int P1>
+// V2 = 1 (M, N, lda, ldb even, 8-byte aligned operands): a thread owns a PAIR of adjacent columns of an operand and 8 consecutive
+// k — eight 8-byte loads per operand (a wave reads 512 contiguous bytes of a row) instead of sixteen 4-byte ones, two 16-byte
+// LDS writes per plane (image rows 2p and 2p + 1).
+template <int P1, int V2 = 0>
 __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __restrict__ A, int64_t lda, int M,
                                                               const float* __restrict__ B, int64_t ldb, int N, int64_t K,
                                                               int64_t kslice, float* __restrict__ Cparts) {
@@ -51,11 +54,26 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
     // thread's four units (tid & 255) and the k group is wave-uniform (tid >> 8 plus 2 for the odd units): a row's address is
     // a scalar, the lane adds its column.  Loads are unconditional on clamped indices; out-of-range values are zeroed at the store.
     float rv[4][8];
-    const int col = tid & 255;
-    const int kg0 = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int col = V2 ? 2 * (tid & 127) : (tid & 255);  // V2: the first column of the thread's pair
+    const int kg0 = __builtin_amdgcn_readfirstlane(V2 ? (tid >> 7) : (tid >> 8));
     // clamped columns: a column past the edge re-reads the last valid one; what it produces lands in rows / columns of the
     // C tile that are never stored, so it needs no zeroing
-    const unsigned ca = (unsigned)(m0 + col < M ? m0 + col : M - 1), cb = (unsigned)(n0 + col < N ? n0 + col : N - 1);
+    const unsigned ca = V2 ? (unsigned)(m0 + col + 1 < M ? m0 + col : M - 2) : (unsigned)(m0 + col < M ? m0 + col : M - 1);
+    const unsigned cb = V2 ? (unsigned)(n0 + col + 1 < N ? n0 + col : N - 2) : (unsigned)(n0 + col < N ? n0 + col : N - 1);
+    // V2: both units of an operand (its two columns) come from one 8-byte load per k row
+    auto load_pair = [&](int opb, int64_t k0) {
+        const float* src = opb ? B : A;
+        const int64_t ld = opb ? ldb : lda;
+        const unsigned c = opb ? cb : ca;
+        const int64_t kb = k0 + 8 * kg0;  // scalar
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = kb + j < K ? kb + j : K - 1;
+            const float2 x = *reinterpret_cast<const float2*>(src + k * ld + c);
+            rv[2 * opb][j] = x.x;
+            rv[2 * opb + 1][j] = x.y;
+        }
+    };
     auto load_unit = [&](int i, int64_t k0) {
         const bool opb = i >= 2;
         const float* src = opb ? B : A;
@@ -71,7 +89,7 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     auto store_unit = [&](int i, int buf, int64_t k0) {
         const bool opb = i >= 2;
-        const int kg = kg0 + 2 * (i & 1);
+        const int kg = V2 ? kg0 : kg0 + 2 * (i & 1);
         const int64_t left = k_end - (k0 + 8 * kg);  // scalar: how many of the unit's 8 k are inside the slice
         f32x8 v;
 #pragma unroll
@@ -81,7 +99,7 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
             for (int j = 0; j < 8; ++j) v[j] = j < left ? v[j] : 0.f;
         }
         const bf16x8 h = __builtin_convertvector(v, bf16x8);
-        const int s = slot_tn(col, kg);
+        const int s = slot_tn(V2 ? col + (i & 1) : col, kg);
         *reinterpret_cast<bf16x8*>(opb ? &sBhi[buf][s] : &sAhi[buf][s]) = h;
         if (!P1) {
             const f32x8 hf = __builtin_convertvector(h, f32x8);
@@ -99,13 +117,20 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
 
+    auto load_all = [&](int64_t k0) {
+        if (V2) {
+            load_pair(0, k0);
+            load_pair(1, k0);
+        } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_unit(i, k_begin);
+            for (int i = 0; i < 4; ++i) load_unit(i, k0);
+        }
+    };
+    load_all(k_begin);
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_unit(i, 0, k_begin);
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) load_unit(i, k_begin + TK);
+    load_all(k_begin + TK);
     int cur = 0;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += TK) {
         // A fragments are read AHEAD groups before their MFMAs (one group of six MFMAs covers the LDS latency; with one
@@ -145,7 +170,8 @@ __global__ __launch_bounds__(kTThreads) void k_gemm_tn_bf16x3(const float* __res
             // one staging unit in the shadow of this group's MFMAs: split + write the next tile's unit, refetch its registers
             if (g < 4) {
                 store_unit(g, cur ^ 1, k0 + TK);
-                load_unit(g, k0 + 2 * TK);
+                if (!V2) load_unit(g, k0 + 2 * TK);
+                else if (g & 1) load_pair(g >> 1, k0 + 2 * TK);  // both units of the operand have been stored: refetch the pair
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -173,8 +199,14 @@ int launch_gemm_tn_bf16x3(const float* A, int64_t lda, int M, const float* B, in
     if (M <= 0 || N <= 0 || S <= 0) return EVI_OK;
     const dim3 grid((unsigned)(((M + TM - 1) / TM) * ((N + TNN - 1) / TNN) * S));
     const int tok = timing_begin(kTimeGemm, st);
-    if (single) hipLaunchKernelGGL(k_gemm_tn_bf16x3<1>, grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
-    else hipLaunchKernelGGL(k_gemm_tn_bf16x3<0>, grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
+    // 8-byte staging loads when every column pair is aligned and inside the operands (EVI_TN_V2=0: the 4-byte form, for A/B runs)
+    static const bool v2_ok = [] { const char* e = getenv("EVI_TN_V2"); return !(e && e[0] == '0'); }();
+    const bool v2 = v2_ok && M >= 2 && N >= 2 && M % 2 == 0 && N % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 &&
+                    (reinterpret_cast<uintptr_t>(A) & 7) == 0 && (reinterpret_cast<uintptr_t>(B) & 7) == 0;
+    if (single && v2) hipLaunchKernelGGL((k_gemm_tn_bf16x3<1, 1>), grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
+    else if (single) hipLaunchKernelGGL((k_gemm_tn_bf16x3<1, 0>), grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
+    else if (v2) hipLaunchKernelGGL((k_gemm_tn_bf16x3<0, 1>), grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
+    else hipLaunchKernelGGL((k_gemm_tn_bf16x3<0, 0>), grid, dim3(kTThreads), 0, st, A, lda, M, B, ldb, N, K, Ks, Cparts);
     timing_end(tok, st);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
