@@ -148,6 +148,9 @@ def _unique_in_graph(ptr: np.ndarray, idx: np.ndarray, node_ptr_h: np.ndarray):
     return u, ug
 
 
+_PAIR_IDS_BOUND_LIMIT = 1 << 26  # entries (512 MiB of int64): beyond it label_pairs_flat sizes the id buffer from the exact total
+
+
 class FlatPairLabels:
     """Shortest-path labels of a whole batch as FLAT arrays (no per-graph Python objects).
 
@@ -289,6 +292,10 @@ def label_pairs_flat(edge_index: torch.Tensor, node_ptr: torch.Tensor, edge_ptr:
     _lib.check(lib.evi_shortest_path_pairs(0, *args, plen.data_ptr(), pcnt.data_ptr(), mask.data_ptr(), None, None, st))
     poff = torch.zeros(P + 1, dtype=torch.int64, device=dev)
     torch.cumsum(pcnt, 0, dtype=torch.int64, out=poff[1:])
+    if cap > _PAIR_IDS_BOUND_LIMIT:
+        # many pairs on large graphs: the no-read-back bound (every slot holding all its graph's edges) would be gigabytes —
+        # read the exact total back instead (one synchronisation) and allocate that
+        cap = int(poff[-1].item())
     pids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
     _lib.check(lib.evi_shortest_path_pairs(1, *args, plen.data_ptr(), pcnt.data_ptr(), mask.data_ptr(), poff.data_ptr(),
                                            pids.data_ptr(), st))

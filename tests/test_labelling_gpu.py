@@ -125,6 +125,16 @@ def test_flat_labelling_entry_point_matches_oracle(dev):
         res2 = L.shortest_path_union_mask_by_pair_batch(gb, seeds, answers, directed=directed)
         for a, b in zip(res, res2):
             assert a[0].tolist() == b[0].tolist() and tuple(a[1:]) == tuple(b[1:])
+    # the id buffer: sized by the host-side bound without a read-back, or — when that bound is too large — from the exact total
+    ref_flat = L.label_pairs_flat(t(ei), t(node_ptr), t(edge_ptr), sp, si, ap, ai)
+    old_limit, L._PAIR_IDS_BOUND_LIMIT = L._PAIR_IDS_BOUND_LIMIT, 10
+    try:
+        tight = L.label_pairs_flat(t(ei), t(node_ptr), t(edge_ptr), sp, si, ap, ai)
+    finally:
+        L._PAIR_IDS_BOUND_LIMIT = old_limit
+    total = int(ref_flat.pair_edge_off[-1].item())
+    assert tight.pair_edge_ids.numel() == max(total, 1) and ref_flat.pair_edge_ids.numel() >= total
+    assert torch.equal(tight.pair_edge_ids[:total], ref_flat.pair_edge_ids[:total]) and torch.equal(tight.mask, ref_flat.mask)
     # nothing to pair at all
     none = L.label_pairs_flat(t(ei), t(node_ptr), t(edge_ptr), np.zeros(7, np.int64), np.empty(0, np.int64), ap, ai)
     assert none.P == 0 and int(none.mask.sum()) == 0 and all(r[1:] == ([], [], [], [], []) for r in none.per_graph())
