@@ -281,10 +281,11 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels(
 // Measured in round 3: with the graph's CSR rows cached in LDS the frontier search above still took ~4.4 us per level (9 levels,
 // 40 us per CWQ-shaped graph) — not memory but the frontier machinery: queue appends, compare-and-swaps, three tiers of hub
 // expansion, four barriers per level, every LDS access waiting for the one before.  These graphs are SMALL (10^3-10^4 edges):
-// each of the 1 024 threads keeps <= 12 edges as packed 16-bit (u, v) pairs in registers for the whole search, the levels sit
-// in LDS, and a pass over the edges RELAXES them (level[v] = min(level[v], level[u] + 1), see below) — ONE barrier per pass, no
-// CSR, no queue, no hubs, 12 KB of LDS.  Graphs with more than 12 288 edges or 65 535 nodes take the CSR-based search above,
-// inside the same kernel.
+// each of the 1 024 threads keeps <= 12 edges as packed 16-bit (u, v) pairs in registers for the whole search, the levels
+// (16-bit, N_g <= 32 767) sit in LDS, and a level is: read level[u], level[v] of all the thread's edges (24 independent LDS
+// reads, issued back to back), then `level[u] == L and level[v] < 0 -> level[v] = L + 1` (both orientations when undirected) as
+// plain stores — every writer of a node writes the same value — and ONE barrier.  No CSR, no queue, no hubs, 6 KB of LDS.
+// Graphs with more than 12 288 edges or 32 767 nodes take the CSR-based search above, inside the same kernel.
 constexpr int kBfsEdgeRegs = 12;
 
 __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
@@ -304,14 +305,14 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
     const int ng = (int)(n1 - n0);
     const int64_t ne64 = e1 - e0;
     int32_t* out = dist_out + dist_off[j];  // local node id -> level
-    if (ng <= 65535 && ne64 <= (int64_t)kBfsEdgeRegs * kBfsThreads && ng <= lds_nodes) {
+    if (ng <= 32767 && ne64 <= (int64_t)kBfsEdgeRegs * kBfsThreads && (ng + 1) / 2 <= lds_nodes) {
         const int ne = (int)ne64;
-        constexpr unsigned kInf = 0x3FFFFFFFu;  // "no level yet" (+ 1 does not overflow)
-        unsigned* d32 = reinterpret_cast<unsigned*>(lds_dist);
-        for (int v = tid; v < ng; v += kBfsThreads) d32[v] = kInf;
+        constexpr unsigned kInf = 0x7FFFu;  // "no level yet" (levels stay below it: N_g <= 32 767)
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(lds_dist);
+        for (int v = tid; v < ng; v += kBfsThreads) d16[v] = (uint16_t)kInf;
         if (tid < 3) s_changed[tid] = 0;
         // this thread's edges, all loads issued before the first use; an edge past the end, or with an endpoint outside the graph
-        // (validated upstream), becomes the self loop (0, 0), which relaxes nothing
+        // (validated upstream), becomes the self loop (0, 0), which no level can cross
         uint32_t pr[kBfsEdgeRegs];
         {
             int64_t a[kBfsEdgeRegs], b[kBfsEdgeRegs];
@@ -328,52 +329,56 @@ __global__ __launch_bounds__(kBfsThreads) void k_bfs_levels_edges(
                 pr[r] = ok ? ((uint32_t)(a[r] - n0) | ((uint32_t)(b[r] - n0) << 16)) : 0u;
             }
         }
+        unsigned live = 0;  // bit r: edge r can still discover a node (self loops and padding never can)
+#pragma unroll
+        for (int r = 0; r < kBfsEdgeRegs; ++r)
+            if ((pr[r] & 0xFFFFu) != (pr[r] >> 16)) live |= 1u << r;
         __syncthreads();
         for (int64_t i = src_ptr[j] + tid; i < src_ptr[j + 1]; i += kBfsThreads) {
             const int64_t s0 = src_idx[i];
-            if (s0 >= n0 && s0 < n1) d32[s0 - n0] = 0;  // out-of-range sources are ignored (:619)
+            if (s0 >= n0 && s0 < n1) d16[s0 - n0] = 0;  // out-of-range sources are ignored (:619)
         }
         __syncthreads();
         // Where the time goes (wall_clock64 stamps of thread 0 on a CWQ-shaped graph, round 3): 4.0 us to load the edges and
-        // initialise, then 1.7-2.7 us per pass over the edges — ~350 instructions per wave with four waves per SIMD, i.e.
-        // instruction issue on ONE CU, not LDS or memory — plus ~9 us of launch and drain around the kernel.  A strict
-        // level-synchronous search pays one such pass per level (8-9 on these graphs).  So the passes RELAX instead:
-        //     level[v] = min(level[v], level[u] + 1)   (LDS atomicMin, issued only when it improves)
-        // in three sub-passes of four edges whose reads see what every thread wrote in the sub-passes before — a node found in
-        // one sub-pass propagates further in the next, several hops per barrier.  Unit weights: the fixed point of the
-        // relaxation IS the BFS level of every node, whatever order the lanes run in; the loop ends with the first pass that
-        // improves nothing.
-        for (int round = 0;; ++round) {
-            // three rotating flags: round R raises flag[R % 3]; flag[(R + 1) % 3] is cleared meanwhile — nobody reads it before
-            // the end of round R + 1, and the flag read at the end of round R - 1 is a different one
-            if (tid == 0) s_changed[(round + 1) % 3] = 0;
+        // initialise, then 1.7-2.7 us per level — ~350 instructions per wave and level with four waves per SIMD, i.e. instruction
+        // issue on ONE CU, not LDS or memory; plus ~9 us of launch and drain around the kernel.  Two things trim the work per
+        // level without changing that picture (34.3 against 34.7 us per batch of 32): an edge whose endpoints both carry a level is
+        // dead, and a register slot that is dead in all 64 lanes is skipped by a scalar branch; the undirected test is
+        // min == L and max == INF on the pair of levels — one comparison chain and one store instead of two.
+        for (int level = 0;; ++level) {
+            // three rotating flags: level L raises flag[L % 3]; flag[(L + 1) % 3] is cleared meanwhile — nobody reads it before
+            // the end of level L + 1, and the flag read at the end of level L - 1 is a different one
+            if (tid == 0) s_changed[(level + 1) % 3] = 0;
             bool any = false;
 #pragma unroll
-            for (int r0 = 0; r0 < kBfsEdgeRegs; r0 += 4) {
-                unsigned du[4], dv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    du[q] = d32[pr[r0 + q] & 0xFFFFu];
-                    dv[q] = d32[pr[r0 + q] >> 16];
+            for (int r = 0; r < kBfsEdgeRegs; ++r) {
+                const bool alive = (live >> r) & 1u;
+                if (__ballot(alive) == 0ull) continue;  // wave-uniform: nobody's slot r can discover anything any more
+                const unsigned ua = pr[r] & 0xFFFFu, va = pr[r] >> 16;
+                unsigned du = kInf, dv = kInf;
+                if (alive) {
+                    du = d16[ua];
+                    dv = d16[va];
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (mode != 2 && du[q] + 1u < dv[q]) {
-                        atomicMin(&d32[pr[r0 + q] >> 16], du[q] + 1u);
-                        any = true;
-                    }
-                    if (mode != 1 && dv[q] + 1u < du[q]) {
-                        atomicMin(&d32[pr[r0 + q] & 0xFFFFu], dv[q] + 1u);
-                        any = true;
-                    }
+                if (!alive) continue;
+                const unsigned lo = du < dv ? du : dv, hi = du < dv ? dv : du;
+                if (hi != kInf) {  // both settled: dead from now on
+                    live &= ~(1u << r);
+                    continue;
                 }
+                if (lo != (unsigned)level) continue;
+                // exactly one endpoint is on the frontier, the other has no level yet: does the orientation allow the step?
+                const bool from_u = du == (unsigned)level;
+                if ((mode == 1 && !from_u) || (mode == 2 && from_u)) continue;
+                d16[from_u ? va : ua] = (uint16_t)(level + 1);
+                any = true;
             }
-            if (any) s_changed[round % 3] = 1;
+            if (any) s_changed[level % 3] = 1;
             __syncthreads();
-            if (!s_changed[round % 3]) break;  // uniform: a whole pass improved nothing
+            if (!s_changed[level % 3]) break;  // uniform: the frontier did not grow
         }
         for (int v = tid; v < ng; v += kBfsThreads) {
-            const unsigned d = d32[v];
+            const unsigned d = d16[v];
             out[v] = d == kInf ? -1 : (int32_t)d;
         }
         return;

@@ -348,10 +348,9 @@ int evi_bfs_levels(const int32_t* job_graph, const int64_t* src_ptr, const int64
                    int32_t* dist_out, void* stream);
 
 /* The same levels with the batch's edge list given as well (edge_index [2, E] i64 batch-global, edge_ptr [B+1]): a graph of at
- * most 12 288 edges and 12 288 nodes (every WebQSP / CWQ graph) is searched EDGE-parallel — every thread of the workgroup keeps
- * <= 12 edges in registers as packed 16-bit (u, v) pairs, the levels sit in LDS, and passes over the edges relax
- * level[v] = min(level[v], level[u] + 1) (LDS atomicMin; the fixed point is the BFS level whatever the lane order) until a pass
- * improves nothing: one barrier per pass, several hops per pass, no queue, no row gathers, no CSR.  Larger graphs take evi_bfs_levels' path inside
+ * most 12 288 edges and 32 767 nodes (every WebQSP / CWQ graph) is searched EDGE-parallel — every thread of the workgroup keeps
+ * <= 12 edges in registers as packed 16-bit (u, v) pairs, the levels sit in LDS, and a level is one round of independent LDS
+ * reads, a few plain stores and one barrier: no queue, no row gathers, no CSR.  Larger graphs take evi_bfs_levels' path inside
  * the same launch (that is what the CSR arguments are for). */
 int evi_bfs_levels_edges(const int32_t* job_graph, const int64_t* src_ptr, const int64_t* src_idx,
                          const int64_t* dist_off, int num_jobs, const int64_t* node_ptr, const int64_t* edge_ptr,
