@@ -573,10 +573,21 @@ static int dpl_for(int d) {
 struct FwdLayout {
     size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
         in_eid, out_ptr, out_nbr, out_eid, csr_ws, wa, wb, wc, wd, vhead, fold, wt, wsplit, hcn, P, RCX, XS, aux, PA, RC, SB,
-        h1n, total;
+        h1n, lane_stride, wsplit2, total;
     int64_t ec;
     int dedupe;
+    int lanes;  // 1, or 2: the per-edge pipeline alternates its chunks between the caller's stream and a side stream
 };
+
+// Two lanes (see retriever_run): on unless EVI_SCORER_LANES=1; a batch of fewer than 2 x 16 384 edges is one chunk on one lane.
+static int scorer_lanes() {
+    static const int v = [] {
+        const char* e = getenv("EVI_SCORER_LANES");
+        return e && e[0] == '1' ? 1 : 2;
+    }();
+    return v;
+}
+constexpr int64_t kLaneMinEdges = 16384;
 
 static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, int64_t R, int dirs) {
     FwdLayout L;
@@ -588,6 +599,13 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     };
     L.dedupe = (R > 0 && R <= E) ? 1 : 0;
     L.ec = E < edge_chunk() ? (E > 0 ? E : 1) : edge_chunk();
+    L.lanes = scorer_lanes();
+    if (L.lanes == 2 && E <= L.ec) {
+        // one chunk would leave the second lane idle: halve it (rounded up to whole 256-row GEMM tiles) when both halves are
+        // still large launches
+        if (E >= 2 * kLaneMinEdges) L.ec = (((E + 1) / 2 + 255) / 256) * 256;
+        else L.lanes = 1;
+    }
     const size_t f = sizeof(float);
     const size_t n1 = (size_t)(N > 0 ? N : 1), e1 = (size_t)(E > 0 ? E : 1);
     L.node_repr = take(n1 * D * f);
@@ -624,6 +642,10 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.RC = take((size_t)L.ec * H * f);
     L.SB = take((size_t)dirs * L.ec * H * f);
     L.h1n = take((size_t)L.ec * H * f);  // combined normalised rows (input of state_net.4 when features are wanted)
+    // the second lane's copy of the per-chunk buffers P .. h1n (same offsets + lane_stride) and its own weight-split scratch
+    L.lane_stride = off - L.P;
+    if (L.lanes == 2) off += L.lane_stride;
+    L.wsplit2 = take(L.lanes == 2 ? gemm_bf16x3_workspace_bytes(H > D ? H : D, H > D ? H : D) : 256);
     L.total = off;
     return L;
 }
@@ -674,6 +696,28 @@ extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, in
     if (N < 0 || E < 0 || B < 1 || D < 1 || H < 1) return 0;
     const int F = 2 * 2 * (1 + dde_rounds + dde_reverse_rounds);
     return fwd_layout(N, E, B, D, H, F, num_relations, 2).total;
+}
+
+// The scorer's second lane: one side stream and three events per host thread and device, made on first use and kept.
+struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
+};
+static int side_lane(SideLane** out) {
+    constexpr int kMaxDev = 16;
+    static thread_local SideLane lanes[kMaxDev];
+    int dev = 0;
+    EVI_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDev) return fail(EVI_ERR_UNSUPPORTED, "evi_retriever_forward: device ordinal %d outside the side-lane table", dev);
+    SideLane& l = lanes[dev];
+    if (!l.stream) {
+        EVI_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        EVI_HIP_CHECK(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+        EVI_HIP_CHECK(hipEventCreateWithFlags(&l.mid, hipEventDisableTiming));
+        EVI_HIP_CHECK(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+    }
+    *out = &l;
+    return EVI_OK;
 }
 
 // Backward context of retriever_run (null: forward only).  Gradients use the weights struct's layout (float* written).
@@ -944,6 +988,30 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     const PrepLayout PL = prep_layout(D, H, F);
     auto planes = [&](size_t off) -> const void* { return prep ? prep + off : nullptr; };
 
+    // Two lanes.  The forward alternates MFMA-bound launches (the GEMMs: 250 VGPRs, one workgroup per CU) with HBM-bound ones
+    // (k_edge_features, k_state_combine: gathers and 12-18 KB of rows per edge) — on one stream each kind leaves the other
+    // half of the CU idle.  So a forward-only call runs its edge chunks alternately on the caller's stream and on a side
+    // stream (own per-chunk buffers), the second lane one stage behind the first, and the hardware overlaps one lane's
+    // GEMMs with the other's per-edge kernels; the latency-bound CSR + DDE launches run on the side lane under the node
+    // projections.  Same kernels, same arguments, same results — only the order in time changes.  The backward pass
+    // (gradients accumulate across chunks in a fixed order) and timed runs (evi_timing_enable) stay on one stream.
+    SideLane* side = nullptr;
+    if (L.lanes == 2 && !bw && !timing_enabled()) {
+        if ((rc = side_lane(&side))) return rc;
+        EVI_HIP_CHECK(hipEventRecord(side->fork, st));  // whatever produced the batch on the caller's stream
+        EVI_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    }
+    auto structure_features = [&](void* on) -> int {
+        int r;
+        if ((r = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
+                               I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
+                               evi_graph_csr_workspace_bytes(N), on)))
+            return r;
+        return evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
+                                          I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, on);
+    };
+    if (side && (rc = structure_features(side->stream))) return rc;
+
     // 1. projections
     if ((rc = scorer_gemm(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, wsplit, st, planes(PL.p_entity)))) return rc;
     if ((rc = scorer_gemm(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, wsplit, st, planes(PL.p_entity)))) return rc;
@@ -971,14 +1039,13 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         if ((rc = scorer_gemm(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     }
 
-    // 2. structure features
-    if ((rc = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
-                            I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
-                            evi_graph_csr_workspace_bytes(N), stream)))
-        return rc;
-    if ((rc = evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
-                                         I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
-        return rc;
+    // 2. structure features: on the side lane (started before the projections, see above) when there is one
+    if (!side) {
+        if ((rc = structure_features(stream))) return rc;
+    } else {
+        EVI_HIP_CHECK(hipEventRecord(side->mid, side->stream));
+        EVI_HIP_CHECK(hipStreamWaitEvent(st, side->mid, 0));
+    }
 
     // 3-5. factored state_net.0 (see the header), per edge chunk
     auto PF = [&](size_t off) { return reinterpret_cast<float*>(const_cast<char*>(prep) + off); };
@@ -1056,8 +1123,19 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         const size_t have = bw ? bw->saved_bytes : out->saved_bytes;
         if (have < need) return fail(EVI_ERR_NOMEM, "evi_retriever: saved buffer %zu B < %zu B", have, need);
     }
-    for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
+    if (side) {  // everything the chunks read is in flight on the caller's stream: the side lane starts after it
+        EVI_HIP_CHECK(hipEventRecord(side->fork, st));
+        EVI_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    }
+    hipStream_t const st_main = st;
+    void* const wsplit_main = wsplit;
+    for (int64_t e0 = 0, ci = 0; e0 < E; e0 += L.ec, ++ci) {
         const int64_t ec = (E - e0) < L.ec ? (E - e0) : L.ec;
+        const bool on_side = side && (ci & 1);
+        hipStream_t st = on_side ? side->stream : st_main;  // this chunk's lane
+        void* wsplit = on_side ? static_cast<void*>(base + L.wsplit2) : wsplit_main;
+        const size_t lane_off = on_side ? L.lane_stride : 0;
+        auto F32 = [&](size_t off) { return reinterpret_cast<float*>(base + off + lane_off); };  // per-chunk buffers only below
         EdgeFeatArgs a;
         a.edge_index = b->edge_index;
         a.E = E;
@@ -1113,6 +1191,10 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
+        if (side && ci == 0) {  // the second lane runs one stage behind: its first per-edge kernel starts under this lane's GEMMs
+            EVI_HIP_CHECK(hipEventRecord(side->mid, st));
+            EVI_HIP_CHECK(hipStreamWaitEvent(side->stream, side->mid, 0));
+        }
         // (r03: writing P / RCX / XS as bf16 hi / lo planes and multiplying them on a pre-split LDS-DMA GEMM was wired in here,
         // bit-identical, and measured with rocprofv3 on this batch: 288.8 us per launch against 285.0 us for this kernel, the edge
         // kernel 344 against 330 us — no gain inside the pipeline, so that kernel and its entry points were removed)
@@ -1216,6 +1298,10 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         }
         // struct_proj.0: weight [D, F] += dU^T SX (its bias gradient, the column sums of dU, came with the kernel's partials)
         if ((rc = tn_gemm(BF(BL.DU), D, BF(BL.SX), F, M, G(g->struct_w), 1, BL, bws, st))) return rc;
+    }
+    if (side) {  // join: the caller's stream continues after the side lane's last chunk
+        EVI_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        EVI_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
     }
     if (!bw) return EVI_OK;
     // ---- backward: once per batch ----------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ One fused kernel pass per batch ranks every graph once; the metric objects of on
 from __future__ import annotations
 
 import ctypes
+from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -614,6 +615,93 @@ class RetrieverMetricCollection:
             m.sync(group)
 
 
+# ---- list-of-samples ranking statistics (src/utils/metrics.py:104-170) --------------------------------------------------------
+@dataclass
+class RankingStats:
+    """reference: RankingStats, src/utils/metrics.py:104-110."""
+    precision_at_k: Dict[int, float]
+    recall_at_k: Dict[int, float]
+    f1_at_k: Dict[int, float]
+    ndcg_at_k: Dict[int, float]
+    mrr: float
+
+
+def _descending_keys(values: torch.Tensor) -> torch.Tensor:
+    """int64 keys whose ASCENDING order is the values' descending order (f32; -0.0 counted as +0.0)."""
+    bits = (values + 0.0).contiguous().view(torch.int32).to(torch.int64)
+    return -torch.where(bits < 0, bits ^ 0x7FFFFFFF, bits)
+
+
+def compute_ranking_metrics(samples, k_values) -> RankingStats:
+    """Precision / recall / F1 / nDCG @k and MRR over an iterable of {"scores", "labels"} samples, averaged over the samples
+    that have positives.  reference: compute_ranking_metrics + _ndcg, src/utils/metrics.py:112-170 — same quirks: hits and
+    DCG sum label VALUES, the recall denominator is the label sum truncated to an int, samples whose truncated label sum is
+    <= 0 are skipped, an empty k list means [1].
+
+    All samples are ranked in ONE pass on the device: the flat score list is sorted per sample by the segmented stable sort
+    (`evi_segment_sort_rank`, order (score desc, position asc) — the reference's argsort leaves ties unspecified), every
+    per-sample sum is a segment reduction, and one small tensor is read back.  Discounts are f32 like the reference's, the
+    sums f64 (the reference sums in f32: agreement to ~1e-7)."""
+    ks = normalize_k_values(k_values, default=[1])
+    zero = {k: 0.0 for k in ks}
+    rows = [(torch.as_tensor(s["scores"]).reshape(-1), torch.as_tensor(s["labels"]).reshape(-1)) for s in samples]
+    for sc, lb in rows:
+        if sc.numel() != lb.numel():
+            raise ValueError(f"scores/labels length mismatch: {sc.numel()} vs {lb.numel()}")
+    rows = [r for r in rows if r[0].numel() > 0]  # an empty sample has no positives: skipped by the reference too
+    if not rows:
+        return RankingStats(dict(zero), dict(zero), dict(zero), dict(zero), 0.0)
+    dev = next((r[0].device for r in rows if r[0].is_cuda), None)
+    if dev is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("compute_ranking_metrics ranks on the GPU (evi_segment_sort_rank): no GPU visible, and there is no CPU path")
+        dev = torch.device("cuda", torch.cuda.current_device())
+    scores = torch.cat([r[0].to(device=dev, dtype=torch.float32) for r in rows])
+    labels = torch.cat([r[1].to(device=dev, dtype=torch.float32) for r in rows])
+    lens = torch.tensor([r[0].numel() for r in rows], dtype=torch.long)
+    ptr = torch.zeros(len(rows) + 1, dtype=torch.long)
+    torch.cumsum(lens, 0, out=ptr[1:])
+    ptr, lens = ptr.to(dev), lens.to(dev)
+    S = len(rows)
+    seg = torch.repeat_interleave(torch.arange(S, device=dev), lens, output_size=int(scores.numel()))
+    kt = torch.tensor(ks, dtype=torch.int32, device=dev)
+
+    def seg_sum(x):  # [T] or [T, K] f64 -> per-sample sums, in element order (deterministic)
+        return torch.segment_reduce(x, "sum", lengths=lens, axis=0, unsafe=True)
+
+    def discounted(rank):  # 1 / log2(position + 1), position = rank + 1, in f32 (:160-161)
+        return (1.0 / torch.log2(rank.to(torch.float32) + 2.0)).to(torch.float64)
+
+    rank, _ = ops.segment_sort_rank(_descending_keys(scores), ptr)
+    ideal_rank, _ = ops.segment_sort_rank(_descending_keys(labels), ptr)  # torch.sort(ranked_labels, descending=True) (:163)
+    lab64 = labels.to(torch.float64)
+    positives = torch.trunc(seg_sum(lab64))                                   # int(labels.sum()) (:121)
+    valid = positives > 0
+    in_k = (rank.unsqueeze(1) < kt.unsqueeze(0)).to(torch.float64)            # [T, K]
+    hits = seg_sum(lab64.unsqueeze(1) * in_k)                                 # ranked_labels[:k].sum() (:132-133)
+    dcg = seg_sum((lab64 * discounted(rank)).unsqueeze(1) * in_k)
+    ideal_in_k = (ideal_rank.unsqueeze(1) < kt.unsqueeze(0)).to(torch.float64)
+    idcg = seg_sum((lab64 * discounted(ideal_rank)).unsqueeze(1) * ideal_in_k)
+    pos_mask = labels > 0.5
+    first = torch.full((S,), 1 << 30, dtype=torch.int32, device=dev)
+    first.scatter_reduce_(0, seg[pos_mask], rank[pos_mask], "amin")           # first ranked label > 0.5 (:127-130)
+    has_first = (first < (1 << 30)) & valid
+    precision = hits / kt.to(torch.float64).unsqueeze(0)
+    recall = hits / positives.clamp(min=1.0).unsqueeze(1)
+    pr = precision + recall
+    f1 = torch.where(pr == 0, torch.zeros_like(pr), 2.0 * precision * recall / pr.clamp(min=1e-300))
+    ndcg = torch.where(idcg > 0, dcg / idcg.clamp(min=1e-300), torch.zeros_like(dcg))
+    v = valid.to(torch.float64).unsqueeze(1)
+    count = valid.sum().to(torch.float64).clamp(min=1.0)
+    mrr_n = has_first.sum().to(torch.float64)
+    mrr = (has_first.to(torch.float64) / (first.to(torch.float64) + 1.0)).sum() / mrr_n.clamp(min=1.0)
+    packed = torch.cat([((precision * v).sum(0) / count), ((recall * v).sum(0) / count), ((f1 * v).sum(0) / count),
+                        ((ndcg * v).sum(0) / count), mrr.view(1)]).cpu().tolist()  # the one read-back
+    K = len(ks)
+    take = lambda j: {k: float(packed[j * K + i]) for i, k in enumerate(ks)}  # noqa: E731
+    return RankingStats(take(0), take(1), take(2), take(3), float(packed[4 * K]))
+
+
 __all__ = ["normalize_k_values", "rank_batch", "RankedBatch", "EdgeRecallAtK", "AnswerReachability", "AnswerHitAtK",
            "ScoreMargin", "BridgeEdgeRecallAtK", "BridgePositiveCoverage", "BridgeProbQuality", "FeatureMonitor",
-           "RetrieverMetricCollection"]
+           "RetrieverMetricCollection", "RankingStats", "compute_ranking_metrics"]

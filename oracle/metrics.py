@@ -8,7 +8,7 @@ from typing import Dict, List, Sequence
 import numpy as np
 
 from . import graph as ograph
-from .ranking import topk_desc
+from .ranking import stable_desc_order, topk_desc
 
 
 def normalize_k_values(raw: Sequence[int]) -> List[int]:
@@ -309,4 +309,51 @@ def bridge_metrics(scores, target, batch, k_values: Sequence[int]) -> Dict[str, 
     gb = np.bincount(eb[target & bridge], minlength=batch.num_graphs) > 0
     out["bridge/pos_edge_frac"] = bridge_pos / max(total_pos, 1.0)
     out["bridge/pos_graph_frac"] = float((gp & gb).sum()) / max(float(gp.sum()), 1.0)
+    return out
+
+
+# ---- T4b: list-of-samples ranking statistics ------------------------------------------------------------------------
+def _ndcg(ranked_labels: np.ndarray, k: int) -> float:
+    """reference: _ndcg, src/utils/metrics.py:156-170 (f32 tensors, python-float ratio)."""
+    trunc = ranked_labels[:k]
+    if trunc.size == 0:
+        return 0.0
+    positions = np.arange(1, trunc.size + 1, dtype=np.float32)
+    discounts = (np.float32(1.0) / np.log2(positions + np.float32(1.0))).astype(np.float32)
+    dcg = float((trunc * discounts).sum(dtype=np.float32))
+    ideal = np.sort(ranked_labels)[::-1][:k]
+    ideal_dcg = float((ideal * discounts[: ideal.size]).sum(dtype=np.float32))
+    return 0.0 if ideal_dcg <= 0 else dcg / ideal_dcg
+
+
+def ranking_metrics(samples, k_values) -> Dict[str, object]:
+    """Precision / recall / F1 / nDCG @k and MRR, averaged over the samples that have positives.
+    reference: compute_ranking_metrics, src/utils/metrics.py:112-153.  `samples`: (scores, labels) pairs.  Hits and DCG sum
+    label VALUES; the recall denominator is the label sum truncated to an int (:121, :136); a sample whose truncated label sum
+    is <= 0 is skipped.  Order: (score desc, position asc) — the reference's argsort is not stable, its fixtures avoid ties."""
+    ks = normalize_k_values(k_values) or [1]
+    tot = {k: {"precision": 0.0, "recall": 0.0, "f1": 0.0, "ndcg": 0.0, "count": 0.0} for k in ks}
+    mrr_sum, mrr_count = 0.0, 0
+    for scores, labels in samples:
+        scores = np.asarray(scores, np.float32).reshape(-1)
+        labels = np.asarray(labels, np.float32).reshape(-1)
+        positives = int(labels.sum(dtype=np.float32))
+        if positives <= 0:
+            continue
+        ranked = labels[stable_desc_order(scores)]
+        pos = np.nonzero(ranked > 0.5)[0]
+        if pos.size:
+            mrr_sum += 1.0 / float(pos[0] + 1)
+            mrr_count += 1
+        for k in ks:
+            hits = float(ranked[:k].sum(dtype=np.float32))
+            precision, recall = hits / float(k), hits / float(positives)
+            st = tot[k]
+            st["precision"] += precision
+            st["recall"] += recall
+            st["f1"] += 0.0 if precision + recall == 0 else 2 * precision * recall / (precision + recall)
+            st["ndcg"] += _ndcg(ranked, k)
+            st["count"] += 1.0
+    out = {name: {k: tot[k][name] / (tot[k]["count"] or 1.0) for k in ks} for name in ("precision", "recall", "f1", "ndcg")}
+    out["mrr"] = mrr_sum / mrr_count if mrr_count else 0.0
     return out

@@ -107,7 +107,7 @@ from src.metrics.retriever_metrics import (  # noqa: E402
 from src.models.components.retriever import Retriever  # noqa: E402
 from src.models.reasoner_module import _oracle_metrics_for_sample  # noqa: E402
 from src.utils.graph_utils import compute_edge_batch, compute_qa_edge_mask  # noqa: E402
-from src.utils.metrics import compute_answer_hit, compute_answer_recall  # noqa: E402
+from src.utils.metrics import compute_answer_hit, compute_answer_recall, compute_ranking_metrics  # noqa: E402
 
 K_VALUES = [1, 10, 25, 50, 100, 200, 300, 400, 500]  # configs/window/default.yaml:8
 
@@ -116,6 +116,44 @@ def save(name, **arrays):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
     print(f"wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path)} B)")
+
+
+# ---- T4b: compute_ranking_metrics (src/utils/metrics.py:112-170) ------------------------------------------------
+def gen_ranking_metrics():
+    """Precision / recall / F1 / nDCG @k and MRR over a list of {"scores", "labels"} samples, computed by the reference.
+    Scores are distinct inside a sample (torch.argsort's tie order is not specified); the cases: ordinary binary labels,
+    a sample without positives (skipped), one with only positives, samples shorter than the largest k, a single-element
+    sample, graded (non-binary) labels — the reference sums label VALUES in the hits and DCG and truncates their sum to an
+    int for the recall denominator."""
+    rng = np.random.default_rng(77)
+    lens = [40, 7, 1, 120, 15, 64, 3, 9]
+    scores, labels = [], []
+    for i, n in enumerate(lens):
+        s = rng.permutation(n).astype(np.float32) * 0.37 - 5.0 + rng.random(1).astype(np.float32)  # distinct
+        lab = (rng.random(n) < 0.2).astype(np.float32)
+        if i == 1:
+            lab[:] = 0.0  # no positives: the sample is skipped
+        if i == 2:
+            lab[:] = 1.0
+        if i == 4:
+            lab[:] = 1.0  # every item positive
+        if i == 6:
+            lab = np.array([0.0, 1.0, 0.0], np.float32)
+        if i == 7:
+            lab = np.array([0.0, 2.0, 0.5, 0.0, 1.0, 0.25, 0.0, 0.0, 3.0], np.float32)  # graded relevance
+        scores.append(s)
+        labels.append(lab)
+    ks = [1, 3, 5, 10, 50, 100]
+    samples = [{"scores": torch.from_numpy(s), "labels": torch.from_numpy(l)} for s, l in zip(scores, labels)]
+    st = compute_ranking_metrics(samples, ks)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    save("ranking_metrics", scores=np.concatenate(scores), labels=np.concatenate(labels), ptr=ptr, k_values=np.asarray(ks),
+         precision=[st.precision_at_k[k] for k in ks], recall=[st.recall_at_k[k] for k in ks], f1=[st.f1_at_k[k] for k in ks],
+         ndcg=[st.ndcg_at_k[k] for k in ks], mrr=st.mrr,
+         # the default k list ([1]) when none is given, and an all-negative sample list (every mean 0, MRR 0)
+         default_k_precision=compute_ranking_metrics(samples, None).precision_at_k[1],
+         empty_mrr=compute_ranking_metrics([samples[1]], ks).mrr,
+         empty_recall=[compute_ranking_metrics([samples[1]], ks).recall_at_k[k] for k in ks])
 
 
 # ---- C1-C4 ---------------------------------------------------------------------------------------
@@ -775,6 +813,7 @@ def main():
     gen_g_agent_build()
     gen_loss()
     gen_feature_monitor()
+    gen_ranking_metrics()
     # toy batch (BASELINE config 1 graph shape: 32 graphs, N_g = 64, E_g ~ 31), D = H = 32
     toy = synthetic.make_batch(32, nodes_per_graph=64, edges_per_graph=31, emb_dim=32, num_relations=16, seed=0)
     eb, eptr, near = gen_graph_utils(toy)

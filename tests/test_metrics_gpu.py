@@ -170,3 +170,36 @@ def test_feature_monitor_matches_reference_golden(dev):
     m.update(torch.from_numpy(z["b1_preds"]).to(dev), torch.zeros(37, dtype=torch.bool, device=dev))
     out = m.compute()
     np.testing.assert_allclose([float(out[k]) for k in sorted(out)], z["nopos_values"], rtol=2e-6, atol=2e-7)
+
+
+def test_compute_ranking_metrics_matches_the_reference_function_and_the_oracle():
+    """src/utils/metrics.py:112-170 (compute_ranking_metrics, _ndcg): golden = the reference's own function on seeded samples
+    (binary and graded labels, all-positive / all-negative / one-element samples, k beyond the sample length)."""
+    from evi_rag_amd import metrics as M
+
+    z = np.load(os.path.join(GOLD, "ranking_metrics.npz"), allow_pickle=False)
+    ptr, ks = z["ptr"], [int(k) for k in z["k_values"]]
+    dev = torch.device("cuda:0")
+    samples = [{"scores": torch.from_numpy(z["scores"][a:b]).to(dev), "labels": torch.from_numpy(z["labels"][a:b]).to(dev)}
+               for a, b in zip(ptr[:-1], ptr[1:])]
+    st = M.compute_ranking_metrics(samples, ks)
+    for name, got in (("precision", st.precision_at_k), ("recall", st.recall_at_k), ("f1", st.f1_at_k), ("ndcg", st.ndcg_at_k)):
+        assert [got[k] for k in ks] == pytest.approx(z[name].tolist(), abs=1e-6), name  # f32 sums in the reference, f64 here
+    assert st.mrr == pytest.approx(float(z["mrr"]), abs=1e-12)
+    assert M.compute_ranking_metrics(samples, None).precision_at_k == {1: pytest.approx(float(z["default_k_precision"]), abs=1e-12)}
+    none = M.compute_ranking_metrics([samples[1]], ks)  # all-negative sample alone
+    assert none.mrr == 0.0 and all(v == 0.0 for v in none.recall_at_k.values())
+    assert M.compute_ranking_metrics([], ks).mrr == 0.0
+    # host tensors are accepted (moved to the GPU), and a larger random case agrees with the oracle
+    rng = np.random.default_rng(5)
+    big = []
+    for n in rng.integers(1, 3000, 64):
+        sc = rng.permutation(int(n)).astype(np.float32) - 17.0
+        big.append((sc, (rng.random(int(n)) < 0.05).astype(np.float32)))
+    want = omet.ranking_metrics(big, [1, 10, 100, 500])
+    got = M.compute_ranking_metrics([{"scores": torch.from_numpy(a), "labels": torch.from_numpy(b)} for a, b in big], [1, 10, 100, 500])
+    for name, g in (("precision", got.precision_at_k), ("recall", got.recall_at_k), ("f1", got.f1_at_k), ("ndcg", got.ndcg_at_k)):
+        assert [g[k] for k in (1, 10, 100, 500)] == pytest.approx([want[name][k] for k in (1, 10, 100, 500)], abs=1e-6), name
+    assert got.mrr == pytest.approx(want["mrr"], abs=1e-12)
+    with pytest.raises(ValueError, match="length mismatch"):
+        M.compute_ranking_metrics([{"scores": torch.zeros(3), "labels": torch.zeros(2)}], ks)

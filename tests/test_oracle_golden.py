@@ -304,3 +304,17 @@ def test_retriever_loss_matches_reference():
         assert sorted(comps) == z[f"{tag}_component_keys"].tolist() and sorted(mets) == z[f"{tag}_metric_keys"].tolist(), tag
         np.testing.assert_allclose([comps[k] for k in sorted(comps)], z[f"{tag}_component_vals"], rtol=2e-6, atol=2e-6)
         np.testing.assert_allclose([mets[k] for k in sorted(mets)], z[f"{tag}_metric_vals"], rtol=2e-6, atol=2e-6)
+
+
+# ---- T4b -------------------------------------------------------------------------------------------------------------
+def test_ranking_metrics_match_the_reference_function():
+    z = load("ranking_metrics")
+    ptr, ks = z["ptr"], [int(k) for k in z["k_values"]]
+    samples = [(z["scores"][a:b], z["labels"][a:b]) for a, b in zip(ptr[:-1], ptr[1:])]
+    got = omet.ranking_metrics(samples, ks)
+    for name in ("precision", "recall", "f1", "ndcg"):
+        np.testing.assert_allclose([got[name][k] for k in ks], z[name], rtol=0, atol=1e-7)  # f32 sums: reassociation only
+    assert got["mrr"] == pytest.approx(float(z["mrr"]), abs=1e-15)
+    assert omet.ranking_metrics(samples, None)["precision"][1] == pytest.approx(float(z["default_k_precision"]), abs=1e-15)
+    none = omet.ranking_metrics([samples[1]], ks)  # the all-negative sample alone: every mean 0, MRR 0
+    assert none["mrr"] == float(z["empty_mrr"]) and [none["recall"][k] for k in ks] == z["empty_recall"].tolist()
