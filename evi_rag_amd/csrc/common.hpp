@@ -75,6 +75,7 @@ struct GemmBatch {
     int64_t c_stride = 0;  // floats between the slices' outputs
     int64_t k_total = 0;   // padded K of the whole operands
     int64_t w_ld = 0;      // row stride of the W planes (elements)
+    const int32_t* m_dev = nullptr;  // device-side row count: rows >= *m_dev are not computed (their tiles exit); M is the bound
 };
 bool gemm_skinny_fits(int64_t M, int K, int64_t lda, int64_t ldw);
 int launch_gemm_skinny(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw, const float* bias, int act,
@@ -95,9 +96,11 @@ int launch_gemm_bf16_presplit(const void* A, int a_f16, int single, int64_t M, i
 // Split-bf16 variant (gemm_bf16x3.hip); wsplit: gemm_bf16x3_workspace_bytes(N, K) bytes.
 size_t gemm_bf16x3_workspace_bytes(int N, int K);
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
-                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single = 0);
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single = 0,
+                          const int32_t* m_dev = nullptr);
 int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
-                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single = 0);
+                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single = 0,
+                                  const int32_t* m_dev = nullptr);
 
 // ---- ordered keys ---------------------------------------------------------------------------
 // A 64-bit key whose unsigned order is the ranking order used everywhere in this library:

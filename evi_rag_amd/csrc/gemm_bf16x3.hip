@@ -114,10 +114,21 @@ __global__ __launch_bounds__(kXThreads) void k_gemm_nt_bf16x3(
     const int nblocks_n = (N + XN - 1) / XN;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
     // so give every XCD a contiguous run of logical tiles — the n-tiles that share an A row panel
-    // then hit the same L2 instead of fetching the panel once per XCD.  Pure speed; bijective
-    // whenever the grid divides by 8, identity otherwise.
-    const unsigned nwg = gridDim.x;
-    const unsigned tile = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+    // then hit the same L2 instead of fetching the panel once per XCD.  Pure speed; a bijection of the grid.
+    unsigned nwg = gridDim.x;
+    if (bt.m_dev) {
+        // the caller knows only a bound on M: the count is on the device (scorer: distinct (relation, graph) pairs).  The first
+        // `live` workgroups cover it — consecutive workgroup ids are dealt round-robin over the XCDs, so the live ones stay spread
+        // over all eight — and the rest exit (uniform over the workgroup, before any barrier)
+        const int64_t m_now = *bt.m_dev;
+        if (m_now < M) M = m_now;
+        const unsigned live = (unsigned)((M + XM - 1) / XM) * (unsigned)nblocks_n;
+        if (blockIdx.x >= live) return;
+        nwg = live;
+    }
+    // the remap covers the largest multiple of 8 (identity on the few workgroups beyond it)
+    const unsigned nwg8 = nwg - nwg % 8;
+    const unsigned tile = blockIdx.x < nwg8 ? (blockIdx.x % 8) * (nwg8 / 8) + blockIdx.x / 8 : blockIdx.x;
     const int64_t m0 = (int64_t)(tile / nblocks_n) * XM;
     const int n0 = (int)(tile % nblocks_n) * XN;
 
@@ -498,7 +509,8 @@ int launch_gemm_bf16x3_filter(const void* A, int a_f16, int single, int64_t M, i
 }
 
 int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const float* W, int N, int64_t ldw,
-                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single) {
+                          const float* bias, int act, float* C, int64_t ldc, void* wsplit, hipStream_t st, int single,
+                          const int32_t* m_dev) {
     if (M == 0 || N == 0) return EVI_OK;
     if (single == 2) {  // f16x2: the weight as one f16 plane in the hi slot of `wsplit`
         const int Kp = (K + XK - 1) / XK * XK;
@@ -509,7 +521,7 @@ int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const f
     } else if (int rc = split_weight_bf16x3(W, N, K, ldw, wsplit, st)) {
         return rc;
     }
-    return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wsplit, N, bias, act, C, ldc, st, single);
+    return launch_gemm_nt_bf16x3_wplanes(A, M, K, lda, wsplit, N, bias, act, C, ldc, st, single, m_dev);
 }
 
 // the same with W already split (split_weight_bf16x3 wrote `wplanes`): what a caller that keeps its weights prepared uses.
@@ -517,9 +529,12 @@ int launch_gemm_nt_bf16x3(const float* A, int64_t M, int K, int64_t lda, const f
 // with an f32 result; the scorer's opt-in `bf16-mixed` training precision.
 // single == 2: the f16x2 form (see the kernel): `wplanes` must then hold the weight as ONE f16 plane (k_round_weight_f16).
 int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda, const void* wplanes, int N,
-                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single) {
+                                  const float* bias, int act, float* C, int64_t ldc, hipStream_t st, int single,
+                                  const int32_t* m_dev) {
     if (M == 0 || N == 0) return EVI_OK;
     const int Kp = (K + XK - 1) / XK * XK;
+    GemmBatch plain;
+    plain.m_dev = m_dev;
     const __bf16* hi = static_cast<const __bf16*>(wplanes);
     const __bf16* lo = reinterpret_cast<const __bf16*>(static_cast<const char*>(wplanes) + align_up((size_t)N * Kp * 2, 256));
     const GemmFilter flt{};
@@ -533,13 +548,13 @@ int launch_gemm_nt_bf16x3_wplanes(const float* A, int64_t M, int K, int64_t lda,
     }();
 #define EVI_LAUNCH_X3(ACT)                                                                                              \
     if (single == 2)                                                                                                    \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 2>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 2>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, plain); \
     else if (single)                                                                                                    \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0, 0, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, plain); \
     else if (mfma16)                                                                                                    \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{}); \
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 1>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, plain); \
     else                                                                                                                \
-        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, GemmBatch{});
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3<ACT, 0>), grid, dim3(kXThreads), 0, st, A, M, K, lda, hi, lo, N, Kp, bias, C, ldc, flt, plain);
     switch (act) {
         case 1: EVI_LAUNCH_X3(1) break;
         case 2: EVI_LAUNCH_X3(2) break;

@@ -115,6 +115,87 @@ __global__ void k_transpose(const float* __restrict__ src, int rows, int cols, f
     if (i < rows * cols) dst[(i % cols) * rows + (i / cols)] = src[i];
 }
 
+// ---- (relation, graph) pairs --------------------------------------------------------------------------
+// r_ctx = rel_repr[relation] * gate_q[graph] + bias_q[graph] (retriever.py:453-462) depends on the edge only through its
+// (relation, graph) pair, and state_net.0's Wc block is applied to it as it stands (RC = r_ctx Wc^T): a graph of 4 096 edges has
+// a few hundred to ~2 600 distinct pairs, so the forward multiplies one row per PAIR instead of one per edge and the combine
+// kernel looks its edge's row up.  The table [B, R] maps a pair to its row (slot), the slots are dealt graph by graph in
+// relation order (deterministic); their number stays on the device — the GEMM gets it as GemmBatch::m_dev.
+__global__ void k_pair_mark(const int64_t* __restrict__ edge_attr, const int64_t* __restrict__ edge_batch, int64_t E, int64_t R,
+                            int32_t* __restrict__ table) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t r = edge_attr[e];
+    r = r < 0 ? 0 : (r >= R ? R - 1 : r);  // out-of-range ids are flagged by k_first_edge_of_relation and scored clamped
+    table[edge_batch[e] * R + r] = 1;
+}
+// one workgroup per graph: the set entries of its table row -> 1 + their rank in the row; count[g] = how many
+__global__ __launch_bounds__(1024) void k_pair_rank(int32_t* __restrict__ table, int64_t R, int32_t* __restrict__ count) {
+    __shared__ int s_sum[1024];
+    const int t = threadIdx.x;
+    int32_t* row = table + (int64_t)blockIdx.x * R;
+    const int64_t per = (R + 1023) / 1024;
+    const int64_t lo = t * per, hi = lo + per < R ? lo + per : R;
+    int mine = 0;
+    for (int64_t i = lo; i < hi; ++i) mine += row[i];
+    s_sum[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int next = s_sum[t] - mine;
+    for (int64_t i = lo; i < hi; ++i)
+        if (row[i]) row[i] = ++next;
+    if (t == 1023) count[blockIdx.x] = s_sum[1023];
+}
+// one workgroup per graph: rank in the row -> slot in the batch (graphs in order); pair_key[slot] = g * R + r; count[B] = total
+__global__ __launch_bounds__(256) void k_pair_slots(int32_t* __restrict__ table, int64_t R, int B, int32_t* __restrict__ count,
+                                                    int32_t* __restrict__ pair_key) {
+    __shared__ int s_part[256];
+    const int g = blockIdx.x, t = threadIdx.x;
+    int before = 0;
+    for (int i = t; i < g; i += 256) before += count[i];
+    s_part[t] = before;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) s_part[t] += s_part[t + off];
+        __syncthreads();
+    }
+    const int base = s_part[0];
+    int32_t* row = table + (int64_t)g * R;
+    for (int64_t r = t; r < R; r += 256) {
+        const int v = row[r];
+        if (v > 0) {
+            const int slot = base + v - 1;
+            row[r] = slot;
+            pair_key[slot] = (int32_t)((int64_t)g * R + r);
+        }
+    }
+    if (g == B - 1 && t == 0) count[B] = base + count[g];
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ inline f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ inline void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+// the relation context of one (relation row, graph) at features d .. d + 3 — ONE definition for the per-edge kernel and the per-pair one
+__device__ inline f4 rel_ctx4(const float* rp, const float* gp, const float* bp, int d) { return ld4(rp + d) * ld4(gp + d) + ld4(bp + d); }
+
+// one wave per pair: RCX[p, :] = rel_repr[r] * gate_q[g] + bias_q[g]
+__global__ __launch_bounds__(256) void k_pair_rows(const int32_t* __restrict__ pair_key, const int32_t* __restrict__ total, int64_t R,
+                                                   const float* __restrict__ rel_repr, const float* __restrict__ gate_q,
+                                                   const float* __restrict__ bias_q, int D, float* __restrict__ RCX) {
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= *total) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t key = pair_key[p];
+    const int64_t g = key / R, r = key % R;
+    const float *rp = rel_repr + r * D, *gp = gate_q + g * D, *bp = bias_q + g * D;
+    for (int d = 4 * lane; d < D; d += 256) st4(RCX + p * D + d, rel_ctx4(rp, gp, bp, d));
+}
+
 // ---- edge features ----------------------------------------------------------------------------------
 // One wave per edge; lane owns features d = lane + 64 i (i < DPL).  Writes two rows of X.
 struct EdgeFeatArgs {
@@ -140,7 +221,7 @@ struct EdgeFeatArgs {
     int64_t e_begin, e_count;  // chunk
     int dir_fwd, dir_bwd;
     float* P;    // [e_count, D]  h * r_ctx * t
-    float* RCX;  // [e_count, D]  r_ctx
+    float* RCX;  // [e_count, D]  r_ctx; null when the caller multiplies r_ctx per (relation, graph) pair instead
     float* XS;   // [(dir_fwd + dir_bwd) * e_count, D]  struct context per direction
     float* aux;  // [(dir_fwd + dir_bwd) * e_count, 2]  (nav gate, -||translation error||)
 };
@@ -148,9 +229,6 @@ struct EdgeFeatArgs {
 // Lane -> feature map of the per-edge kernels: lane owns the float4 chunks d = 4 * lane + 256 * i, i < C4 = ceil(D / 256)
 // (D % 4 == 0), so every row access is a 16-byte load / store per lane — 1 KiB per wave instruction, four times fewer
 // memory and LDS instructions than one float per lane (cdna_hip_programming.md guideline 13).
-typedef float f4 __attribute__((ext_vector_type(4)));
-__device__ inline f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
-__device__ inline void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 __device__ inline float hsum4(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 template <int C4>
 __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
@@ -199,7 +277,7 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             if (d < D) {
                 h[i] = ld4(hp + d);
                 t[i] = ld4(tp + d);
-                rc[i] = ld4(rp + d) * ld4(gp + d) + ld4(bp + d);
+                rc[i] = rel_ctx4(rp, gp, bp, d);
             } else {
                 h[i] = t[i] = rc[i] = z4;
             }
@@ -291,7 +369,7 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             const int d = 4 * lane + 256 * i;
             if (d < D) {
                 st4(pp + d, h[i] * rc[i] * t[i]);
-                st4(rx + d, rc[i]);
+                if (a.RCX) st4(rx + d, rc[i]);
             }
         }
     }
@@ -350,7 +428,11 @@ struct CombineArgs {
     const int64_t* edge_index;
     int64_t E, e_begin, e_count;
     const float* PA;   // [e_count, H]
-    const float* RC;   // [e_count, H]
+    const float* RC;   // [e_count, H]; with pair_table: [pairs, H], row = pair_table[graph * R + relation]
+    const int32_t* pair_table;  // or null
+    const int64_t* edge_attr;
+    const int64_t* edge_batch;
+    int64_t R;
     const float* SB;   // [dirs * e_count, H]
     const float* HcN;  // [N, H]
     const float* aux;  // [dirs * e_count, 2]
@@ -391,6 +473,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
     const int64_t e = a.e_begin + le;
     const float* pa = a.PA + le * H;
     const float* rc = a.RC + le * H;
+    if (a.pair_table) {
+        int64_t r = a.edge_attr[e];
+        r = r < 0 ? 0 : (r >= a.R ? a.R - 1 : r);
+        rc = a.RC + (int64_t)a.pair_table[a.edge_batch[e] * a.R + r] * H;
+    }
     const float* hh = a.HcN + a.edge_index[e] * H;
     const float* ht = a.HcN + a.edge_index[a.E + e] * H;
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -573,21 +660,18 @@ static int dpl_for(int d) {
 struct FwdLayout {
     size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, rel_first, status, ns, in_ptr, in_nbr,
         in_eid, out_ptr, out_nbr, out_eid, csr_ws, wa, wb, wc, wd, vhead, fold, wt, wsplit, hcn, P, RCX, XS, aux, PA, RC, SB,
-        h1n, lane_stride, wsplit2, total;
-    int64_t ec;
+        h1n, pair_table, pair_count, pair_key, pair_rcx, pair_rc, total;
+    int64_t ec, pair_max;  // pair_max: bound on the (relation, graph) pairs of a batch, 0 = the per-edge form
     int dedupe;
-    int lanes;  // 1, or 2: the per-edge pipeline alternates its chunks between the caller's stream and a side stream
 };
 
-// Two lanes (see retriever_run): on unless EVI_SCORER_LANES=1; a batch of fewer than 2 x 16 384 edges is one chunk on one lane.
-static int scorer_lanes() {
-    static const int v = [] {
-        const char* e = getenv("EVI_SCORER_LANES");
-        return e && e[0] == '1' ? 1 : 2;
-    }();
-    return v;
+// (relation, graph) pair rows instead of per-edge r_ctx rows: on unless EVI_SCORER_PAIRS=0; needs the relation table form
+// (R <= E) and a [B, R] slot table of at most 4 M entries
+static bool scorer_pairs() {  // read per call (the parity test switches it inside one process)
+    const char* e = getenv("EVI_SCORER_PAIRS");
+    return !(e && e[0] == '0');
 }
-constexpr int64_t kLaneMinEdges = 16384;
+constexpr int64_t kPairTableMax = (int64_t)1 << 22;
 
 static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, int64_t R, int dirs) {
     FwdLayout L;
@@ -599,13 +683,6 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     };
     L.dedupe = (R > 0 && R <= E) ? 1 : 0;
     L.ec = E < edge_chunk() ? (E > 0 ? E : 1) : edge_chunk();
-    L.lanes = scorer_lanes();
-    if (L.lanes == 2 && E <= L.ec) {
-        // one chunk would leave the second lane idle: halve it (rounded up to whole 256-row GEMM tiles) when both halves are
-        // still large launches
-        if (E >= 2 * kLaneMinEdges) L.ec = (((E + 1) / 2 + 255) / 256) * 256;
-        else L.lanes = 1;
-    }
     const size_t f = sizeof(float);
     const size_t n1 = (size_t)(N > 0 ? N : 1), e1 = (size_t)(E > 0 ? E : 1);
     L.node_repr = take(n1 * D * f);
@@ -642,10 +719,13 @@ static FwdLayout fwd_layout(int64_t N, int64_t E, int B, int D, int H, int F, in
     L.RC = take((size_t)L.ec * H * f);
     L.SB = take((size_t)dirs * L.ec * H * f);
     L.h1n = take((size_t)L.ec * H * f);  // combined normalised rows (input of state_net.4 when features are wanted)
-    // the second lane's copy of the per-chunk buffers P .. h1n (same offsets + lane_stride) and its own weight-split scratch
-    L.lane_stride = off - L.P;
-    if (L.lanes == 2) off += L.lane_stride;
-    L.wsplit2 = take(L.lanes == 2 ? gemm_bf16x3_workspace_bytes(H > D ? H : D, H > D ? H : D) : 256);
+    const int64_t table = (int64_t)B * R;
+    L.pair_max = (L.dedupe && scorer_pairs() && !use_f32_gemm() && table <= kPairTableMax && E >= 1024) ? (E < table ? E : table) : 0;
+    L.pair_table = take(L.pair_max ? (size_t)table * 4 : 256);
+    L.pair_count = take(L.pair_max ? (size_t)(B + 1) * 4 : 256);
+    L.pair_key = take(L.pair_max ? (size_t)L.pair_max * 4 : 256);
+    L.pair_rcx = take(L.pair_max ? (size_t)L.pair_max * D * f : 256);
+    L.pair_rc = take(L.pair_max ? (size_t)L.pair_max * H * f : 256);
     L.total = off;
     return L;
 }
@@ -696,28 +776,6 @@ extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, in
     if (N < 0 || E < 0 || B < 1 || D < 1 || H < 1) return 0;
     const int F = 2 * 2 * (1 + dde_rounds + dde_reverse_rounds);
     return fwd_layout(N, E, B, D, H, F, num_relations, 2).total;
-}
-
-// The scorer's second lane: one side stream and three events per host thread and device, made on first use and kept.
-struct SideLane {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
-};
-static int side_lane(SideLane** out) {
-    constexpr int kMaxDev = 16;
-    static thread_local SideLane lanes[kMaxDev];
-    int dev = 0;
-    EVI_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDev) return fail(EVI_ERR_UNSUPPORTED, "evi_retriever_forward: device ordinal %d outside the side-lane table", dev);
-    SideLane& l = lanes[dev];
-    if (!l.stream) {
-        EVI_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        EVI_HIP_CHECK(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
-        EVI_HIP_CHECK(hipEventCreateWithFlags(&l.mid, hipEventDisableTiming));
-        EVI_HIP_CHECK(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
-    }
-    *out = &l;
-    return EVI_OK;
 }
 
 // Backward context of retriever_run (null: forward only).  Gradients use the weights struct's layout (float* written).
@@ -988,30 +1046,6 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     const PrepLayout PL = prep_layout(D, H, F);
     auto planes = [&](size_t off) -> const void* { return prep ? prep + off : nullptr; };
 
-    // Two lanes.  The forward alternates MFMA-bound launches (the GEMMs: 250 VGPRs, one workgroup per CU) with HBM-bound ones
-    // (k_edge_features, k_state_combine: gathers and 12-18 KB of rows per edge) — on one stream each kind leaves the other
-    // half of the CU idle.  So a forward-only call runs its edge chunks alternately on the caller's stream and on a side
-    // stream (own per-chunk buffers), the second lane one stage behind the first, and the hardware overlaps one lane's
-    // GEMMs with the other's per-edge kernels; the latency-bound CSR + DDE launches run on the side lane under the node
-    // projections.  Same kernels, same arguments, same results — only the order in time changes.  The backward pass
-    // (gradients accumulate across chunks in a fixed order) and timed runs (evi_timing_enable) stay on one stream.
-    SideLane* side = nullptr;
-    if (L.lanes == 2 && !bw && !timing_enabled()) {
-        if ((rc = side_lane(&side))) return rc;
-        EVI_HIP_CHECK(hipEventRecord(side->fork, st));  // whatever produced the batch on the caller's stream
-        EVI_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-    }
-    auto structure_features = [&](void* on) -> int {
-        int r;
-        if ((r = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
-                               I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
-                               evi_graph_csr_workspace_bytes(N), on)))
-            return r;
-        return evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
-                                          I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, on);
-    };
-    if (side && (rc = structure_features(side->stream))) return rc;
-
     // 1. projections
     if ((rc = scorer_gemm(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, wsplit, st, planes(PL.p_entity)))) return rc;
     if ((rc = scorer_gemm(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, wsplit, st, planes(PL.p_entity)))) return rc;
@@ -1039,13 +1073,14 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         if ((rc = scorer_gemm(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     }
 
-    // 2. structure features: on the side lane (started before the projections, see above) when there is one
-    if (!side) {
-        if ((rc = structure_features(stream))) return rc;
-    } else {
-        EVI_HIP_CHECK(hipEventRecord(side->mid, side->stream));
-        EVI_HIP_CHECK(hipStreamWaitEvent(st, side->mid, 0));
-    }
+    // 2. structure features
+    if ((rc = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
+                            I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
+                            evi_graph_csr_workspace_bytes(N), stream)))
+        return rc;
+    if ((rc = evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
+                                         I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
+        return rc;
 
     // 3-5. factored state_net.0 (see the header), per edge chunk
     auto PF = [&](size_t off) { return reinterpret_cast<float*>(const_cast<char*>(prep) + off); };
@@ -1123,19 +1158,35 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         const size_t have = bw ? bw->saved_bytes : out->saved_bytes;
         if (have < need) return fail(EVI_ERR_NOMEM, "evi_retriever: saved buffer %zu B < %zu B", have, need);
     }
-    if (side) {  // everything the chunks read is in flight on the caller's stream: the side lane starts after it
-        EVI_HIP_CHECK(hipEventRecord(side->fork, st));
-        EVI_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    // r_ctx Wc^T once per (relation, graph) pair (forward-only calls; the backward and the saved-activation forward keep per-edge rows)
+    const bool pairs = L.pair_max > 0 && !bw && !saved;
+    if (pairs) {
+        const int64_t R = b->num_relations;
+        int32_t *table = I32(L.pair_table), *count = I32(L.pair_count), *key = I32(L.pair_key);
+        EVI_HIP_CHECK(hipMemsetAsync(table, 0, (size_t)B * R * 4, st));
+        hipLaunchKernelGGL(k_pair_mark, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr, b->edge_batch, E, R, table);
+        hipLaunchKernelGGL(k_pair_rank, dim3((unsigned)B), dim3(1024), 0, st, table, R, count);
+        hipLaunchKernelGGL(k_pair_slots, dim3((unsigned)B), dim3(256), 0, st, table, R, B, count, key);
+        hipLaunchKernelGGL(k_pair_rows, dim3((unsigned)((L.pair_max + 3) / 4)), dim3(256), 0, st, key, count + B, R, rel_repr, gate_q, bias_q,
+                           D, F32(L.pair_rcx));
+        EVI_LAUNCH_CHECK();
+        // always the tiled split-bf16 kernel, also for a handful of pairs: a row's result does not depend on where it sits in the
+        // product, so the pair rows equal the per-edge rows bit for bit (the exact-f32 skinny kernel would not)
+        if (prep && t_gemm_single != 2) {
+            if ((rc = launch_gemm_nt_bf16x3_wplanes(F32(L.pair_rcx), L.pair_max, D, D, planes(PL.p_wc), H, nullptr, 0, F32(L.pair_rc), H, st,
+                                                    t_gemm_single, count + B)))
+                return rc;
+        } else if ((rc = launch_gemm_nt_bf16x3(F32(L.pair_rcx), L.pair_max, D, D, wc, H, D, nullptr, 0, F32(L.pair_rc), H, wsplit, st,
+                                               t_gemm_single, count + B))) {
+            return rc;
+        }
     }
-    hipStream_t const st_main = st;
-    void* const wsplit_main = wsplit;
-    for (int64_t e0 = 0, ci = 0; e0 < E; e0 += L.ec, ++ci) {
+    // (r03: alternating the chunks between the caller's stream and a side stream, so that one chunk's HBM-bound per-edge kernels
+    // run under the other's GEMMs, was built and measured: 3.471 -> 3.427 ms per forward, nothing once the pair rows above were
+    // in.  The GEMM workgroup owns its CU — 2 x 250 of the 512 VGPRs of every SIMD, 128 KB of LDS — so nothing co-resides with it
+    // and two streams only interleave whole kernels.  Removed.)
+    for (int64_t e0 = 0; e0 < E; e0 += L.ec) {
         const int64_t ec = (E - e0) < L.ec ? (E - e0) : L.ec;
-        const bool on_side = side && (ci & 1);
-        hipStream_t st = on_side ? side->stream : st_main;  // this chunk's lane
-        void* wsplit = on_side ? static_cast<void*>(base + L.wsplit2) : wsplit_main;
-        const size_t lane_off = on_side ? L.lane_stride : 0;
-        auto F32 = [&](size_t off) { return reinterpret_cast<float*>(base + off + lane_off); };  // per-chunk buffers only below
         EdgeFeatArgs a;
         a.edge_index = b->edge_index;
         a.E = E;
@@ -1173,7 +1224,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
             pAux = q;
         }
         a.P = pP;
-        a.RCX = pRCX;
+        a.RCX = pairs ? nullptr : pRCX;
         a.XS = pXS;
         a.aux = pAux;
         int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
@@ -1191,15 +1242,11 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
-        if (side && ci == 0) {  // the second lane runs one stage behind: its first per-edge kernel starts under this lane's GEMMs
-            EVI_HIP_CHECK(hipEventRecord(side->mid, st));
-            EVI_HIP_CHECK(hipStreamWaitEvent(side->stream, side->mid, 0));
-        }
         // (r03: writing P / RCX / XS as bf16 hi / lo planes and multiplying them on a pre-split LDS-DMA GEMM was wired in here,
         // bit-identical, and measured with rocprofv3 on this batch: 288.8 us per launch against 285.0 us for this kernel, the edge
         // kernel 344 against 330 us — no gain inside the pipeline, so that kernel and its entry points were removed)
         if ((rc = scorer_gemm(pP, ec, D, D, wa, H, D, nullptr, 0, pPA, H, wsplit, st, planes(PL.p_wa)))) return rc;
-        if ((rc = scorer_gemm(pRCX, ec, D, D, wc, H, D, nullptr, 0, pRC, H, wsplit, st, planes(PL.p_wc)))) return rc;
+        if (!pairs && (rc = scorer_gemm(pRCX, ec, D, D, wc, H, D, nullptr, 0, pRC, H, wsplit, st, planes(PL.p_wc)))) return rc;
         if ((rc = scorer_gemm(pXS, M, D, D, wb, H, D, w->state0_b, 0, pSB, H, wsplit, st, planes(PL.p_wb)))) return rc;
         }
         CombineArgs c;
@@ -1208,7 +1255,11 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         c.e_begin = e0;
         c.e_count = ec;
         c.PA = pPA;
-        c.RC = pRC;
+        c.RC = pairs ? reinterpret_cast<float*>(base + L.pair_rc) : pRC;
+        c.pair_table = pairs ? I32(L.pair_table) : nullptr;
+        c.edge_attr = b->edge_attr;
+        c.edge_batch = b->edge_batch;
+        c.R = b->num_relations;
         c.SB = pSB;
         c.HcN = hcn;
         c.aux = pAux;
@@ -1298,10 +1349,6 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         }
         // struct_proj.0: weight [D, F] += dU^T SX (its bias gradient, the column sums of dU, came with the kernel's partials)
         if ((rc = tn_gemm(BF(BL.DU), D, BF(BL.SX), F, M, G(g->struct_w), 1, BL, bws, st))) return rc;
-    }
-    if (side) {  // join: the caller's stream continues after the side lane's last chunk
-        EVI_HIP_CHECK(hipEventRecord(side->join, side->stream));
-        EVI_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
     }
     if (!bw) return EVI_OK;
     // ---- backward: once per batch ----------------------------------------------------------------------------------

@@ -201,6 +201,33 @@ def test_retriever_forward_matches_oracle_webqsp_shape(dev, dedupe):
     assert np.array_equal(out.query_ids.cpu().numpy(), ref["query_ids"])
 
 
+@pytest.mark.parametrize("B,E_g,R,D,features", [(5, 900, 37, 96, True), (3, 2100, 600, 256, False), (2, 700, 1, 64, True),
+                                                  (64, 40, 9, 32, True)])
+def test_relation_graph_pair_rows_equal_the_per_edge_rows_bit_for_bit(dev, monkeypatch, B, E_g, R, D, features):
+    """The forward multiplies r_ctx Wc^T once per distinct (relation, graph) pair (device-side count, GemmBatch::m_dev) and the
+    combine kernel looks the row up; EVI_SCORER_PAIRS=0 keeps one row per edge.  Same arithmetic on the same values: every output
+    must be IDENTICAL — logits, both directions, the edge features.  Cases: few / many relations per graph, ONE relation, more
+    graphs than a pair table row is wide."""
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(B, nodes_per_graph=max(60, E_g // 4), edges_per_graph=E_g, emb_dim=D, num_relations=R, seed=B + R)
+    torch.manual_seed(R)
+    model = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
+    model.emit_edge_embeddings = features
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = R
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("EVI_SCORER_PAIRS", flag)
+        o = model(batch)
+        outs[flag] = (o.logits.clone(), o.logits_fwd.clone(), o.logits_bwd.clone(),
+                      None if o.edge_embeddings is None else o.edge_embeddings.clone())
+    for a, b in zip(outs["0"], outs["1"]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    ref = oscorer.retriever_forward({k: v.cpu().numpy() for k, v in model.state_dict().items()}, sb, num_rounds=2, num_reverse_rounds=2)
+    assert float(np.max(np.abs(outs["1"][0].cpu().numpy() - ref["logits"]))) <= 3e-4
+
+
 @pytest.mark.parametrize("D,H,E_g", [(768, 768, 1200), (1024, 1024, 700), (96, 64, 300)])
 def test_retriever_forward_f16x2_option_within_the_score_tolerance(dev, D, H, E_g):
     """matmul_precision="f16x2" (opt-in, evaluation only): two f16 MFMA products — activations split hi + lo in f16, every
