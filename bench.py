@@ -242,7 +242,12 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     E, N, H = sb.num_edges, sb.num_nodes, D
     # projections + Wc node_repr + per edge (Wa p, Wc r_ctx: E rows; Wb s: 2E rows; state_net.4: E rows — it runs once on the
     # softmax-combined row, the head is folded) — DESIGN.md §4
-    gemm_flops = 2.0 * D * D * (N + 1 + 3 * graphs + relations) + 2.0 * N * D * H + 8.0 * E * D * H + 2.0 * E * H * H
+    # ... of which the relation-context block (Wc r_ctx) is multiplied once per distinct (relation, graph) PAIR by a forward-only
+    # call, not once per edge (scorer.hip, k_pair_*): the executed flops count the pair rows
+    eb = torch.repeat_interleave(torch.arange(graphs, device=dev), torch.from_numpy(np.diff(sb.edge_ptr)).to(dev))
+    pairs = int(torch.unique(eb * relations + batch.edge_attr.to(dev).view(-1)).numel()) if not os.environ.get("EVI_SCORER_PAIRS", "1").startswith("0") else E
+    gemm_flops = 2.0 * D * D * (N + 1 + 3 * graphs + relations) + 2.0 * N * D * H + (6.0 * E + 2.0 * pairs) * D * H + 2.0 * E * H * H
+    gemm_flops_per_edge_form = gemm_flops + 2.0 * (E - pairs) * D * H
 
     def one():
         out = model(batch)
@@ -305,6 +310,33 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         f16x2 = {"forward_logits_only_ms_per_batch": t_f16 * 1e3, "speedup_over_default": t_lite / t_f16,
                  "max_abs_dlogit_vs_default": float((lo2 - lite_logits).abs().max().item()),
                  "topk_sets_changed_vs_default": changed, "of_graph_k_boundaries": graphs * len(K_WINDOW)}
+    # How much the per-pair rows save depends on how often a graph repeats its relations.  The batch above draws every edge's
+    # relation uniformly from all 4 096 (~2 600 distinct per 4 096-edge graph: the hard end); the same batch with 300 distinct
+    # relations per graph — synthetic too, a sensitivity figure, not a dataset claim — shows the other end.
+    pair_rows = None
+    if pairs < E:
+        gen = torch.Generator(device=dev).manual_seed(11)
+        per_graph = min(300, relations)
+        sets = torch.randint(0, relations, (graphs, per_graph), device=dev, generator=gen)
+        attr0, emb0 = batch.edge_attr, batch.edge_embeddings
+        attr1 = sets[eb, torch.randint(0, per_graph, (E,), device=dev, generator=gen)]
+        table = torch.randn(relations, D, device=dev, generator=gen)
+        batch.edge_attr, batch.edge_embeddings = attr1, table[attr1]
+        try:
+            model(batch)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                model(batch)
+            torch.cuda.synchronize(dev)
+            t_skew = (time.perf_counter() - t0) / iters
+            pairs1 = int(torch.unique(eb * relations + attr1).numel())
+        finally:
+            batch.edge_attr, batch.edge_embeddings = attr0, emb0
+        pair_rows = {"what": "state_net.0's relation-context block multiplied once per distinct (relation, graph) pair (forward-only calls)",
+                     "pairs_per_graph_this_batch": pairs / graphs, "edges_per_graph": E / graphs,
+                     "with_300_relations_per_graph": {"pairs_per_graph": pairs1 / graphs,
+                                                      "forward_logits_only_ms_per_batch": t_skew * 1e3}}
     model.emit_edge_embeddings = True
     gemm_ms = ms[2] / iters
     tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -315,6 +347,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     roof = {"bound": "mfma", "achieved": executed_tf, "peak": peak, "unit": "TFLOP/s", "frac": executed_tf / peak,
             "kernel": kname, "algorithmic_tflops": tf, "gemm_ms_per_batch": gemm_ms,
             "gemm_launches_per_batch": ln[2] / iters, "algorithmic_flops_per_batch": gemm_flops,
+            "relation_graph_pairs": pairs, "edges": E, "algorithmic_flops_per_batch_with_one_relation_row_per_edge": gemm_flops_per_edge_form,
             "edge_feature_ms_per_batch": ms[3] / iters, "traffic": None, "traffic_source": None}
     pm = pmc_leg_traffic("scorer", f"D{D}", "gemm")
     if pm is not None and gemm_ms > 0:
@@ -330,7 +363,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         return {"workload": f"{graphs} graphs, N={N}, E={E}, D=H={D}, DDE 2+2, bidirectional",
                 "forward_ms_per_batch": t_fwd * 1e3, "forward_logits_only_ms_per_batch": t_lite * 1e3,
                 "metrics_ms_per_batch": t_met * 1e3, "queries_per_s": graphs / (t_lite + t_met), "edges_per_s": E / t_lite,
-                "f16x2": f16x2, "roofline": roof}
+                "f16x2": f16x2, "pair_rows": pair_rows, "roofline": roof}
     # training-shaped step (§8f-4): differentiable forward (per-edge intermediates kept) -> RetrieverLoss -> backward
     # (evi_retriever_backward replays them); eval-mode graph (no dropout), gradients of all 25 parameters
     from evi_rag_amd.loss import RetrieverLoss
@@ -402,6 +435,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
         "forward_logits_only_ms_per_batch": t_lite * 1e3,
         "metrics_ms_per_batch": t_met * 1e3,
         "f16x2": f16x2,
+        "pair_rows": pair_rows,
         "train_step_ms_per_batch": t_train * 1e3,
         "train": train_obj,
         "queries_per_s": graphs / (t_fwd + t_met),

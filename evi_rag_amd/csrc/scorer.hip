@@ -17,6 +17,8 @@
 //      node, so the work is  Wc node_repr [N rows, once per batch],  Wa p and Wc r_ctx [E rows],
 //      Wb s [2E rows]  —  8 D H flops per edge instead of 12 D H for the concatenated form, and the
 //      [2E, 3D+1] input is never materialised                                      -> gemm*.hip
+//      Forward-only calls go one step further: r_ctx depends on the edge only through its (relation, graph) pair, so
+//      Wc r_ctx is multiplied once per distinct PAIR (k_pair_* below; count kept on the device) instead of once per edge.
 //      then one wave per edge sums the terms, LayerNorm + GELU                    -> k_state_combine
 //   5. score_head after state_net.4 is one linear map of the normalised row, so the head is FOLDED:
 //      logit_dir = (W2^T w) . y_dir + (w . b2 + b), and the 2-way softmax combine happens in k_state_combine.

@@ -636,7 +636,10 @@ typedef struct EviRetrieverOutput {
  * evi_retriever_backward.  direction_mode: 0 bidirectional, 1 forward, 2 backward.
  * Dense contractions run on the split-bf16 GEMM (evi_gemm_nt_bf16x3) unless the environment
  * variable EVI_SCORER_GEMM=f32 selects the exact f32-MFMA GEMM; batch.matmul_precision = 1 opts a training run into
- * single-product bf16 (see the field). */
+ * single-product bf16 (see the field).
+ * Forward-only calls (no output.saved) multiply state_net.0's relation-context block once per distinct (relation, graph)
+ * pair of the batch instead of once per edge — same values, bit for bit (tests/test_retriever_gpu.py); it needs
+ * batch.num_relations <= E and num_graphs * num_relations <= 2^22, else — or with EVI_SCORER_PAIRS=0 — one row per edge. */
 /* C [M, N] (+)= A^T B for A [K, M], B [K, N] f32 row-major (row strides lda, ldb) and K long: the weight-gradient product of
  * a Linear layer over K rows (autograd's `grad_out.t() @ input` behind every nn.Linear of src/models/components/retriever.py).
  * Split-bf16 arithmetic like evi_gemm_nt_bf16x3, split-K with an ordered reduction (deterministic, no float atomics). */
