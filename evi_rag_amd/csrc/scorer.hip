@@ -413,10 +413,19 @@ __global__ void k_fold_head_final(const float* __restrict__ partial, const float
         for (int s = 0; s < kFoldSlices; ++s) acc += partial[(int64_t)s * H + j];
         v[j] = acc;
     }
-    if (j == 0) {
-        float acc = score_b[0];
-        for (int i = 0; i < H; ++i) acc = fmaf(score_w[i], b2[i], acc);
-        v[H] = acc;
+    // v[H] = score_w . b2 + score_b by the first workgroup: per-thread strided partial sums, then a fixed-order tree in LDS (one
+    // thread walking all H products took 48 us — twice per training step, where the weights change every step)
+    if (blockIdx.x == 0) {
+        __shared__ float s_dot[256];
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) acc = fmaf(score_w[i], b2[i], acc);
+        s_dot[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) s_dot[threadIdx.x] += s_dot[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) v[H] = s_dot[0] + score_b[0];
     }
 }
 
@@ -927,7 +936,12 @@ static int colsum_into(const float* X, int64_t rows, int cols, float* out, int a
     if (rows <= 0) return EVI_OK;
     float* part = reinterpret_cast<float*>(ws + L.colpart);
     const int nb = (int)((rows + kColsumRows - 1) / kColsumRows);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(nb, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part);
+    if (nb == 1) {  // one row block: summed straight into `out`
+        hipLaunchKernelGGL(k_colsum_partial, dim3(1, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part, out, accumulate);
+        EVI_LAUNCH_CHECK();
+        return EVI_OK;
+    }
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part, static_cast<float*>(nullptr), 0);
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, nb, (int64_t)cols, out, accumulate);
     EVI_LAUNCH_CHECK();
     return EVI_OK;
@@ -941,7 +955,7 @@ static int colsum_into_multi(const float* X, int64_t rows, int Q, int W, float* 
     const int nb = (int)((rows + kColsumRows - 1) / kColsumRows);
     ReduceDst d{};
     for (int q = 0; q < Q; ++q) d.p[q] = dst[q];
-    hipLaunchKernelGGL(k_colsum_partial, dim3(nb, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb, (unsigned)((cols + 255) / 256)), dim3(256), 0, st, X, rows, cols, part, static_cast<float*>(nullptr), 0);
     hipLaunchKernelGGL(k_reduce_partials_multi, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, nb, Q, W, d);
     EVI_LAUNCH_CHECK();
     return EVI_OK;

@@ -228,7 +228,10 @@ __global__ void k_keep_zero_id_rows(const float* __restrict__ src, const int64_t
 constexpr int kColsumRows = 256;
 // block = (kColsumRows rows, 256 columns): a thread sums its column over the rows eight at a time (eight loads in flight,
 // added in a fixed order)
-__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t rows, int cols, float* __restrict__ part) {
+// `direct` (one row block only, gridDim.x == 1): the sum goes straight to out[c] (+= when accumulate) — no partial table, no
+// second launch (the question-side bias gradients sum B = 32 rows)
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t rows, int cols, float* __restrict__ part,
+                                                        float* __restrict__ direct = nullptr, int accumulate = 0) {
     const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
     const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
     const int c = blockIdx.y * 256 + threadIdx.x;
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
     for (; r < r1; ++r) acc += X[r * cols + c];
-    part[(int64_t)blockIdx.x * cols + c] = acc;
+    if (direct) direct[c] = accumulate ? direct[c] + acc : acc;  // the order of k_reduce_partials: out + partial
+    else part[(int64_t)blockIdx.x * cols + c] = acc;
 }
 
 // ---- the head: state_net.4 and score_head from ysum [H] and S ---------------------------------------------

@@ -331,7 +331,13 @@ class Retriever(nn.Module):
         dev, E, N, B = pack["dev"], pack["E"], pack["N"], pack["B"]
         D, H = self.emb_dim, self.hidden_dim
         fields = self._param_fields()
-        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for _, p in fields]
+        # `grads_in_place` (set by RetrieverTrainer, whose `.grad`s are views of ONE flat buffer it has just cleared): the kernels
+        # write every gradient straight into `p.grad` and autograd gets None — no 25 temporaries, no 25 accumulate-adds per step.
+        # OVERWRITE semantics (the C backward clears what it writes): only for callers that run one backward per zero_grad.
+        in_place = bool(getattr(self, "grads_in_place", False)) and all(
+            p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.device == p.device
+            and p.grad.shape == p.shape for _, p in fields)
+        grads = [p.grad if in_place else torch.empty_like(p, memory_format=torch.contiguous_format) for _, p in fields]
         w = self._weights_struct()
         g = _lib.EviRetrieverWeights()
         g.emb_dim, g.hidden_dim, g.num_topics = w.emb_dim, w.hidden_dim, w.num_topics
@@ -356,7 +362,7 @@ class Retriever(nn.Module):
                                               saved.data_ptr() if saved is not None else None,
                                               saved.numel() if saved is not None else 0,
                                               torch.cuda.current_stream(dev).cuda_stream))
-        return grads
+        return [None] * len(grads) if in_place else grads
 
     def _empty_output(self, head_idx: torch.Tensor, return_features: bool):
         dev = head_idx.device

@@ -165,6 +165,9 @@ class RetrieverTrainer:
         else:
             raise ValueError(f"Unsupported scheduler type '{stype}' (cosine or none).")
         self.gradient_clip_val = None if not gradient_clip_val else float(gradient_clip_val)
+        # one backward per zero_grad, `.grad`s are views of the optimiser's flat buffer: the backward kernels write them directly
+        if hasattr(model, "_launch_backward"):
+            model.grads_in_place = True
         self.group = process_group
         self.global_step = 0
         self.current_epoch = 0
