@@ -165,9 +165,6 @@ class RetrieverTrainer:
         else:
             raise ValueError(f"Unsupported scheduler type '{stype}' (cosine or none).")
         self.gradient_clip_val = None if not gradient_clip_val else float(gradient_clip_val)
-        # one backward per zero_grad, `.grad`s are views of the optimiser's flat buffer: the backward kernels write them directly
-        if hasattr(model, "_launch_backward"):
-            model.grads_in_place = True
         self.group = process_group
         self.global_step = 0
         self.current_epoch = 0
@@ -230,7 +227,16 @@ class RetrieverTrainer:
                                              num_graphs, near, True)
         bad = scalars[15] == 0.0  # edges not grouped by graph: the loss kernel's groups would be wrong (loader contract)
         self._ungrouped = bad if self._ungrouped is None else (self._ungrouped | bad)
-        logits.backward(grad.view_as(logits))
+        # one backward per zero_grad and `.grad`s that are views of the flat buffer cleared above: for THIS backward the kernels
+        # write the gradients in place (overwrite semantics — so the switch does not outlive the call)
+        in_place = hasattr(model, "_launch_backward")
+        if in_place:
+            model.grads_in_place = True
+        try:
+            logits.backward(grad.view_as(logits))
+        finally:
+            if in_place:
+                model.grads_in_place = False
         world = self._world()
         if world > 1:
             self._all_reduce_grads()
