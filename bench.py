@@ -1130,16 +1130,34 @@ def arm_deadline(seconds, rank):
     return t
 
 
+def barrier(dev):
+    """dist.barrier on THIS rank's GPU (RCCL: the device is named, not guessed from the rank)."""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[dev.index])
+    else:
+        dist.barrier()
+
+
 class Ctx:
     """What every leg needs: the device, the rank layout and the loaded library."""
 
     def __init__(self, dev, world, rank, lib):
         self.dev, self.world, self.rank, self.lib = dev, world, rank, lib
 
+    def agree(self, flag):
+        """`flag` on one rank, its OR over the ranks on several: every decision that sets how many COLLECTIVE steps a rank runs
+        (a time-based warm-up loop, say) goes through here — ranks that count differently pair their all-gathers with the
+        wrong partners' and hang."""
+        if self.world <= 1:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=self.dev)
+        all_reduce_(t, dist.ReduceOp.MAX)
+        return bool(t.item() > 0.0)
+
     def fence(self):
         torch.cuda.synchronize(self.dev)
         if self.world > 1:
-            dist.barrier()
+            barrier(self.dev)
             torch.cuda.synchronize(self.dev)
 
 
@@ -1226,7 +1244,8 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             # in its steady state (the first ~20 ms of two-lane steps after an idle period run ~10 % slower)
             t_ramp = time.perf_counter()
             n_pre = 0
-            while n_pre < max(2, warmup) or time.perf_counter() - t_ramp < 0.05:
+            # (each step is a collective: how long to go on is decided by ALL ranks together — ctx.agree — never by a rank's own clock)
+            while ctx.agree(n_pre < max(2, warmup) or time.perf_counter() - t_ramp < 0.05):
                 for b in range(4):
                     step(n_pre + b)
                 n_pre += 4
@@ -1238,7 +1257,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
             torch.cuda.synchronize(dev)
             # keep warming (untimed) until ~50 ms of sustained load have passed: in the first tens of milliseconds after an
             # idle period the same kernels run up to 10 % slower, which a 3-step warm-up of a small shard does not cover
-            while warmup > 0 and time.perf_counter() - t_ramp < 0.05:
+            while ctx.agree(warmup > 0 and time.perf_counter() - t_ramp < 0.05):  # collective steps: the ranks decide together
                 for b in range(min(4, n_batches)):
                     step(b)
                 torch.cuda.synchronize(dev)
@@ -1281,7 +1300,7 @@ def run_index_leg(ctx, *, N, D, Q, k, index_dtype, method, steps, warmup, seed, 
         t_all = time.perf_counter()
         lib.evi_timing_enable(1)
         n_done = 0
-        while time.perf_counter() - t_all < sustained_s or len(chunks) < 4:
+        while ctx.agree(time.perf_counter() - t_all < sustained_s or len(chunks) < 4):
             t0 = time.perf_counter()
             for b in range(per_chunk):
                 index.topk_async(queries[(n_done + b) % n_batches], k)
@@ -1569,7 +1588,13 @@ def main():
         if REHEARSAL_BACKEND == "gloo":
             dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            # lazy communicator creation (the first collective of a group builds it: ncclCommInitRank over the store) — the
+            # path every torchrun job on ROCm takes.  EVI_NCCL_EAGER_INIT=1 binds the device at init instead (device_id: eager
+            # init, sub-groups by ncclCommSplit).
+            if os.environ.get("EVI_NCCL_EAGER_INIT", "") == "1":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group("nccl", timeout=tmo)
 
     from evi_rag_amd import _lib
 
@@ -1657,7 +1682,7 @@ def main():
                 result["end_to_end"] = {"skipped": str(exc)}
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if world > 1 or rehearse:
-        dist.barrier()
+        barrier(dev)
         dist.destroy_process_group()
 
 

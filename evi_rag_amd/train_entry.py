@@ -182,7 +182,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     if world > 1:
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("EVI_NCCL_EAGER_INIT", "") == "1":
+            dist.init_process_group("nccl", device_id=dev)  # eager init, sub-groups by ncclCommSplit
+        else:
+            dist.init_process_group("nccl")  # communicators built by their first collective (the device is current: set_device above)
     try:
         out = run(args.config_dir, args.overrides, device=args.device, searchpath=args.searchpath)
         if int(os.environ.get("RANK", "0")) == 0:
