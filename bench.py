@@ -353,7 +353,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     if pm is not None and gemm_ms > 0:
         # HBM bytes the GEMM kernels of ONE forward (edge features on, like the timed pass above) moved (counter passes of tools/scorer_forward_profile.py full on
         # the same batch shape), as GB/s at this run's GEMM time; the per-edge kernels' bytes beside it
-        legs = {leg: pmc_leg_traffic("scorer", f"D{D}", leg) for leg in ("edge_features", "state_combine")}
+        legs = {leg: pmc_leg_traffic("scorer", f"D{D}", leg) for leg in ("edge_features", "state_combine", "pair_rows")}
         roof.update(traffic=pm[1]["hbm_bytes_per_batch"] / (gemm_ms * 1e-3) / 1e9, traffic_unit="GB/s (HBM bytes of the GEMM launches)",
                     hbm_bytes_per_forward={"gemm": pm[1]["hbm_bytes_per_batch"],
                                            **{leg: v[1]["hbm_bytes_per_batch"] for leg, v in legs.items() if v is not None}},

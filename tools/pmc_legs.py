@@ -32,6 +32,7 @@ SCORER_LEGS = {
     "edge_features": ("k_edge_features",),
     "state_combine": ("k_state_combine",),
     "dde_csr": ("k_dde_round", "k_dde_graph", "k_csr_part", "k_graph_csr"),
+    "pair_rows": ("k_pair_mark", "k_pair_rank", "k_pair_slots", "k_pair_rows"),
     "other": (),
 }
 
