@@ -475,8 +475,10 @@ __device__ inline f4 dropout_mul4(uint64_t seed, int64_t row, int H, int d, uint
     return m;
 }
 
-template <int C4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4 : 1, 8))) void k_state_combine(CombineArgs a) {
+// FEAT: the combined normalised row is wanted (a.h1c); without it the two directions' rows are not kept.  Registers: 4 waves per SIMD at
+// C4 <= 3 (121 VGPRs; a 5-wave budget spills and ran 367 vs 258 us), 3 at C4 = 4 (154 VGPRs, was 232 and 2 waves)
+template <int C4, bool FEAT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4 : (C4 == 4 ? 3 : 1), 8))) void k_state_combine(CombineArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (le >= a.e_count) return;
@@ -508,12 +510,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
         }
     }
     float lg[2] = {0.f, 0.f};
-    f4 y[2][C4];  // the normalised rows of both directions (kept for the combined row)
+    f4 y[FEAT ? 2 : 1][C4];  // the normalised rows of both directions (kept for the combined row when it is wanted)
     int out_row = 0;
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
+        constexpr int kY = FEAT ? 1 : 0;  // y[dir * kY]: one shared row when nothing is kept
 #pragma unroll
-        for (int i = 0; i < C4; ++i) y[dir][i] = z4;
+        for (int i = 0; i < C4; ++i) y[dir * kY][i] = z4;
         if ((dir == 0 && !a.dir_fwd) || (dir == 1 && !a.dir_bwd)) continue;
         const int64_t row = (int64_t)out_row * a.e_count + le;
         const float nav = a.aux[row * 2], negdist = a.aux[row * 2 + 1];
@@ -549,9 +552,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
             const int d = 4 * lane + 256 * i;
             if (d < H) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) y[dir][i][c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
-                if (a.drop_thr) y[dir][i] = y[dir][i] * dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale);
-                dot += hsum4(ld4(a.v + d) * y[dir][i]);
+                for (int c = 0; c < 4; ++c) y[dir * kY][i][c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
+                if (a.drop_thr) y[dir * kY][i] = y[dir * kY][i] * dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale);
+                dot += hsum4(ld4(a.v + d) * y[dir * kY][i]);
             }
         }
         lg[dir] = wsum(dot) + a.v[H];
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
         if (a.logits_fwd && a.dir_fwd) a.logits_fwd[e] = lf;
         if (a.logits_bwd && a.dir_bwd) a.logits_bwd[e] = lb;
     }
-    if (a.h1c) {  // edge features requested: state_net.4 is linear, so it runs ONCE on the combined normalised row
+    if constexpr (FEAT) {  // edge features requested: state_net.4 is linear, so it runs ONCE on the combined normalised row
 #pragma unroll
         for (int i = 0; i < C4; ++i) {
             const int d = 4 * lane + 256 * i;
@@ -1295,7 +1298,13 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         c.logits_fwd = out->logits_fwd;
         c.logits_bwd = out->logits_bwd;
         const dim3 cgrid((unsigned)((ec + 3) / 4));
-        if (!replay) EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL>), cgrid, dim3(256), 0, st, c));
+        if (!replay) {
+            if (c.h1c) {
+                EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, true>), cgrid, dim3(256), 0, st, c));
+            } else {
+                EVI_DPL_DISPATCH(dpl_h, hipLaunchKernelGGL((k_state_combine<DPL, false>), cgrid, dim3(256), 0, st, c));
+            }
+        }
         EVI_LAUNCH_CHECK();
         if (out->edge_features && !replay)  // state_net.4 on the combined rows, straight into the caller's [E, H] output
             if ((rc = scorer_gemm(F32(L.h1n), ec, H, H, w->state4_w, H, H, w->state4_b, 0, out->edge_features + e0 * H, H, wsplit,
