@@ -233,7 +233,7 @@ struct EdgeFeatArgs {
 // memory and LDS instructions than one float per lane (cdna_hip_programming.md guideline 13).
 __device__ inline float hsum4(f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 template <int C4>
-__global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 8 : 4, 8))) void k_edge_features(EdgeFeatArgs a) {
     extern __shared__ float lds_wt[];  // [F][D] + b, ln_w, ln_b, gate_w [4][D]
     const int D = a.D, F = a.F;
     for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds_wt[i] = a.struct_wt[i];
@@ -283,6 +283,27 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             } else {
                 h[i] = t[i] = rc[i] = z4;
             }
+        }
+        // the DistMult product, r_ctx and the translation errors first: h, t and r_ctx (36 registers at C4 = 3) are dead before the
+        // struct MLP starts, which is what lets six waves per SIMD fit
+        float negdist[2];
+        {
+            float dsq_f = 0.f, dsq_b = 0.f;
+            float* pp = a.P + le * D;
+            float* rx = a.RCX + le * D;
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < D) {
+                    const f4 ef = h[i] + rc[i] - t[i], eb = t[i] + rc[i] - h[i];
+                    dsq_f += hsum4(ef * ef);
+                    dsq_b += hsum4(eb * eb);
+                    st4(pp + d, h[i] * rc[i] * t[i]);
+                    if (a.RCX) st4(rx + d, rc[i]);
+                }
+            }
+            negdist[0] = -sqrtf(wsum(dsq_f));
+            negdist[1] = -sqrtf(wsum(dsq_b));
         }
         // struct_proj.0 for BOTH directions in one pass over the weights: struct_raw = cat(ns[a], ns[b]) with
         // (a, b) = (head, tail) forward and (tail, head) backward, so every weight row is read from LDS once and
@@ -347,32 +368,16 @@ __global__ __launch_bounds__(1024) void k_edge_features(EdgeFeatArgs a) {
             const float nav = sigmoidf_(wsum(gacc) + gate_b);
             const int64_t row = (int64_t)out_row * a.e_count + le;
             float* xs = a.XS + row * D;
-            float dsq = 0.f;
 #pragma unroll
             for (int i = 0; i < C4; ++i) {
                 const int d = 4 * lane + 256 * i;
-                if (d < D) {
-                    const f4 err = dir == 0 ? h[i] + rc[i] - t[i] : t[i] + rc[i] - h[i];
-                    st4(xs + d, sv[i]);
-                    dsq += hsum4(err * err);
-                }
+                if (d < D) st4(xs + d, sv[i]);
             }
-            dsq = wsum(dsq);
             if (lane == 0) {
                 a.aux[row * 2] = nav;
-                a.aux[row * 2 + 1] = -sqrtf(dsq);
+                a.aux[row * 2 + 1] = negdist[dir];
             }
             ++out_row;
-        }
-        float* pp = a.P + le * D;
-        float* rx = a.RCX + le * D;
-#pragma unroll
-        for (int i = 0; i < C4; ++i) {
-            const int d = 4 * lane + 256 * i;
-            if (d < D) {
-                st4(pp + d, h[i] * rc[i] * t[i]);
-                if (a.RCX) st4(rx + d, rc[i]);
-            }
         }
     }
 }
@@ -476,9 +481,9 @@ __device__ inline f4 dropout_mul4(uint64_t seed, int64_t row, int H, int d, uint
 }
 
 // FEAT: the combined normalised row is wanted (a.h1c); without it the two directions' rows are not kept.  Registers: 4 waves per SIMD at
-// C4 <= 3 (121 VGPRs; a 5-wave budget spills and ran 367 vs 258 us), 3 at C4 = 4 (154 VGPRs, was 232 and 2 waves)
+// six waves per SIMD at C4 <= 3 (80 VGPRs), four at C4 = 4 (104), two at C4 = 5
 template <int C4, bool FEAT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4 : (C4 == 4 ? 3 : 1), 8))) void k_state_combine(CombineArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 6 : (C4 == 4 ? 4 : 2), 8))) void k_state_combine(CombineArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t le = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (le >= a.e_count) return;
@@ -494,7 +499,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
     const float* hh = a.HcN + a.edge_index[e] * H;
     const float* ht = a.HcN + a.edge_index[a.E + e] * H;
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f4 base[C4], diff[C4], pav[C4], wdv[C4], lnw[C4], lnb[C4];
+    // the per-edge rows are loaded up front; the LayerNorm weights (the same 3 KB for every edge: L1 / L2 hits) where they are used —
+    // holding them (and wd) too cost 36 registers per lane and a wave or two per SIMD
+    f4 base[C4], diff[C4], pav[C4];
 #pragma unroll
     for (int i = 0; i < C4; ++i) {
         const int d = 4 * lane + 256 * i;
@@ -502,11 +509,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
             pav[i] = ld4(pa + d);
             base[i] = ld4(rc + d);
             diff[i] = ld4(hh + d) - ld4(ht + d);
-            wdv[i] = ld4(a.wd + d);
-            lnw[i] = ld4(a.ln_w + d);
-            lnb[i] = ld4(a.ln_b + d);
         } else {
-            pav[i] = base[i] = diff[i] = wdv[i] = lnw[i] = lnb[i] = z4;
+            pav[i] = base[i] = diff[i] = z4;
         }
     }
     float lg[2] = {0.f, 0.f};
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
                 f4 x = nav * pav[i] + ld4(sb + d);
                 x += dir == 0 ? diff[i] : -diff[i];
                 x += base[i];
-                x += wdv[i] * negdist;
+                x += ld4(a.wd + d) * negdist;
                 v[i] = x;
                 sum += hsum4(x);
             } else {
@@ -551,8 +555,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C4 <= 3 ? 4
         for (int i = 0; i < C4; ++i) {
             const int d = 4 * lane + 256 * i;
             if (d < H) {
+                const f4 lnw = ld4(a.ln_w + d), lnb = ld4(a.ln_b + d);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) y[dir * kY][i][c] = gelu_erf((v[i][c] - mean) * rstd * lnw[i][c] + lnb[i][c]);
+                for (int c = 0; c < 4; ++c) y[dir * kY][i][c] = gelu_erf((v[i][c] - mean) * rstd * lnw[c] + lnb[c]);
                 if (a.drop_thr) y[dir * kY][i] = y[dir * kY][i] * dropout_mul4(a.drop_seed, (int64_t)dir * a.E + e, H, d, a.drop_thr, a.drop_scale);
                 dot += hsum4(ld4(a.v + d) * y[dir * kY][i]);
             }
@@ -1246,8 +1251,14 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         a.RCX = pairs ? nullptr : pRCX;
         a.XS = pXS;
         a.aux = pAux;
-        int64_t blocks = (ec + 15) / 16;  // 16 waves per block, one edge per wave
-        if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS: 32 waves per CU hide the gather latency
+        static const int ef_threads = [] {
+            const char* e = getenv("EVI_EF_THREADS");
+            const int n = e ? atoi(e) : 0;
+            return (n >= 64 && n <= 1024 && n % 64 == 0) ? n : 1024;
+        }();
+        const int ef_waves = ef_threads / 64;
+        int64_t blocks = (ec + ef_waves - 1) / ef_waves;  // one edge per wave
+        if (blocks > 512) blocks = 512;   // 2 blocks per CU fit in LDS
         if (!replay) {
         const int tok = timing_begin(kTimeEdge, st);
         EVI_DPL_DISPATCH(dpl_d, {
@@ -1257,7 +1268,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr = true;
             }
-            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(1024), feat_lds, st, a);
+            hipLaunchKernelGGL(k_edge_features<DPL>, dim3((unsigned)blocks), dim3(ef_threads), feat_lds, st, a);
         });
         timing_end(tok, st);
         EVI_LAUNCH_CHECK();
