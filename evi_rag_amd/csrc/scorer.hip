@@ -986,6 +986,30 @@ static int segment_rowsum_into(const float* X, int D, const int64_t* ptr, const 
     return EVI_OK;
 }
 
+// out2[s][:] = sum over segment s of X[row] * T[clamp(idx[row])], and (out != null) out[s][:] = sum of X[row], from one pass
+static int segment_rowsum_mul_into(const float* X, int D, const int64_t* ptr, const int64_t* perm, int64_t S, int64_t rows_total,
+                                   float* out, float* out2, const float* T, const int64_t* idx, int64_t idx_hi, const BwdLayout& L,
+                                   char* ws, hipStream_t st) {
+    if (S <= 0) return EVI_OK;
+    int64_t Z = (rows_total / S + 255) / 256;
+    if (Z < 1) Z = 1;
+    if (Z > 32) Z = 32;
+    const size_t cap = (size_t)kTnMaxSlices * (D > 1 ? D : 1) * (D > 1 ? D : 1) / 2;  // two partial tables share the TN partial buffer
+    while (Z > 1 && (size_t)Z * S * D > cap) --Z;
+    float* part = reinterpret_cast<float*>(ws + L.tnpart);
+    float* dst = Z == 1 ? out : part;
+    float* dst2 = Z == 1 ? out2 : part + (size_t)Z * S * D;
+    const dim3 grid((unsigned)S, (unsigned)((D + 255) / 256), (unsigned)Z);
+    if (out) hipLaunchKernelGGL(k_segment_rowsum_mul<true>, grid, dim3(256), 0, st, X, D, ptr, perm, dst, dst2, S, T, idx, idx_hi);
+    else hipLaunchKernelGGL(k_segment_rowsum_mul<false>, grid, dim3(256), 0, st, X, D, ptr, perm, dst, dst2, S, T, idx, idx_hi);
+    if (Z > 1) {
+        if (out) hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((S * D + 255) / 256)), dim3(256), 0, st, dst, (int)Z, S * D, out, 0);
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((S * D + 255) / 256)), dim3(256), 0, st, dst2, (int)Z, S * D, out2, 0);
+    }
+    EVI_LAUNCH_CHECK();
+    return EVI_OK;
+}
+
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -1357,8 +1381,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         eb.daux = BF(BL.daux);
         eb.DH = BF(BL.DH);
         eb.DT = BF(BL.DT);
-        eb.DRR = BF(BL.DRR);
-        eb.DGQ = BF(BL.DGQ);
+        // with a relation table the three uses of d r_ctx are formed from ONE stored array (DBQ) by k_segment_rowsum_mul
+        eb.DRR = L.dedupe ? nullptr : BF(BL.DRR);
+        eb.DGQ = L.dedupe ? nullptr : BF(BL.DGQ);
         eb.DBQ = BF(BL.DBQ);
         eb.DU = BF(BL.DU);
         eb.SX = BF(BL.SX);
@@ -1417,7 +1442,10 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         // relation_proj
         if (L.dedupe) {
             const int64_t R = b->num_relations;
-            if ((rc = segment_rowsum_into(BF(BL.DRR), D, bw->rel_ptr, bw->rel_perm, R, E, BF(BL.dRRu), BL, bws, st))) return rc;
+            // d rel_repr[r] = sum over the edges of relation r of d r_ctx[e] * gate_q[graph(e)]
+            if ((rc = segment_rowsum_mul_into(BF(BL.DBQ), D, bw->rel_ptr, bw->rel_perm, R, E, nullptr, BF(BL.dRRu), gate_q, b->edge_batch,
+                                              (int64_t)B - 1, BL, bws, st)))
+                return rc;
             hipLaunchKernelGGL(k_act_bwd, blocks_of(R * D), dim3(256), 0, st, BF(BL.dRRu), rel_repr, R, D, 1, (const int64_t*)nullptr);
             EVI_LAUNCH_CHECK();
             if ((rc = tn_gemm(BF(BL.dRRu), D, F32(L.rel_rows), D, R, G(g->relation_w), 0, BL, bws, st))) return rc;
@@ -1429,8 +1457,14 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
             if ((rc = colsum_into(BF(BL.DRR), E, D, G(g->relation_b), 0, BL, bws, st))) return rc;
         }
         // question side: gate (sigmoid) and bias (tanh) of the projected question, then query_proj (tanh)
-        if ((rc = segment_rowsum_into(BF(BL.DGQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dGQ), BL, bws, st))) return rc;
-        if ((rc = segment_rowsum_into(BF(BL.DBQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dBQ), BL, bws, st))) return rc;
+        if (L.dedupe) {  // d bias_q[g] = sum of d r_ctx over the graph, d gate_q[g] = sum of d r_ctx * rel_repr[relation]: one pass
+            if ((rc = segment_rowsum_mul_into(BF(BL.DBQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dBQ), BF(BL.dGQ), rel_repr, b->edge_attr,
+                                              b->num_relations - 1, BL, bws, st)))
+                return rc;
+        } else {
+            if ((rc = segment_rowsum_into(BF(BL.DGQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dGQ), BL, bws, st))) return rc;
+            if ((rc = segment_rowsum_into(BF(BL.DBQ), D, b->edge_ptr, nullptr, B, E, BF(BL.dBQ), BL, bws, st))) return rc;
+        }
         hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, BF(BL.dGQ), gate_q, (int64_t)B, D, 2, (const int64_t*)nullptr);
         hipLaunchKernelGGL(k_act_bwd, blocks_of((int64_t)B * D), dim3(256), 0, st, BF(BL.dBQ), bias_q, (int64_t)B, D, 1, (const int64_t*)nullptr);
         EVI_LAUNCH_CHECK();

@@ -149,6 +149,75 @@ __global__ __launch_bounds__(256) void k_segment_rowsum(const float* __restrict_
             (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
 }
 
+// The same sums with a per-row multiplier row: out2[z][s][:] = sum of X[row][:] * T[clamp(idx[row], 0, idx_hi)][:] (the f32 product,
+// then f64 accumulation — what summing a stored product array gives), and with PLAIN also out[z][s][:] = sum of X[row][:] from the
+// same loads.  The relation-context gradient d r_ctx [E, D] is written ONCE by k_edge_translate_bwd and its three uses
+// (d bias_q = sum over the graph, d gate_q = sum over the graph of d r_ctx * rel_repr[relation], d rel_repr = sum over the
+// relation of d r_ctx * gate_q[graph]) are formed here, instead of three [E, D] product arrays written and read back.
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void k_segment_rowsum_mul(const float* __restrict__ X, int D, const int64_t* __restrict__ ptr,
+                                                            const int64_t* __restrict__ perm, float* __restrict__ out,
+                                                            float* __restrict__ out2, int64_t S, const float* __restrict__ T,
+                                                            const int64_t* __restrict__ idx, int64_t idx_hi) {
+    __shared__ double red[4][256];
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int d = blockIdx.y * 256 + 4 * lane;
+    const int64_t b0 = ptr[s], e0 = ptr[s + 1];
+    const int64_t per = (e0 - b0 + gridDim.z - 1) / gridDim.z;
+    const int64_t b = b0 + per * blockIdx.z;
+    const int64_t e = b + per < e0 ? b + per : e0;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (d < D) {
+        int64_t p = b + grp;
+        for (; p + 12 < e; p += 16) {
+            f4 v[4], m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = perm ? perm[p + 4 * u] : p + 4 * u;
+                int64_t t = idx[row];
+                t = t < 0 ? 0 : (t > idx_hi ? idx_hi : t);
+                v[u] = ld4(X + row * D + d);
+                m[u] = ld4(T + t * D + d);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f4 pr = v[u] * m[u];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (PLAIN) acc[c] += (double)v[u][c];
+                    acc2[c] += (double)pr[c];
+                }
+            }
+        }
+        for (; p < e; p += 4) {
+            const int64_t row = perm ? perm[p] : p;
+            int64_t t = idx[row];
+            t = t < 0 ? 0 : (t > idx_hi ? idx_hi : t);
+            const f4 v = ld4(X + row * D + d);
+            const f4 pr = v * ld4(T + t * D + d);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (PLAIN) acc[c] += (double)v[c];
+                acc2[c] += (double)pr[c];
+            }
+        }
+    }
+    const int dc = blockIdx.y * 256 + threadIdx.x;
+    const int64_t o = ((int64_t)blockIdx.z * S + s) * D + dc;
+    if (PLAIN) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[grp][4 * lane + c] = acc[c];
+        __syncthreads();
+        if (dc < D) out[o] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[grp][4 * lane + c] = acc2[c];
+    __syncthreads();
+    if (dc < D) out2[o] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
 // sum over the CSR row [eb, ee) of +-rows of a [*, W] matrix into f64 accumulators (edge order = CSR order), eight rows in flight
 __device__ inline void csr_rows_accumulate(const int32_t* __restrict__ eid, int eb, int ee, const float* __restrict__ M, int W, int d,
                                            double sign, double (&acc)[4]) {
@@ -501,8 +570,8 @@ struct EdgeBwdArgs {
     const float* daux;    // [dirs * e_count, 2]
     float* DH;            // [E, D] (global rows)
     float* DT;            // [E, D]
-    float* DRR;           // [E, D]  d rel_repr row of the edge  (drc * gate_q)
-    float* DGQ;           // [E, D]  drc * rel_repr row
+    float* DRR;           // [E, D]  d rel_repr row of the edge  (drc * gate_q); null with a relation table (see k_segment_rowsum_mul)
+    float* DGQ;           // [E, D]  drc * rel_repr row; null with a relation table
     float* DBQ;           // [E, D]  drc
     float* DU;            // [dirs * e_count, D]  d (struct_proj.0 output)
     float* SX;            // [dirs * e_count, F]  struct_proj.0 input rows
@@ -733,8 +802,8 @@ __global__ __launch_bounds__(256) void k_edge_translate_bwd(EdgeBwdArgs b) {
             if (d < D) {
                 st4(b.DH + e * D + d, dh[i]);
                 st4(b.DT + e * D + d, dt[i]);
-                st4(b.DRR + e * D + d, drc[i] * gq[i]);
-                st4(b.DGQ + e * D + d, drc[i] * rr[i]);
+                if (b.DRR) st4(b.DRR + e * D + d, drc[i] * gq[i]);  // null: formed from DBQ by k_segment_rowsum_mul
+                if (b.DGQ) st4(b.DGQ + e * D + d, drc[i] * rr[i]);
                 st4(b.DBQ + e * D + d, drc[i]);
             }
         }
