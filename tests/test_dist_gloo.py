@@ -97,6 +97,23 @@ def _worker(rank, world, port, out_dir):
         m.sync()
         assert m._states["graph_count"] == 7.0 and m._states["recall_sum_at_1"] == float(sum(range(7)))
         assert edist.all_reduce_sum_([1.0, rank]) == [float(world), float(sum(range(world)))]
+        # bench.py's loop decisions: a warm-up loop whose steps are collectives must run the SAME number of steps on every rank —
+        # `Ctx.agree` is the OR over the ranks.  Rank-local clocks that disagree (rank 0 wants 3 more rounds, rank 1 wants 5)
+        # must yield the same count, the larger one, on both ranks.
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        bench.REHEARSAL_BACKEND = "gloo"
+        ctx = bench.Ctx(torch.device("cpu"), world, rank, None)
+        want_local = 3 if rank == 0 else 5
+        rounds = 0
+        while ctx.agree(rounds < want_local):
+            dist.all_reduce(torch.zeros(1))  # the "collective step" of the loop body
+            rounds += 1
+        assert rounds == 5
+        assert ctx.agree(False) is False and ctx.agree(rank == 1) is True
         # ragged gather used by the top-k artifact writer: rank r contributes r + 2 rows
         from evi_rag_amd.topk_writer import gather_padded
 
