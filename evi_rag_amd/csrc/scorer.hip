@@ -1421,20 +1421,19 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                            I32(L.out_eid), BF(BL.DH), BF(BL.DT), D, BF(BL.DDF), H, BF(BL.dNR), BF(BL.dHcN), (int64_t)N);
         EVI_LAUNCH_CHECK();
         if ((rc = scorer_gemm(BF(BL.dHcN), N, H, H, BF(BL.WcT), D, H, nullptr, 0, BF(BL.tmpN), D, wsplit, st))) return rc;
-        hipLaunchKernelGGL(k_add_inplace, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), BF(BL.tmpN), N * D);
+        // dNR += the Wc path; the id-0 rows set aside for the non-text embedding (into tmpN, in place); tanh backward: one pass
+        hipLaunchKernelGGL(k_node_grad_finish, blocks_of((N * D + 3) / 4), dim3(256), 0, st, BF(BL.dNR), BF(BL.tmpN), node_repr,
+                           b->node_embedding_ids, N, D, BF(BL.tmpN));
         if ((rc = tn_gemm(BF(BL.dHcN), H, node_repr, D, N, BF(BL.gWc), 1, BL, bws, st))) return rc;
         hipLaunchKernelGGL(k_merge_state0, dim3(H), dim3(256), 0, st, BF(BL.gWa), BF(BL.gWb), BF(BL.gWc), BF(BL.gwd), H, D,
                            G(g->state0_w));
         // the non-text embedding: its projection replaced every node row with embedding id 0
         float* dnt = BF(BL.dnt);
-        hipLaunchKernelGGL(k_keep_zero_id_rows, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), b->node_embedding_ids, N, D, BF(BL.tmpN));
         if ((rc = colsum_into(BF(BL.tmpN), N, D, dnt, 0, BL, bws, st))) return rc;
         hipLaunchKernelGGL(k_act_bwd, blocks_of(D), dim3(256), 0, st, dnt, non_text, (int64_t)1, D, 1, (const int64_t*)nullptr);
         EVI_LAUNCH_CHECK();
         if ((rc = scorer_gemm(dnt, 1, D, D, BF(BL.WeT), D, D, nullptr, 0, G(g->non_text_emb), D, wsplit, st))) return rc;
-        // entity_proj: dpre = dNR (1 - NR^2), rows with id 0 dropped
-        hipLaunchKernelGGL(k_act_bwd, blocks_of(N * D), dim3(256), 0, st, BF(BL.dNR), node_repr, N, D, 1, b->node_embedding_ids);
-        EVI_LAUNCH_CHECK();
+        // entity_proj: dpre = dNR (1 - NR^2), rows with id 0 dropped — done by k_node_grad_finish above
         if ((rc = tn_gemm(BF(BL.dNR), D, b->node_embeddings, D, N, G(g->entity_w), 0, BL, bws, st))) return rc;
         if ((rc = tn_gemm(dnt, D, w->non_text_emb, D, 1, G(g->entity_w), 1, BL, bws, st))) return rc;
         if ((rc = colsum_into(BF(BL.dNR), N, D, G(g->entity_b), 0, BL, bws, st))) return rc;

@@ -284,13 +284,21 @@ __global__ void k_act_bwd(float* __restrict__ dY, const float* __restrict__ Y, i
     dY[i] = g;
 }
 
-// dst = src where ids[row] == 0, else 0: the rows whose projection was replaced by the non-text embedding (their column sum
-// is that embedding's gradient)
-__global__ void k_keep_zero_id_rows(const float* __restrict__ src, const int64_t* __restrict__ ids, int64_t N, int D,
-                                    float* __restrict__ dst) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// The node side's three elementwise passes over [N, D] in one (float4 per thread): g = dNR + add (the Wc path joins the gathered
+// gradients); kept[v] = g where ids[v] == 0 else 0 (the rows the non-text embedding replaced: its gradient is their column sum);
+// dNR[v] = 0 where ids[v] == 0, else g * (1 - y^2) (tanh backward through entity_proj, y = node_repr).
+// `kept` may be `add` itself (a thread reads its four elements before it writes them).
+__global__ void k_node_grad_finish(float* __restrict__ dNR, const float* add, const float* __restrict__ Y,
+                                   const int64_t* __restrict__ ids, int64_t N, int D, float* kept) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= N * D) return;
-    dst[i] = ids[i / D] == 0 ? src[i] : 0.f;
+    const bool zero_id = ids[i / D] == 0;  // D % 4 == 0: the four elements share a row
+    const f4 g = ld4(dNR + i) + ld4(add + i), y = ld4(Y + i), z4 = {0.f, 0.f, 0.f, 0.f};
+    st4(kept + i, zero_id ? g : z4);
+    f4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = g[c] * (1.0f - y[c] * y[c]);
+    st4(dNR + i, zero_id ? z4 : r);
 }
 
 // column sums of X [rows, cols] into out[cols] (+)=, two ordered stages: partial per block of kColsumRows rows, then the blocks
