@@ -129,6 +129,7 @@ _SIGNATURES = {
     "evi_grad_norm": (c_int, [_P, c_int64, c_float, _P, _P, c_size_t, _P]),
     "evi_adamw_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64, c_float, _P, c_float, _P]),
     "evi_retriever_saved_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "evi_retriever_saved_bytes_full": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int]),
     "evi_retriever_backward": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P, c_size_t, _P]),
     "evi_retriever_forward_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64]),
     "evi_retriever_forward": (c_int, [POINTER(EviRetrieverWeights), POINTER(EviRetrieverBatch), c_int,

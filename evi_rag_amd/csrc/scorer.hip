@@ -797,6 +797,42 @@ extern "C" size_t evi_retriever_forward_workspace_bytes(int64_t N, int64_t E, in
     return fwd_layout(N, E, B, D, H, F, num_relations, 2).total;
 }
 
+// The node-level results of a training forward, kept behind the per-edge rows of `saved` when the caller's buffer has room
+// (evi_retriever_saved_bytes_full): projected nodes / questions / relations, the structure features, both CSR halves and
+// node_repr Wc^T.  The backward then starts from them instead of recomputing the node-level forward (three large GEMMs, the CSR
+// build, DDE, the relation de-duplication: ~0.6 ms of a 13.6 ms step at the bench shape).
+struct NodeKeep {
+    size_t node_repr, non_text, q_proj, gate_q, bias_q, rel_repr, rel_rows, ns, in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid, hcn, total;
+};
+static NodeKeep node_keep_layout(int64_t N, int64_t E, int B, int D, int H, int F, int64_t R, int dedupe) {
+    NodeKeep K;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t f = sizeof(float);
+    const size_t n1 = (size_t)(N > 0 ? N : 1), e1 = (size_t)(E > 0 ? E : 1);
+    K.node_repr = take(n1 * D * f);
+    K.non_text = take((size_t)D * f);
+    K.q_proj = take((size_t)B * D * f);
+    K.gate_q = take((size_t)B * D * f);
+    K.bias_q = take((size_t)B * D * f);
+    K.rel_repr = take((size_t)(dedupe ? R : e1) * D * f);
+    K.rel_rows = take(dedupe ? (size_t)R * D * f : 256);
+    K.ns = take(n1 * (F / 2) * f);
+    K.in_ptr = take((size_t)(N + 1) * 4);
+    K.in_nbr = take(e1 * 4);
+    K.in_eid = take(e1 * 4);
+    K.out_ptr = take((size_t)(N + 1) * 4);
+    K.out_nbr = take(e1 * 4);
+    K.out_eid = take(e1 * 4);
+    K.hcn = take(n1 * H * f);
+    K.total = off;
+    return K;
+}
+
 // Backward context of retriever_run (null: forward only).  Gradients use the weights struct's layout (float* written).
 struct BwdCtx {
     const float* dlogits;          // [E]
@@ -1080,13 +1116,29 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     char* base = static_cast<char*>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
-    float* node_repr = F32(L.node_repr);
-    float* non_text = F32(L.non_text);
-    float* q_proj = F32(L.q_proj);
-    float* gate_q = F32(L.gate_q);
-    float* bias_q = F32(L.bias_q);
-    float* rel_repr = F32(L.rel_repr);
-    float* ns = out->node_struct ? out->node_struct : F32(L.ns);
+    // node-level results: in the workspace, or — training, when `saved` has room behind its per-edge rows — in `saved`, where the
+    // backward of the same step finds them (nodes_replayed) instead of recomputing
+    const size_t edge_saved_bytes = align_up((size_t)E * saved_floats_per_edge(D, H, dirs) * sizeof(float), 256);
+    const NodeKeep NK = node_keep_layout(N, E, B, D, H, F, b->num_relations, L.dedupe);
+    char* nkeep = nullptr;
+    {
+        char* sv = bw ? const_cast<char*>(bw->saved) : static_cast<char*>(out->saved);
+        const size_t have = bw ? bw->saved_bytes : out->saved_bytes;
+        if (sv && have >= edge_saved_bytes + NK.total) nkeep = sv + edge_saved_bytes;
+    }
+    const bool nodes_replayed = bw && nkeep;
+    auto NF = [&](size_t ws_off, size_t keep_off) { return reinterpret_cast<float*>(nkeep ? nkeep + keep_off : base + ws_off); };
+    auto NI = [&](size_t ws_off, size_t keep_off) { return reinterpret_cast<int32_t*>(nkeep ? nkeep + keep_off : base + ws_off); };
+    float* node_repr = NF(L.node_repr, NK.node_repr);
+    float* non_text = NF(L.non_text, NK.non_text);
+    float* q_proj = NF(L.q_proj, NK.q_proj);
+    float* gate_q = NF(L.gate_q, NK.gate_q);
+    float* bias_q = NF(L.bias_q, NK.bias_q);
+    float* rel_repr = NF(L.rel_repr, NK.rel_repr);
+    float* rel_rows = NF(L.rel_rows, NK.rel_rows);
+    float* ns = nkeep ? NF(0, NK.ns) : (out->node_struct ? out->node_struct : F32(L.ns));
+    int32_t *in_ptr = NI(L.in_ptr, NK.in_ptr), *in_nbr = NI(L.in_nbr, NK.in_nbr), *in_eid = NI(L.in_eid, NK.in_eid);
+    int32_t *out_ptr = NI(L.out_ptr, NK.out_ptr), *out_nbr = NI(L.out_nbr, NK.out_nbr), *out_eid = NI(L.out_eid, NK.out_eid);
     void* wsplit = base + L.wsplit;
     int rc;
     // weight-derived pieces: from the caller's prepared buffer when it keeps one, else made below in the workspace
@@ -1094,6 +1146,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     const PrepLayout PL = prep_layout(D, H, F);
     auto planes = [&](size_t off) -> const void* { return prep ? prep + off : nullptr; };
 
+    if (!nodes_replayed) {  // (the backward of a step whose forward kept its node-level results skips 1 and 2)
     // 1. projections
     if ((rc = scorer_gemm(b->node_embeddings, N, D, D, w->entity_w, D, D, w->entity_b, 1, node_repr, D, wsplit, st, planes(PL.p_entity)))) return rc;
     if ((rc = scorer_gemm(w->non_text_emb, 1, D, D, w->entity_w, D, D, w->entity_b, 1, non_text, D, wsplit, st, planes(PL.p_entity)))) return rc;
@@ -1114,26 +1167,28 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         hipLaunchKernelGGL(k_first_edge_of_relation, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr,
                            E, R, first, status);
         hipLaunchKernelGGL(k_gather_relation_rows, dim3((unsigned)R), dim3(256), 0, st, b->edge_embeddings, first, D,
-                           F32(L.rel_rows));
+                           rel_rows);
         EVI_LAUNCH_CHECK();
-        if ((rc = scorer_gemm(F32(L.rel_rows), R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
+        if ((rc = scorer_gemm(rel_rows, R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     } else {
         if ((rc = scorer_gemm(b->edge_embeddings, E, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     }
 
     // 2. structure features
-    if ((rc = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, I32(L.in_ptr), I32(L.in_nbr),
-                            I32(L.in_eid), I32(L.out_ptr), I32(L.out_nbr), I32(L.out_eid), base + L.csr_ws,
-                            evi_graph_csr_workspace_bytes(N), stream)))
+    if ((rc = evi_graph_csr(b->edge_index, E, b->node_ptr, b->edge_ptr, B, N, in_ptr, in_nbr, in_eid, out_ptr, out_nbr, out_eid,
+                            base + L.csr_ws, evi_graph_csr_workspace_bytes(N), stream)))
         return rc;
-    if ((rc = evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, I32(L.in_ptr), I32(L.in_nbr),
-                                         I32(L.out_ptr), I32(L.out_nbr), w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
+    if ((rc = evi_dde_node_struct_graphs(b->topic_one_hot, b->topic_stride, 2, N, b->node_ptr, B, in_ptr, in_nbr, out_ptr, out_nbr,
+                                         w->dde_rounds, w->dde_reverse_rounds, ns, stream)))
         return rc;
+    if (nkeep && out->node_struct)  // the caller wants the structure features as well: a copy of the kept rows
+        EVI_HIP_CHECK(hipMemcpyAsync(out->node_struct, ns, (size_t)N * (F / 2) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
 
     // 3-5. factored state_net.0 (see the header), per edge chunk
     auto PF = [&](size_t off) { return reinterpret_cast<float*>(const_cast<char*>(prep) + off); };
     float *wa = prep ? PF(PL.wa) : F32(L.wa), *wb = prep ? PF(PL.wb) : F32(L.wb), *wc = prep ? PF(PL.wc) : F32(L.wc);
-    float *wd = prep ? PF(PL.wd) : F32(L.wd), *vhead = prep ? PF(PL.vhead) : F32(L.vhead), *hcn = F32(L.hcn);
+    float *wd = prep ? PF(PL.wd) : F32(L.wd), *vhead = prep ? PF(PL.vhead) : F32(L.vhead), *hcn = NF(L.hcn, NK.hcn);
     float* wt = prep ? PF(PL.wt) : F32(L.wt);
     if (!prep) {
         hipLaunchKernelGGL(k_slice_state0, dim3(H), dim3(256), 0, st, w->state0_w, H, D, wa, wb, wc, wd);
@@ -1148,7 +1203,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                            w->score_b, H, vhead);
         EVI_LAUNCH_CHECK();
     }
-    if ((rc = scorer_gemm(node_repr, N, D, D, wc, H, D, nullptr, 0, hcn, H, wsplit, st, planes(PL.p_wc)))) return rc;
+    if (!nodes_replayed && (rc = scorer_gemm(node_repr, N, D, D, wc, H, D, nullptr, 0, hcn, H, wsplit, st, planes(PL.p_wc)))) return rc;
     const int dpl_d = dpl_for(D), dpl_h = dpl_for(H);
     const size_t feat_lds = (size_t)(F + 4) * D * sizeof(float);
     // ---- backward: set-up ----------------------------------------------------------------------------------------
@@ -1417,8 +1472,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         const EviRetrieverWeights* g = bw->g;
         auto blocks_of = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
         // nodes: gather the per-edge gradients through the CSR, add the Wc path (HcN = node_repr Wc^T)
-        hipLaunchKernelGGL(k_node_gather_grad, dim3((unsigned)((N * ((D + 255) / 256 + (H + 255) / 256) + 3) / 4)), dim3(256), 0, st, I32(L.in_ptr), I32(L.in_eid), I32(L.out_ptr),
-                           I32(L.out_eid), BF(BL.DH), BF(BL.DT), D, BF(BL.DDF), H, BF(BL.dNR), BF(BL.dHcN), (int64_t)N);
+        hipLaunchKernelGGL(k_node_gather_grad, dim3((unsigned)((N * ((D + 255) / 256 + (H + 255) / 256) + 3) / 4)), dim3(256), 0, st, in_ptr, in_eid, out_ptr,
+                           out_eid, BF(BL.DH), BF(BL.DT), D, BF(BL.DDF), H, BF(BL.dNR), BF(BL.dHcN), (int64_t)N);
         EVI_LAUNCH_CHECK();
         if ((rc = scorer_gemm(BF(BL.dHcN), N, H, H, BF(BL.WcT), D, H, nullptr, 0, BF(BL.tmpN), D, wsplit, st))) return rc;
         // dNR += the Wc path; the id-0 rows set aside for the non-text embedding (into tmpN, in place); tanh backward: one pass
@@ -1447,7 +1502,7 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
                 return rc;
             hipLaunchKernelGGL(k_act_bwd, blocks_of(R * D), dim3(256), 0, st, BF(BL.dRRu), rel_repr, R, D, 1, (const int64_t*)nullptr);
             EVI_LAUNCH_CHECK();
-            if ((rc = tn_gemm(BF(BL.dRRu), D, F32(L.rel_rows), D, R, G(g->relation_w), 0, BL, bws, st))) return rc;
+            if ((rc = tn_gemm(BF(BL.dRRu), D, rel_rows, D, R, G(g->relation_w), 0, BL, bws, st))) return rc;
             if ((rc = colsum_into(BF(BL.dRRu), R, D, G(g->relation_b), 0, BL, bws, st))) return rc;
         } else {
             hipLaunchKernelGGL(k_act_bwd, blocks_of(E * D), dim3(256), 0, st, BF(BL.DRR), rel_repr, E, D, 1, (const int64_t*)nullptr);
@@ -1497,6 +1552,16 @@ extern "C" int evi_retriever_forward(const EviRetrieverWeights* w, const EviRetr
 extern "C" size_t evi_retriever_saved_bytes(int64_t E, int D, int H, int direction_mode) {
     if (E < 0 || D < 1 || H < 1 || direction_mode < 0 || direction_mode > 2) return 0;
     return (size_t)(E > 0 ? E : 1) * saved_floats_per_edge(D, H, direction_mode == 0 ? 2 : 1) * sizeof(float);
+}
+
+extern "C" size_t evi_retriever_saved_bytes_full(int64_t N, int64_t E, int B, int D, int H, int dde_rounds, int dde_reverse_rounds,
+                                                 int64_t num_relations, int direction_mode) {
+    const size_t edges = evi_retriever_saved_bytes(E, D, H, direction_mode);
+    if (edges == 0 || N < 0 || B < 1 || dde_rounds < 0 || dde_reverse_rounds < 0) return 0;
+    const int F = 2 * 2 * (1 + dde_rounds + dde_reverse_rounds);
+    const int dedupe = (num_relations > 0 && num_relations <= E) ? 1 : 0;
+    // (the per-edge part is sized for at least one edge; retriever_run places the node section behind E rows)
+    return align_up(edges, 256) + node_keep_layout(N, E, B, D, H, F, num_relations, dedupe).total;
 }
 
 extern "C" size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,

@@ -312,7 +312,9 @@ class Retriever(nn.Module):
         o.status = self._status_word(dev).data_ptr()
         o.saved, o.saved_bytes = None, 0
         if keep_for_backward and E > 0:
-            nbytes = int(lib.evi_retriever_saved_bytes(E, D, H, _DIRECTION_CODE[self.direction_mode]))
+            # per-edge rows + the node-level results (projections, structure features, CSR): the backward replays both
+            nbytes = int(lib.evi_retriever_saved_bytes_full(N, E, B, D, H, self.dde.num_rounds, self.dde.num_reverse_rounds,
+                                                            pack["num_relations"], _DIRECTION_CODE[self.direction_mode]))
             pack["saved"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             o.saved, o.saved_bytes = pack["saved"].data_ptr(), nbytes
         need = int(lib.evi_retriever_forward_workspace_bytes(N, E, B, D, H, self.dde.num_rounds,

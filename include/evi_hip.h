@@ -659,13 +659,20 @@ int evi_retriever_forward(const EviRetrieverWeights* weights, const EviRetriever
  * given dL/dlogits [E] — the autograd of Retriever._forward_impl (src/models/components/retriever.py:195-289, 403-507) in the
  * arithmetic of the forward above (eval-mode graph: no dropout, no hide-and-seek bias).  `grads` has the weights struct's
  * layout with every pointer a caller-owned OUTPUT buffer of the parameter's shape (overwritten; `prepared` ignored).
- * The forward is recomputed inside (nothing is kept from a forward call).  When batch.num_relations is given (relation rows
+ * Without `saved` the forward is recomputed inside; with it the kept rows are replayed (see EviRetrieverOutput.saved and
+ * evi_retriever_saved_bytes_full).  When batch.num_relations is given (relation rows
  * de-duplicated), rel_perm [E] lists the edge ids grouped by relation id (stable order) and rel_ptr [R+1] the group bounds.
  * Reductions run in a fixed order (f64 segment sums along the CSR / the relation grouping; no float atomics).  Gradients
  * with respect to the batch's embeddings are not produced (the reference's tables are frozen inputs). */
 size_t evi_retriever_backward_workspace_bytes(int64_t N, int64_t E, int B, int D, int H, int dde_rounds,
                                               int dde_reverse_rounds, int64_t num_relations);
 size_t evi_retriever_saved_bytes(int64_t E, int D, int H, int direction_mode);
+/* The same plus room for the forward's NODE-level results (projected nodes / questions / relations, structure features, both CSR
+ * halves, node_repr Wc^T): a `saved` buffer of at least this size makes evi_retriever_forward keep them too and lets
+ * evi_retriever_backward skip the node-level forward as well (three large GEMMs, CSR, DDE).  A buffer of only
+ * evi_retriever_saved_bytes() keeps the per-edge rows alone. */
+size_t evi_retriever_saved_bytes_full(int64_t N, int64_t E, int B, int D, int H, int dde_rounds, int dde_reverse_rounds,
+                                      int64_t num_relations, int direction_mode);
 int evi_retriever_backward(const EviRetrieverWeights* weights, const EviRetrieverBatch* batch, int direction_mode,
                            const float* dlogits, const EviRetrieverWeights* grads, const int64_t* rel_perm,
                            const int64_t* rel_ptr, void* workspace, size_t workspace_bytes, const void* saved,
