@@ -36,13 +36,10 @@ namespace evi {
 // the limit, on a 288 GB part; against 65 536 the bench batch (131 k edges) runs half the per-chunk launches (weight-gradient
 // products and their reductions above all): forward 3.24 -> 3.21 ms, optimiser step 12.89 -> 12.63 ms, same results.
 constexpr int kEdgeChunkDefault = 262144;
-static int edge_chunk() {
-    static const int v = [] {
-        const char* e = getenv("EVI_EDGE_CHUNK");
-        const int n = e ? atoi(e) : 0;
-        return n >= 64 ? n : kEdgeChunkDefault;
-    }();
-    return v;
+static int edge_chunk() {  // read per call (the multi-chunk tests switch it inside one process)
+    const char* e = getenv("EVI_EDGE_CHUNK");
+    const int n = e ? atoi(e) : 0;
+    return n >= 64 ? n : kEdgeChunkDefault;
 }
 constexpr float kLnEps = 1e-5f;  // torch.nn.LayerNorm default
 

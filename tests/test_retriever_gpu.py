@@ -201,6 +201,40 @@ def test_retriever_forward_matches_oracle_webqsp_shape(dev, dedupe):
     assert np.array_equal(out.query_ids.cpu().numpy(), ref["query_ids"])
 
 
+@pytest.mark.parametrize("chunk", [256, 1000])
+def test_per_edge_pipeline_in_several_chunks_equals_one_chunk(dev, monkeypatch, chunk):
+    """EVI_EDGE_CHUNK cuts the per-edge pipeline (edge features -> three GEMMs -> combine, and their backward) into chunks; a
+    WebQSP-sized batch is ONE chunk at the default (262 144 edges), so the several-chunk path is exercised here: forward
+    outputs must be identical (an edge's row does not depend on its chunk), parameter gradients equal up to the order in which
+    the per-chunk partial sums are added."""
+    from evi_rag_amd.retriever import Retriever
+
+    sb = synthetic.make_batch(4, nodes_per_graph=300, edges_per_graph=800, emb_dim=64, num_relations=30, seed=21)
+    batch = synthetic.as_namespace(sb, device=dev)
+    batch.num_relations = 30
+    torch.manual_seed(3)
+    model = Retriever(emb_dim=64, hidden_dim=96).to(dev).eval()
+    gl = torch.randn(sb.num_edges, device=dev)
+    res = {}
+    for tag, env in (("one", None), ("many", str(chunk))):
+        if env is None:
+            monkeypatch.delenv("EVI_EDGE_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("EVI_EDGE_CHUNK", env)
+        model.differentiable = None
+        o = model(batch)
+        fwd = (o.logits.clone(), o.logits_fwd.clone(), o.logits_bwd.clone(), o.edge_embeddings.clone())
+        model.differentiable = True
+        model.zero_grad(set_to_none=True)
+        (model(batch).logits * gl).sum().backward()
+        res[tag] = (fwd, {n: p.grad.clone() for n, p in model.named_parameters()})
+    for a, b in zip(res["one"][0], res["many"][0]):
+        assert torch.equal(a, b)
+    for n, g in res["one"][1].items():
+        scale = float(g.abs().max()) + 1e-12
+        assert float((g - res["many"][1][n]).abs().max()) <= 2e-5 * scale + 1e-7, n
+
+
 @pytest.mark.parametrize("B,E_g,R,D,features", [(5, 900, 37, 96, True), (3, 2100, 600, 256, False), (2, 700, 1, 64, True),
                                                   (64, 40, 9, 32, True)])
 def test_relation_graph_pair_rows_equal_the_per_edge_rows_bit_for_bit(dev, monkeypatch, B, E_g, R, D, features):
