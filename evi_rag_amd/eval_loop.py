@@ -24,7 +24,8 @@ DEFAULT_K_VALUES = (1, 10, 25, 50, 100, 200, 300, 400, 500)  # configs/window/de
 class RetrieverEvaluator:
     def __init__(self, model, *, loss: Optional[RetrieverLoss] = None, k_values: Sequence[int] = DEFAULT_K_VALUES,
                  split: str = "test", bridge_metrics: bool = False, feature_metrics: bool = False,
-                 ablate_topic: bool = False, callbacks: Sequence[Any] = (), emit_predict_outputs: bool = False) -> None:
+                 ablate_topic: bool = False, callbacks: Sequence[Any] = (), emit_predict_outputs: bool = False,
+                 overlap_metrics: bool = True) -> None:
         if split not in ("val", "test"):
             raise ValueError(f"split must be 'val' or 'test', got {split!r}")
         self.model = model
@@ -42,16 +43,40 @@ class RetrieverEvaluator:
         # test_step strips them from what it returns anyway (:118).  When nobody reads them the forward runs logits-only:
         # score_head is folded into state_net.4 (csrc/scorer.hip), same logits, no features formed.
         self.need_edge_embeddings = bool(feature_metrics) or any(getattr(cb, "needs_edge_embeddings", False) for cb in self.callbacks)
+        # The loss scalars and the ranking metrics of a batch are a handful of launches that fill an eighth of the GPU (one
+        # workgroup per graph: top-k, the incremental union-find of reachability@k — 0.4-0.5 ms per batch of 32) and nothing
+        # but the epoch totals depends on them: with overlap_metrics they run on a side stream, UNDER the next batch's forward.
+        # The batch and its output are held (self._inflight) until their side work has finished — the loader's tensors are
+        # fresh allocations per batch, so nothing the side stream reads is rewritten or recycled before that — and
+        # epoch_end joins the streams.  Same kernels, same per-batch results; sums of f64 batch totals in batch order.
+        self.overlap_metrics = bool(overlap_metrics) and not ablate_topic
+        self._side = None
+        self._inflight: list = []
         self.reset()
 
     def reset(self) -> None:
         self.metrics.reset()
         if self.metrics_ablate is not None:
             self.metrics_ablate.reset()
+        self._drain()
         self._loss_sum = 0.0          # host part (batches whose loss was read eagerly)
         self._loss_dev = None         # device accumulator: sum over batches of loss * num_graphs
         self._graphs = 0
         self._batches = 0
+
+    def _drain(self) -> None:
+        """Wait for the side-stream work of every held batch and let the caller's stream see it."""
+        inflight = getattr(self, "_inflight", None)
+        if not inflight:
+            return
+        for _batch, _output, done in inflight:
+            done.synchronize()
+        inflight.clear()
+
+    def _side_stream(self, dev: torch.device):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(dev)
+        return self._side
 
     @staticmethod
     def _require_num_graphs(batch: Any) -> int:
@@ -84,25 +109,22 @@ class RetrieverEvaluator:
         """`_shared_eval_step` (:410-451)."""
         num_graphs = self._require_num_graphs(batch)
         output = self._forward(batch)
-        edge_ptr = getattr(batch, "edge_ptr", None)
-        if edge_ptr is not None and isinstance(self.loss, RetrieverLoss):
-            # edges grouped by graph (compute_edge_batch validated it): loss scalars stay on the device
-            near = None
-            if self.loss.requires_edge_is_near:
-                near = getattr(batch, "edge_is_near", None)
-                if near is None:
-                    near = batch.edge_is_near = ops.qa_edge_mask(batch.edge_index, int(batch.num_nodes), batch.q_local_indices,
-                                                                 batch.a_local_indices)
-            sc = self.loss.device_scalars(output.logits, batch.labels, edge_ptr, near)
-            term = sc[2] * float(num_graphs)
-            self._loss_dev = term if self._loss_dev is None else self._loss_dev + term
+        overlap = self.overlap_metrics and output.logits.is_cuda and output.logits.numel() > 0
+        if overlap:
+            dev = output.logits.device
+            main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+            side.wait_stream(main)  # the forward (and the batch's collation) are in flight on the caller's stream
+            with torch.cuda.stream(side):
+                self._loss_and_metrics(batch, output, num_graphs)
+                done = torch.cuda.Event()
+                done.record(side)
+            self._inflight.append((batch, output, done))
+            while len(self._inflight) > 2:  # two batches may be held; the third-last has long finished
+                self._inflight.pop(0)[2].synchronize()
         else:
-            loss_out = self._compute_loss_output(batch, output, num_graphs)
-            self._loss_sum += float(loss_out.components["infonce"] * self.loss.infonce_weight
-                                    + loss_out.components["bce"] * self.loss.bce_weight) * num_graphs
+            self._loss_and_metrics(batch, output, num_graphs)
         self._graphs += num_graphs
         self._batches += 1
-        self._update_metrics(self.metrics, batch, output, num_graphs)
         if self.metrics_ablate is not None:
             topic = getattr(batch, "topic_one_hot", None)
             if topic is None:
@@ -123,6 +145,26 @@ class RetrieverEvaluator:
             pred.edge_embeddings = None
             return pred
         return None
+
+    def _loss_and_metrics(self, batch: Any, output, num_graphs: int) -> None:
+        """The per-batch loss scalars and metric updates (current stream)."""
+        edge_ptr = getattr(batch, "edge_ptr", None)
+        if edge_ptr is not None and isinstance(self.loss, RetrieverLoss):
+            # edges grouped by graph (compute_edge_batch validated it): loss scalars stay on the device
+            near = None
+            if self.loss.requires_edge_is_near:
+                near = getattr(batch, "edge_is_near", None)
+                if near is None:
+                    near = batch.edge_is_near = ops.qa_edge_mask(batch.edge_index, int(batch.num_nodes), batch.q_local_indices,
+                                                                 batch.a_local_indices)
+            sc = self.loss.device_scalars(output.logits, batch.labels, edge_ptr, near)
+            term = sc[2] * float(num_graphs)
+            self._loss_dev = term if self._loss_dev is None else self._loss_dev + term
+        else:
+            loss_out = self._compute_loss_output(batch, output, num_graphs)
+            self._loss_sum += float(loss_out.components["infonce"] * self.loss.infonce_weight
+                                    + loss_out.components["bce"] * self.loss.bce_weight) * num_graphs
+        self._update_metrics(self.metrics, batch, output, num_graphs)
 
     def _forward(self, batch: Any):
         lite = not self.need_edge_embeddings and hasattr(self.model, "emit_edge_embeddings")
@@ -153,6 +195,7 @@ class RetrieverEvaluator:
     def epoch_end(self, *, sync: bool = False) -> Dict[str, float]:
         """`on_test_epoch_end` (:401-403): metric dict + the epoch loss; sync=True sums the metric states
         and the loss accumulators over ranks first (dist_reduce_fx="sum", sync_dist=True)."""
+        self._drain()  # the side stream's last batches; their results are visible to this thread's reads below
         loss_sum, graphs = self._loss_sum, float(self._graphs)
         if self._loss_dev is not None:
             loss_sum += float(self._loss_dev.item())

@@ -100,6 +100,14 @@ def test_evaluator_epoch_matches_single_batch(dev, tmp_path):
             continue  # the epoch loss is a graph-weighted mean of per-batch means over VALID graphs: batching-dependent
         assert abs(res["metrics"][k] - v) < 1e-6, k
     # topic ablation + feature metrics: a second metric set under test/ablate_topic/, features/* keys, batch left intact
+    # overlap_metrics (default): loss scalars and ranking metrics of a batch run on a side stream under the next batch's forward.
+    # Same kernels on the same inputs, per-batch totals added in batch order: the epoch's numbers must be IDENTICAL to the
+    # one-stream evaluation, over several passes (buffers recycled by the allocator between batches would show up here)
+    for bs in (3, 5):
+        serial = RetrieverEvaluator(model, k_values=[1, 5, 20], bridge_metrics=True, overlap_metrics=False).run(pd.PackedLoader(ds, batch_size=bs))
+        for _ in range(3):
+            over = RetrieverEvaluator(model, k_values=[1, 5, 20], bridge_metrics=True).run(pd.PackedLoader(ds, batch_size=bs))
+            assert over["metrics"] == serial["metrics"] and over["num_graphs"] == serial["num_graphs"]
     ab = RetrieverEvaluator(model, k_values=[1, 5], ablate_topic=True, feature_metrics=True).run(pd.PackedLoader(ds, batch_size=5))
     keys = ab["metrics"]
     assert "test/ablate_topic/edge/recall@5" in keys and "test/features/norm_avg" in keys and keys["test/features/norm_avg"] > 0
