@@ -931,6 +931,11 @@ static int tn_gemm(const float* A, int M, const float* Bm, int N, int64_t K, flo
         if (!accumulate) hipLaunchKernelGGL(k_zero_f32, dim3(64), dim3(256), 0, st, C, (int64_t)M * N);
         return EVI_OK;
     }
+    if (K <= 64) {  // a handful of rows: exact f32, one launch (k_gemm_tn_small)
+        hipLaunchKernelGGL(k_gemm_tn_small, dim3((unsigned)((N + 255) / 256), (unsigned)M), dim3(256), 0, st, A, M, Bm, N, (int)K, C, accumulate ? 1 : 0);
+        EVI_LAUNCH_CHECK();
+        return EVI_OK;
+    }
     const int64_t Kp = (K + 31) / 32 * 32;
     float* part = reinterpret_cast<float*>(ws + L.tnpart);
     if (!use_f32_gemm()) {

@@ -284,6 +284,20 @@ __global__ void k_act_bwd(float* __restrict__ dY, const float* __restrict__ Y, i
     dY[i] = g;
 }
 
+// C [M, N] (+)= A^T B for a handful of rows (K <= 64: the question-side weight gradients sum over the B questions of a batch, the
+// non-text embedding's over one row): exact f32 FMAs in row order, one thread per output element, coalesced over n — the split-K
+// TN kernel and its reduction launch cost 35 us for the same 19 MFLOP.
+__global__ void k_gemm_tn_small(const float* __restrict__ A, int M, const float* __restrict__ B, int N, int K, float* __restrict__ C,
+                                int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(A[(int64_t)k * M + m], B[(int64_t)k * N + n], acc);
+    float* c = C + (int64_t)m * N + n;
+    *c = accumulate ? *c + acc : acc;
+}
+
 // The node side's three elementwise passes over [N, D] in one (float4 per thread): g = dNR + add (the Wc path joins the gathered
 // gradients); kept[v] = g where ids[v] == 0 else 0 (the rows the non-text embedding replaced: its gradient is their column sum);
 // dNR[v] = 0 where ids[v] == 0, else g * (1 - y^2) (tanh backward through entity_proj, y = node_repr).
