@@ -46,7 +46,8 @@ class EviRetrieverBatch(Structure):
                 ("question_emb", c_void_p), ("node_embeddings", c_void_p), ("node_embedding_ids", c_void_p),
                 ("edge_embeddings", c_void_p), ("edge_attr", c_void_p), ("num_relations", c_int64),
                 ("topic_one_hot", c_void_p), ("topic_stride", c_int), ("edge_bias", c_void_p),
-                ("dropout_p", ctypes.c_float), ("dropout_seed", ctypes.c_uint64), ("matmul_precision", ctypes.c_int)]
+                ("dropout_p", ctypes.c_float), ("dropout_seed", ctypes.c_uint64), ("matmul_precision", ctypes.c_int),
+                ("relation_rows", c_void_p)]
 
 
 class EviRetrieverOutput(Structure):

@@ -91,6 +91,14 @@ __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// status |= 1 when some edge_attr lies outside [0, R): what k_first_edge_of_relation reports on the gather path, for callers that hand
+// the relation table over (EviRetrieverBatch.relation_rows)
+__global__ void k_check_relation_range(const int64_t* __restrict__ edge_attr, int64_t E, int64_t R, int32_t* __restrict__ status) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t r = edge_attr[e];
+    if (r < 0 || r >= R) atomicOr(status, 1);
+}
 __global__ void k_first_edge_of_relation(const int64_t* __restrict__ edge_attr, int64_t E, int64_t R,
                                          int32_t* __restrict__ first, int32_t* __restrict__ status) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1096,7 +1104,8 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     EVI_REQUIRE(b->edge_index, "Batch missing edge_index required for scoring.");
     EVI_REQUIRE(b->question_emb && b->node_embedding_ids && b->edge_attr,
                 "Batch must provide question_emb, node_embedding_ids, and edge_attr.");
-    EVI_REQUIRE(b->node_embeddings && b->edge_embeddings, "Batch must provide node_embeddings and edge_embeddings.");
+    EVI_REQUIRE(b->node_embeddings && (b->edge_embeddings || (b->relation_rows && b->num_relations > 0 && b->num_relations <= E)),
+                "Batch must provide node_embeddings and edge_embeddings.");
     EVI_REQUIRE(b->topic_one_hot, "topic_one_hot is required for DDE-based structure features.");
     EVI_REQUIRE(b->topic_stride >= 2, "topic_one_hot feature dim %d < num_topics=2", b->topic_stride);
     EVI_REQUIRE(b->node_ptr && b->edge_ptr && b->edge_batch, "evi_retriever_forward: node_ptr/edge_ptr/edge_batch required");
@@ -1140,7 +1149,9 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
     float* gate_q = NF(L.gate_q, NK.gate_q);
     float* bias_q = NF(L.bias_q, NK.bias_q);
     float* rel_repr = NF(L.rel_repr, NK.rel_repr);
-    float* rel_rows = NF(L.rel_rows, NK.rel_rows);
+    // the relation table handed over (relation_rows): its rows ARE the de-duplicated relation rows, nothing is gathered or kept
+    const bool table_given = L.dedupe && b->relation_rows;
+    float* rel_rows = table_given ? const_cast<float*>(b->relation_rows) : NF(L.rel_rows, NK.rel_rows);
     float* ns = nkeep ? NF(0, NK.ns) : (out->node_struct ? out->node_struct : F32(L.ns));
     int32_t *in_ptr = NI(L.in_ptr, NK.in_ptr), *in_nbr = NI(L.in_nbr, NK.in_nbr), *in_eid = NI(L.in_eid, NK.in_eid);
     int32_t *out_ptr = NI(L.out_ptr, NK.out_ptr), *out_nbr = NI(L.out_nbr, NK.out_nbr), *out_eid = NI(L.out_eid, NK.out_eid);
@@ -1168,11 +1179,15 @@ static int retriever_run(const EviRetrieverWeights* w, const EviRetrieverBatch* 
         // host mirror: Retriever.check_deferred), else into a scratch word nobody reads
         int32_t* status = out->status ? out->status : I32(L.status);
         if (!out->status) EVI_HIP_CHECK(hipMemsetAsync(status, 0, 4, st));
-        hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, first, R, 0x7FFFFFFF);
-        hipLaunchKernelGGL(k_first_edge_of_relation, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr,
-                           E, R, first, status);
-        hipLaunchKernelGGL(k_gather_relation_rows, dim3((unsigned)R), dim3(256), 0, st, b->edge_embeddings, first, D,
-                           rel_rows);
+        if (table_given) {
+            hipLaunchKernelGGL(k_check_relation_range, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr, E, R, status);
+        } else {
+            hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, first, R, 0x7FFFFFFF);
+            hipLaunchKernelGGL(k_first_edge_of_relation, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, b->edge_attr,
+                               E, R, first, status);
+            hipLaunchKernelGGL(k_gather_relation_rows, dim3((unsigned)R), dim3(256), 0, st, b->edge_embeddings, first, D,
+                               rel_rows);
+        }
         EVI_LAUNCH_CHECK();
         if ((rc = scorer_gemm(rel_rows, R, D, D, w->relation_w, D, D, w->relation_b, 1, rel_repr, D, wsplit, st, planes(PL.p_rel)))) return rc;
     } else {

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import logging
 from pathlib import Path
+from types import SimpleNamespace
 from typing import Optional, Union
 
 import torch
@@ -43,6 +44,20 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor, *, status: Optional[torc
     if not deferred and int(status.item()) != 0:
         raise IndexError(f"index out of range in gather_rows: table has {table.size(0)} rows")
     return out
+
+
+class LazyEdgeEmbeddings(SimpleNamespace):
+    """A batch namespace whose `edge_embeddings` ([E, D] = relation_table[edge_attr], what the reference's collater attaches) is
+    gathered on first read and then kept: `getattr`, `hasattr` and plain attribute access all see it."""
+
+    def __getattr__(self, name):  # only reached when the attribute is not set
+        if name == "edge_embeddings":
+            fn = self.__dict__.get("_edge_embeddings_fn")
+            if fn is not None:
+                value = fn()
+                self.__dict__["edge_embeddings"] = value
+                return value
+        raise AttributeError(name)
 
 
 class GlobalEmbeddingStore:
@@ -121,8 +136,16 @@ class GlobalEmbeddingStore:
                 self._deferred_status = torch.zeros(1, dtype=torch.int32, device=self.device)
             status = self._deferred_status
         batch.node_embeddings = self.get_entity_embeddings(torch.as_tensor(batch.node_embedding_ids), status=status)
-        batch.edge_embeddings = self.get_relation_embeddings(torch.as_tensor(batch.edge_attr), status=status)
+        # the relation table itself rides along: a consumer that projects each relation once (Retriever with relation
+        # de-duplication) reads it instead of the [E, D] per-edge gather ...
+        batch.relation_embedding_table = self.relation_embeddings
         batch.num_relations = int(self.relation_embeddings.size(0))
+        if isinstance(batch, LazyEdgeEmbeddings):
+            # ... which a batch of that type performs only when `edge_embeddings` is actually read (400 MB per WebQSP batch of 32)
+            edge_attr = torch.as_tensor(batch.edge_attr)
+            batch.__dict__["_edge_embeddings_fn"] = lambda: self.get_relation_embeddings(edge_attr, status=status)
+        else:
+            batch.edge_embeddings = self.get_relation_embeddings(torch.as_tensor(batch.edge_attr), status=status)
 
     def raise_if_failed(self) -> None:
         """Reports an out-of-range id seen by any deferred gather since the last call."""

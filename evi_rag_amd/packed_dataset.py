@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
+from .embedding_store import LazyEdgeEmbeddings
 
 FORMAT_VERSION = 1
 
@@ -194,7 +195,7 @@ class PackedRetrievalDataset:
                                                    ids.data_ptr(), B, out_ptr[fam].data_ptr(),
                                                    add.data_ptr() if add is not None else None, dst.data_ptr(), st))
             got[key] = dst
-        b = SimpleNamespace()
+        b = LazyEdgeEmbeddings()  # a SimpleNamespace whose [E, D] edge_embeddings are gathered only if somebody reads them
         b.edge_index = torch.stack([got.pop("edge_src"), got.pop("edge_dst")]).contiguous()
         for key, val in got.items():
             setattr(b, key, val)

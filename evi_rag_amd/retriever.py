@@ -270,7 +270,9 @@ class Retriever(nn.Module):
         b.edge_index, b.node_ptr = pack["edge_index"].data_ptr(), pack["node_ptr"].data_ptr()
         b.edge_ptr, b.edge_batch = pack["edge_ptr"].data_ptr(), pack["edge_batch"].data_ptr()
         b.question_emb, b.node_embeddings = pack["question_emb"].data_ptr(), pack["node_embeddings"].data_ptr()
-        b.node_embedding_ids, b.edge_embeddings = pack["node_embedding_ids"].data_ptr(), pack["edge_embeddings"].data_ptr()
+        b.node_embedding_ids = pack["node_embedding_ids"].data_ptr()
+        b.edge_embeddings = pack["edge_embeddings"].data_ptr() if pack["edge_embeddings"] is not None else None
+        b.relation_rows = pack["relation_rows"].data_ptr() if pack.get("relation_rows") is not None else None
         b.edge_attr, b.num_relations = pack["edge_attr"].data_ptr(), pack["num_relations"]
         b.topic_one_hot, b.topic_stride = pack["topic_one_hot"].data_ptr(), int(pack["topic_one_hot"].size(1))
         b.edge_bias = pack["edge_bias"].data_ptr() if pack["edge_bias"] is not None else None
@@ -433,8 +435,18 @@ class Retriever(nn.Module):
         if question_emb is None or node_embedding_ids is None or edge_attr is None:
             raise ValueError("Batch must provide question_emb, node_embedding_ids, and edge_attr.")
         node_embeddings = getattr(batch, "node_embeddings", None)
-        edge_embeddings = getattr(batch, "edge_embeddings", None)
-        if node_embeddings is None or edge_embeddings is None:
+        # A loader that knows the relation TABLE (GlobalEmbeddingStore.attach) hands it over as `relation_embedding_table` [R, D] and
+        # leaves `edge_embeddings` (= table[edge_attr], [E, D]) to be gathered only if somebody asks for it: with relation
+        # de-duplication on, the forward wants one row per relation, which the table already is.
+        relation_rows = None
+        table = getattr(batch, "relation_embedding_table", None) if self.dedupe_relations else None
+        if table is not None and getattr(batch, "num_relations", None) is not None:
+            t = torch.as_tensor(table)
+            R_hint = int(batch.num_relations)
+            if t.dim() == 2 and t.size(0) == R_hint and t.size(1) == self.emb_dim and 0 < R_hint <= int(edge_index.size(1)):
+                relation_rows = t
+        edge_embeddings = None if relation_rows is not None else getattr(batch, "edge_embeddings", None)
+        if node_embeddings is None or (edge_embeddings is None and relation_rows is None):
             raise ValueError("Batch must provide node_embeddings and edge_embeddings.")
         topic_one_hot = getattr(batch, "topic_one_hot", None)
         if topic_one_hot is None:
@@ -447,7 +459,9 @@ class Retriever(nn.Module):
 
         f32 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()  # noqa: E731
         i64 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.long, non_blocking=True).contiguous()  # noqa: E731
-        question_emb, node_embeddings, edge_embeddings = f32(question_emb), f32(node_embeddings), f32(edge_embeddings)
+        question_emb, node_embeddings = f32(question_emb), f32(node_embeddings)
+        edge_embeddings = f32(edge_embeddings) if edge_embeddings is not None else None
+        relation_rows = f32(relation_rows) if relation_rows is not None else None
         node_embedding_ids, edge_attr, node_ptr = i64(node_embedding_ids).view(-1), i64(edge_attr).view(-1), i64(node_ptr).view(-1)
         topic_one_hot = f32(topic_one_hot)
         if topic_one_hot.dim() == 1:
@@ -469,6 +483,8 @@ class Retriever(nn.Module):
             )
         for name, t, rows in (("question_emb", question_emb, B), ("node_embeddings", node_embeddings, N),
                               ("edge_embeddings", edge_embeddings, E)):
+            if t is None:
+                continue
             if t.dim() != 2 or t.size(0) != rows or t.size(1) != D:
                 raise ValueError(f"{name} must have shape [{rows}, {D}], got {tuple(t.shape)}")
         if node_embedding_ids.numel() != N or edge_attr.numel() != E:
@@ -508,7 +524,7 @@ class Retriever(nn.Module):
 
         pack = dict(N=N, E=E, B=B, dev=dev, edge_index=edge_index, node_ptr=node_ptr, edge_ptr=edge_ptr, edge_batch=edge_batch,
                     question_emb=question_emb, node_embeddings=node_embeddings, node_embedding_ids=node_embedding_ids,
-                    edge_embeddings=edge_embeddings, edge_attr=edge_attr, num_relations=num_relations,
+                    edge_embeddings=edge_embeddings, relation_rows=relation_rows, edge_attr=edge_attr, num_relations=num_relations,
                     topic_one_hot=topic_one_hot,
                     edge_bias=self._compute_hide_seek_bias(batch, edge_index=edge_index),  # None unless apply_in_eval
                     want_features=return_features or self.emit_edge_embeddings)

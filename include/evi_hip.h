@@ -583,7 +583,7 @@ typedef struct EviRetrieverBatch {
     const float* question_emb;          /* [B, D] */
     const float* node_embeddings;       /* [N, D] */
     const int64_t* node_embedding_ids;  /* [N], 0 = non-text entity */
-    const float* edge_embeddings;       /* [E, D] (= relation_table[edge_attr]) */
+    const float* edge_embeddings;       /* [E, D] (= relation_table[edge_attr]); NULL allowed with relation_rows (below) */
     const int64_t* edge_attr;           /* [E] relation ids */
     int64_t num_relations;  /* if 0 < num_relations <= E: every edge_attr < num_relations and equal ids
                                carry equal edge_embeddings rows, so each relation is projected once;
@@ -609,6 +609,10 @@ typedef struct EviRetrieverBatch {
                                          * to f16 (2^-12 relative: four times finer than the TF32 rounding of both operands
                                          * the reference's CUDA run applies, configs/extras/default.yaml:11); two thirds of
                                          * the matrix work of 0; operands must stay inside f16's range (|x| < 65 504) */
+    const float* relation_rows;         /* [num_relations, D] or NULL: the relation table itself (row r = the embedding every edge
+                                         * with edge_attr == r carries).  With it and 0 < num_relations <= E the relation rows are
+                                         * taken from here — edge_embeddings may then be NULL: nobody has to gather [E, D] rows only
+                                         * for this call to find one per relation again */
 } EviRetrieverBatch;
 
 /* RetrieverOutput (src/models/components/retriever.py:80-99); any pointer but logits may be NULL. */
