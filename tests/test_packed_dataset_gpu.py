@@ -138,3 +138,51 @@ def test_deferred_embedding_id_check(dev, tmp_path):
     with pytest.raises(IndexError):
         ds.check_deferred()  # ... but the epoch-end check does
     ds.check_deferred()  # flag cleared
+
+
+def test_relation_table_rides_along_and_edge_embeddings_are_lazy(dev, tmp_path):
+    """`GlobalEmbeddingStore.attach` hands the relation TABLE to the batch; the Retriever (relation de-duplication on) reads one
+    row per relation from it (EviRetrieverBatch.relation_rows) and the [E, D] `edge_embeddings` the reference's collater attaches
+    are gathered only when somebody reads them.  Same outputs as the gathered path; a relation id outside the table is still
+    reported (by the forward's range check instead of the gather's)."""
+    from evi_rag_amd import packed_dataset as pd
+    from evi_rag_amd.embedding_store import GlobalEmbeddingStore
+    from evi_rag_amd.retriever import Retriever
+
+    base, samples, _ = _split(tmp_path, graphs=6, seed=9)
+    rng = np.random.default_rng(3)
+    ent = torch.from_numpy(rng.standard_normal((int(base.node_embedding_ids.max()) + 1, 16)).astype(np.float32))
+    rel = torch.from_numpy(rng.standard_normal((12, 16)).astype(np.float32))
+    store = GlobalEmbeddingStore.from_tensors(ent, rel, device=dev)
+    ds = pd.PackedRetrievalDataset(tmp_path / "split", device=dev, embeddings=store)
+    torch.manual_seed(2)
+    model = Retriever(emb_dim=16, hidden_dim=24).to(dev).eval()
+    batch = ds.collate(list(range(6)))
+    assert "edge_embeddings" not in vars(batch) and batch.relation_embedding_table.shape == (12, 16) and batch.num_relations == 12
+    out = model(batch)
+    assert "edge_embeddings" not in vars(batch)  # the forward did not need them
+    gathered = batch.edge_embeddings              # first read: gathered now, then kept
+    assert "edge_embeddings" in vars(batch) and torch.equal(gathered, rel.to(dev)[batch.edge_attr])
+    # the gathered path (no table on the batch): identical outputs
+    plain = ds.collate(list(range(6)))
+    _ = plain.edge_embeddings
+    del plain.relation_embedding_table
+    ref = model(plain)
+    assert torch.equal(out.logits, ref.logits) and torch.equal(out.edge_embeddings, ref.edge_embeddings)
+    # training: gradients equal too (the relation_proj weight gradient multiplies the table's rows instead of gathered copies)
+    grads = []
+    for b in (ds.collate(list(range(6))), plain):
+        model.differentiable = True
+        model.zero_grad(set_to_none=True)
+        model(b).logits.sum().backward()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters()})
+    model.differentiable = None
+    for n, g in grads[0].items():
+        assert float((g - grads[1][n]).abs().max()) <= 1e-6 * (float(g.abs().max()) + 1e-9) + 1e-8, n
+    # a relation id beyond the table: scored clamped, reported by check_deferred (the reference raises at its gather)
+    bad = ds.collate([0, 1])
+    bad.edge_attr = bad.edge_attr.clone()
+    bad.edge_attr[3] = 12
+    model(bad)
+    with pytest.raises(IndexError):
+        model.check_deferred()
