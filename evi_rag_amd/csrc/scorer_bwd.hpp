@@ -637,30 +637,39 @@ __global__ __launch_bounds__(512) void k_edge_struct_bwd(EdgeBwdArgs b) {
         const int64_t tv = __builtin_amdgcn_readfirstlane((int)a.edge_index[a.E + e]);
         const float* nsh = a.node_struct + hv * half;
         const float* nst = a.node_struct + tv * half;
-#pragma unroll 1
-        for (int out_row = 0; out_row < dirs; ++out_row) {
+        // struct_proj.0 of BOTH directions in one pass over the weights, as the forward does it (every LDS weight row feeds two
+        // accumulators): the per-direction form read the 20 rows twice, and with 12 waves per CU the LDS pipe was as busy as the VALU
+        f4 s2d[2][C4];
+#pragma unroll
+        for (int i = 0; i < C4; ++i) {
+            const int d = 4 * lane + 256 * i;
+            s2d[0][i] = s2d[1][i] = d < D ? ld4(l_b + d) : z4;
+        }
+        for (int j = 0; j < half; ++j) {
+            const float xh = nsh[j], xt = nst[j];
+#pragma unroll
+            for (int i = 0; i < C4; ++i) {
+                const int d = 4 * lane + 256 * i;
+                if (d < D) {
+                    const f4 w1 = ld4(lds_wt + j * D + d), w2 = ld4(lds_wt + (half + j) * D + d);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s2d[0][i][c] = fmaf(w2[c], xt, fmaf(w1[c], xh, s2d[0][i][c]));
+                        s2d[1][i][c] = fmaf(w2[c], xh, fmaf(w1[c], xt, s2d[1][i][c]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int out_row = 0; out_row < 2; ++out_row) {
+            if (out_row >= dirs) continue;
             const int dir = a.dir_fwd ? out_row : 1;
             const int64_t row = (int64_t)out_row * a.e_count + le;
             const float* na = dir == 0 ? nsh : nst;  // first half of the MLP input
             const float* nb = dir == 0 ? nst : nsh;
             f4 s2[C4];
 #pragma unroll
-            for (int i = 0; i < C4; ++i) {
-                const int d = 4 * lane + 256 * i;
-                s2[i] = d < D ? ld4(l_b + d) : z4;
-            }
-            for (int j = 0; j < half; ++j) {
-                const float xa = na[j], xb = nb[j];
-#pragma unroll
-                for (int i = 0; i < C4; ++i) {
-                    const int d = 4 * lane + 256 * i;
-                    if (d < D) {
-                        const f4 w1 = ld4(lds_wt + j * D + d), w2 = ld4(lds_wt + (half + j) * D + d);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) s2[i][c] = fmaf(w2[c], xb, fmaf(w1[c], xa, s2[i][c]));
-                    }
-                }
-            }
+            for (int i = 0; i < C4; ++i) s2[i] = s2d[dir][i];
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < C4; ++i) sum += (4 * lane + 256 * i < D) ? hsum4(s2[i]) : 0.f;
