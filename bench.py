@@ -96,6 +96,7 @@ def parse_args():
     ap.add_argument("--no-labelling", action="store_true",
                     help="with --graph-kernels: skip the shortest-path labelling leg (counter passes: only CSR / DDE / BFS / expansion run)")
     ap.add_argument("--no-graph-eval", action="store_true")
+    ap.add_argument("--eval-shard-questions", type=int, default=256, help="N > 1: questions per rank of the graph_eval_sharded leg")
     ap.add_argument("--no-encode", action="store_true", help="skip the text-encoding leg (random-init BERT + pooling kernel)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the sustained leg and the BASELINE config 3 / 4 / 5 legs of the default line")
@@ -459,7 +460,7 @@ def bench_graph_eval(dev, D, iters=8, warmup=2, graphs=32, nodes=1500, edges=409
     }
 
 
-def bench_eval_pipeline(dev, D, model, *, graphs_total=512, batch_size=32, nodes=1500, edges=4096, relations=4096, passes=2):
+def bench_eval_pipeline(dev, D, model, *, graphs_total=512, batch_size=32, nodes=1500, edges=4096, relations=4096, passes=2, seed=2):
     """End-to-end evaluation epoch over an HBM-resident packed split: device collation, embedding gather,
     Retriever forward, loss, ranking metrics (RetrieverEvaluator.run) — queries/s of the whole per-question
     stage, everything the reference does between its DataLoader and `test/...` metrics.  512 questions = 16 batches per pass
@@ -474,7 +475,7 @@ def bench_eval_pipeline(dev, D, model, *, graphs_total=512, batch_size=32, nodes
 
     num_entities = 1 << 17
     sb = synthetic.make_batch(graphs_total, nodes_per_graph=nodes, edges_per_graph=edges, emb_dim=D, num_relations=relations,
-                              num_entities=num_entities, seed=2, attach_embeddings=False)
+                              num_entities=num_entities, seed=seed, attach_embeddings=False)
     tmp = tempfile.mkdtemp(prefix="evi_packed_")
     try:
         pd.write_packed(tmp, pd.samples_from_flat_batch(sb))
@@ -495,6 +496,38 @@ def bench_eval_pipeline(dev, D, model, *, graphs_total=512, batch_size=32, nodes
                 "loss": best["metrics"]["test/loss"], "reachability@100": best["metrics"].get("test/answer/reachability@100")}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def bench_eval_sharded(ctx, D, *, graphs_per_rank=256, seed_base=20):
+    """N > 1: the per-question stage sharded by QUESTION (second bullet): graphs are independent, so every rank
+    evaluates its own share (here: its own synthetic split of `graphs_per_rank` questions, embedding tables replicated in its
+    HBM) with no exchange inside the epoch, and the epoch's counters are summed with ONE small all-reduce (the reference's
+    dist_reduce_fx="sum").  Weak scaling by construction: value = all ranks' questions / the slowest rank's seconds.
+    Every rank returns; rank 0's result goes into the JSON line.  A rank whose local epoch fails says so and ALL ranks skip the
+    collectives together (ctx.agree) — the leg never leaves a rank waiting."""
+    from evi_rag_amd.retriever import Retriever
+
+    dev = ctx.dev
+    local, err = None, None
+    try:
+        torch.manual_seed(0)
+        model = Retriever(emb_dim=D, hidden_dim=D).to(dev).eval()
+        local = bench_eval_pipeline(dev, D, model, graphs_total=graphs_per_rank, passes=2, seed=seed_base + ctx.rank)
+    except Exception as exc:  # noqa: BLE001 - reported in the line, the other legs stand
+        err = f"rank {ctx.rank}: {type(exc).__name__}: {exc}"
+    if ctx.agree(err is not None):
+        return {"skipped": err or "another rank's local epoch failed"}
+    secs = graphs_per_rank / local["queries_per_s"]
+    t = torch.tensor([secs, float(graphs_per_rank), (local["reachability@100"] or 0.0) * graphs_per_rank], dtype=torch.float64, device=dev)
+    tmax = t[:1].clone()
+    all_reduce_(tmax, dist.ReduceOp.MAX)
+    all_reduce_(t, dist.ReduceOp.SUM)  # the metric counters' all-reduce: questions and reachability hits over all ranks
+    total_q, slowest = float(t[1].item()), float(tmax[0].item())
+    return {"workload": f"{ctx.world} ranks x {graphs_per_rank} questions (own split per rank, batches of 32, D=H={D}): device collation + "
+                        "embedding gather + Retriever forward + loss + ranking metrics, no exchange inside the epoch; counters summed by one all-reduce",
+            "metric": "queries/sec", "value": total_q / slowest, "unit": "queries/s", "n_gpus": ctx.world, "scaling": "weak",
+            "questions": int(total_q), "slowest_rank_seconds": slowest, "rank0_queries_per_s": local["queries_per_s"],
+            "reachability@100_all_ranks": float(t[2].item()) / max(total_q, 1.0)}
 
 
 def _random_bert(dev, D):
@@ -1645,9 +1678,13 @@ def main():
             warmup=args.warmup, seed=4, fp8_mfma=True,
             workload=f"configs[4]: {args.config4_rows} x 1024 index, OCP e4m3 storage + f32 row scale (bge-large dim), native fp8 "
                      f"MFMA scoring, row-sharded over {world} MI355X + RCCL all-gather merge")
+        torch.cuda.empty_cache()
+        ge = bench_eval_sharded(ctx, args.dim, graphs_per_rank=args.eval_shard_questions) if not args.no_graph_eval else None
         if rank == 0:
             result["config4_sharded"] = c4
             result["config5_sharded"] = c5
+            if ge is not None:
+                result["graph_eval_sharded"] = ge
     if rank == 0:
         D = args.dim
         if extra and not args.no_config4_full:

@@ -156,6 +156,19 @@ def test_bench_two_rank_config4_and_config5_sharded_legs(dev):
 
 
 @pytest.mark.timeout(900)
+def test_bench_two_rank_graph_eval_sharded_leg(dev):
+    """N > 1 also measures the per-question stage sharded by question (graphs never span ranks, counters summed
+    with one all-reduce): every rank evaluates its own split, the line carries the aggregate."""
+    line = _rehearse({}, ["--steps", "3", "--warmup", "1", "--rows", "100001", "--dim", "64", "--k", "20", "--no-cpu-baseline",
+                          "--no-encode", "--config4-rows", "100001", "--eval-shard-questions", "64"])
+    ge = line["graph_eval_sharded"]
+    assert "skipped" not in ge, ge
+    assert ge["n_gpus"] == 2 and ge["questions"] == 128 and ge["scaling"] == "weak" and ge["value"] > 0
+    assert ge["value"] <= 2.0 * ge["rank0_queries_per_s"] * 1.5  # an aggregate of two ranks, not a unit error
+    assert 0.0 <= ge["reachability@100_all_ranks"] <= 1.0
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("where", ["group", "step"])
 def test_bench_two_rank_lane_failure_falls_back_in_process(dev, where):
     """If the lane-1 communicator cannot be created, or the first two-lane step raises, every rank drops IN-PROCESS to the
