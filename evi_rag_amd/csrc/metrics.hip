@@ -318,49 +318,33 @@ __global__ __launch_bounds__(kSelectThreads) void k_retriever_metrics(MetricsArg
 //   acc[4nk+3]          sum of score margins                              acc[4nk+4]   graphs with both classes
 //   acc[4nk+5]          graphs whose answer list exceeded the kernel's capacity (answer_valid == 2)
 // One thread per state walks the graphs in order: a fixed summation order, no atomics.
-__global__ __launch_bounds__(256) void k_metric_accumulate(
+__global__ __launch_bounds__(64) void k_metric_accumulate(
     const float* __restrict__ edge_recall, const uint8_t* __restrict__ recall_valid, const uint8_t* __restrict__ reach,
     const uint8_t* __restrict__ reach_valid, const uint8_t* __restrict__ answer_hit, const float* __restrict__ answer_recall,
     const uint8_t* __restrict__ answer_valid, const float* __restrict__ score_margin, const uint8_t* __restrict__ margin_valid,
     int B, int nk, double* __restrict__ acc) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = 4 * nk + 6;
-    if (s >= total) return;
+    // one WAVE per state: lane l adds the graphs l, l + 64, ... in ascending order, then the 64 partial sums meet in a fixed
+    // butterfly — a fixed summation order without float atomics, and all loads of a state in flight at once (one thread walking
+    // the graphs paid a dependent load per graph: 42 us for 32 graphs)
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
     double sum = 0.0;
-    if (s < nk) {
-        for (int g = 0; g < B; ++g)
-            if (recall_valid[g]) sum += (double)edge_recall[(int64_t)g * nk + s];
-    } else if (s == nk) {
-        for (int g = 0; g < B; ++g) sum += recall_valid[g] ? 1.0 : 0.0;
-    } else if (s < 2 * nk + 1) {
-        const int c = s - nk - 1;
-        for (int g = 0; g < B; ++g)
-            if (reach_valid[g]) sum += (double)reach[(int64_t)g * nk + c];
-    } else if (s == 2 * nk + 1) {
-        for (int g = 0; g < B; ++g) sum += reach_valid[g] ? 1.0 : 0.0;
-    } else if (s < 3 * nk + 2) {
-        const int c = s - 2 * nk - 2;
-        if (answer_valid)
-            for (int g = 0; g < B; ++g)
-                if (answer_valid[g] == 1) sum += (double)answer_hit[(int64_t)g * nk + c];
-    } else if (s < 4 * nk + 2) {
-        const int c = s - 3 * nk - 2;
-        if (answer_valid)
-            for (int g = 0; g < B; ++g)
-                if (answer_valid[g] == 1) sum += (double)answer_recall[(int64_t)g * nk + c];
-    } else if (s == 4 * nk + 2) {
-        if (answer_valid)
-            for (int g = 0; g < B; ++g) sum += answer_valid[g] == 1 ? 1.0 : 0.0;
-    } else if (s == 4 * nk + 3) {
-        for (int g = 0; g < B; ++g)
-            if (margin_valid[g]) sum += (double)score_margin[g];
-    } else if (s == 4 * nk + 4) {
-        for (int g = 0; g < B; ++g) sum += margin_valid[g] ? 1.0 : 0.0;
-    } else {
-        if (answer_valid)
-            for (int g = 0; g < B; ++g) sum += answer_valid[g] == 2 ? 1.0 : 0.0;
-    }
-    acc[s] += sum;
+    auto term = [&](int g) -> double {
+        if (s < nk) return recall_valid[g] ? (double)edge_recall[(int64_t)g * nk + s] : 0.0;
+        if (s == nk) return recall_valid[g] ? 1.0 : 0.0;
+        if (s < 2 * nk + 1) return reach_valid[g] ? (double)reach[(int64_t)g * nk + (s - nk - 1)] : 0.0;
+        if (s == 2 * nk + 1) return reach_valid[g] ? 1.0 : 0.0;
+        if (s < 3 * nk + 2) return (answer_valid && answer_valid[g] == 1) ? (double)answer_hit[(int64_t)g * nk + (s - 2 * nk - 2)] : 0.0;
+        if (s < 4 * nk + 2) return (answer_valid && answer_valid[g] == 1) ? (double)answer_recall[(int64_t)g * nk + (s - 3 * nk - 2)] : 0.0;
+        if (s == 4 * nk + 2) return (answer_valid && answer_valid[g] == 1) ? 1.0 : 0.0;
+        if (s == 4 * nk + 3) return margin_valid[g] ? (double)score_margin[g] : 0.0;
+        if (s == 4 * nk + 4) return margin_valid[g] ? 1.0 : 0.0;
+        return (answer_valid && answer_valid[g] == 2) ? 1.0 : 0.0;
+    };
+    for (int g = lane; g < B; g += 64) sum += term(g);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) acc[s] += sum;
 }
 
 }  // namespace evi
@@ -424,7 +408,7 @@ extern "C" int evi_metric_accumulate(const float* edge_recall, const uint8_t* re
                 "evi_metric_accumulate: null pointer");
     EVI_REQUIRE(!answer_valid || (answer_hit && answer_recall), "evi_metric_accumulate: answer arrays must come together");
     const int total = 4 * num_k + 6;
-    hipLaunchKernelGGL(k_metric_accumulate, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_metric_accumulate, dim3((unsigned)total), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
                        edge_recall, recall_valid, reach, reach_valid, answer_hit, answer_recall, answer_valid, score_margin,
                        margin_valid, B, num_k, acc);
     EVI_LAUNCH_CHECK();
