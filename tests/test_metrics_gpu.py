@@ -203,3 +203,28 @@ def test_compute_ranking_metrics_matches_the_reference_function_and_the_oracle()
     assert got.mrr == pytest.approx(want["mrr"], abs=1e-12)
     with pytest.raises(ValueError, match="length mismatch"):
         M.compute_ranking_metrics([{"scores": torch.zeros(3), "labels": torch.zeros(2)}], ks)
+
+
+def test_metric_collection_over_more_graphs_than_a_wave(dev):
+    """k_metric_accumulate adds one batch's per-graph results into the epoch states with one wave per state (lane l takes graphs
+    l, l + 64, ...): a batch of 150 graphs crosses the wave width; the collection's means must equal the means of rank_batch's
+    per-graph outputs."""
+    from evi_rag_amd import metrics as M
+
+    sb = synthetic.make_batch(150, nodes_per_graph=40, edges_per_graph=90, emb_dim=4, seed=31, attach_embeddings=False, max_answers=6)
+    ns = synthetic.as_namespace(sb, device=dev)
+    ns.answer_entity_ids_ptr = torch.from_numpy(sb.answer_ptr).to(dev)
+    torch.manual_seed(4)
+    scores = torch.randn(sb.num_edges, device=dev) + 1.5 * ns.labels
+    target = ns.labels > 0.5
+    ks = [1, 5, 20]
+    coll = M.RetrieverMetricCollection(ks)
+    for _ in range(2):  # two updates: the states accumulate
+        coll.update(preds=scores, target=target, indexes=None, batch=ns, num_graphs=150)
+    got = {k: float(v) for k, v in coll.compute().items()}
+    rb = M.rank_batch(scores, target, ns, ks, num_graphs=150)
+    rv, hv, av = rb.recall_valid.bool(), rb.reach_valid.bool(), rb.answer_valid == 1
+    for j, k in enumerate(ks):
+        assert got[f"edge/recall@{k}"] == pytest.approx(float(rb.edge_recall[rv, j].double().mean()), abs=1e-6)
+        assert got[f"answer/reachability@{k}"] == pytest.approx(float(rb.reach[hv, j].double().mean()), abs=1e-6)
+        assert got[f"answer_hit@{k}"] == pytest.approx(float(rb.answer_hit[av, j].double().mean()), abs=1e-6)
